@@ -1,0 +1,201 @@
+/*
+ * vaenar_hip.h -- C ABI of libvaenar_hip.so: the MI355X (gfx950) execution engine of the
+ * VAENAR-TTS text->mel path.
+ *
+ * The reference (thuhcsi/VAENAR-TTS) has no native/FFI interface: its operator API for this
+ * path is the Python call surface models.VAENAR / modules.* executed by TensorFlow ops.  Each
+ * entry point below therefore names the reference *Python* interface it replaces (file:line
+ * under /root/reference).  The Python mirror of that surface lives in vaenar_tts_amd/ and
+ * binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative vnr_status; the message is available
+ *     from vnr_last_error(handle) (or vnr_last_error(NULL) when no handle exists yet);
+ *   - no exception crosses the ABI, no torch/TF types appear in a signature;
+ *   - pointers named d_* are DEVICE pointers obtained from vnr_malloc (plain hipMalloc memory
+ *     on the handle's device); pointers named h_* / host are caller-owned host memory;
+ *   - tensors are fp32 row-major [batch, time, channels]; lengths are int32 [batch];
+ *   - one handle = one device = one HIP stream; a handle is not thread-safe, different
+ *     handles are independent (one per GPU process for data parallelism);
+ *   - all module calls are asynchronous on the handle's stream; vnr_memcpy_d2h and
+ *     vnr_synchronize are the synchronisation points.
+ */
+#ifndef VAENAR_HIP_H
+#define VAENAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNR_ABI_VERSION 1
+
+typedef struct vnr_context *vnr_handle;
+
+typedef enum vnr_status {
+  VNR_OK = 0,
+  VNR_ERR_ARG = -1,        /* bad argument / unsupported shape */
+  VNR_ERR_HIP = -2,        /* a HIP runtime call failed */
+  VNR_ERR_WEIGHT = -3,     /* unknown weight path, shape mismatch, or weights not finalized */
+  VNR_ERR_NOMEM = -4,
+  VNR_ERR_STATE = -5
+} vnr_status;
+
+enum { VNR_ACT_IDENTITY = 0, VNR_ACT_RELU = 1, VNR_ACT_TANH = 2 };
+
+/* Hyper-parameters read by the reference constructor models/models.py:10-65
+ * (values: configs/hparams.py:233-348).  The engine requires head width 64
+ * (attention_dim / heads), odd conv kernels and channel counts divisible by 4. */
+typedef struct vnr_config {
+  int32_t abi_version;                 /* = VNR_ABI_VERSION */
+  /* Common (hparams.py:284-289) */
+  int32_t latent_dim, output_dim, max_reduction_factor, num_mels;
+  /* Encoder.Transformer (hparams.py:291-306) */
+  int32_t enc_vocab_size, enc_embd_dim, enc_n_conv, enc_pre_hidden, enc_conv_kernel,
+          enc_pre_activation, enc_bn_before_act, enc_n_blk, enc_attention_dim,
+          enc_attention_heads, enc_ffn_hidden;
+  float   enc_attention_temperature;
+  /* Decoder.Transformer (hparams.py:308-321) */
+  int32_t dec_nblk, dec_attention_dim, dec_attention_heads, dec_ffn_hidden, dec_post_n_conv,
+          dec_post_conv_filters, dec_post_conv_kernel;
+  float   dec_attention_temperature;
+  /* Prior.Transformer (hparams.py:336-344) */
+  int32_t prior_n_blk, prior_n_transformer_blk, prior_attention_dim, prior_attention_heads,
+          prior_ffn_hidden;
+  float   prior_temperature;
+  /* Posterior.Transformer (hparams.py:323-334) */
+  int32_t post_pre_hidden, post_pre_activation, post_nblk, post_attention_dim,
+          post_attention_heads, post_ffn_hidden;
+  float   post_temperature;
+  /* LengthPredictor.Dense (hparams.py:346-348) */
+  int32_t lenpred_activation;
+} vnr_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+/* replaces VAENAR.__init__ (models/models.py:10-65): builds the engine for one device. */
+int vnr_create(const vnr_config *cfg, int device, vnr_handle *out);
+int vnr_destroy(vnr_handle h);
+const char *vnr_last_error(vnr_handle h);
+int vnr_abi_version(void);
+int vnr_device_count(int *count);
+/* name, CU count and wavefront size of the handle's device (name buffer >= 64 bytes) */
+int vnr_device_info(vnr_handle h, char *name, int name_len, int *compute_units, int *wavefront);
+
+/* ---- device memory (plumbing) ---------------------------------------------------------- */
+int vnr_malloc(vnr_handle h, size_t bytes, void **d_ptr);
+int vnr_free(vnr_handle h, void *d_ptr);
+int vnr_memcpy_h2d(vnr_handle h, void *d_dst, const void *h_src, size_t bytes);
+int vnr_memcpy_d2h(vnr_handle h, void *h_dst, const void *d_src, size_t bytes); /* syncs */
+int vnr_memcpy_d2d(vnr_handle h, void *d_dst, const void *d_src, size_t bytes);
+int vnr_memset(vnr_handle h, void *d_dst, int value, size_t bytes);
+int vnr_synchronize(vnr_handle h);
+
+/* ---- weights ---------------------------------------------------------------------------- */
+/* replaces tf.train.Checkpoint(model=model).restore (inference.py:122-123): one call per
+ * variable of the object-graph tree, path e.g. "decoder/attentions/0/att_proj1/kernel"
+ * (vaenar_tts_amd/weights.py lists all paths).  The data is copied. */
+int vnr_set_weight(vnr_handle h, const char *path, const float *host, const int64_t *shape,
+                   int ndim);
+/* reads a variable back (model.trainable_variables / checkpoint save, train.py:246-255) */
+int vnr_get_weight(vnr_handle h, const char *path, float *host, int64_t count);
+/* packs the weights for the kernels (transposed [out][in] panels, fused QKV / K|V panels,
+ * ActNorm o InvertibleLinear folding (flow.py:166-175 + 123-135), BN inference affine
+ * (utils.py:76-85)).  Must be called after the last vnr_set_weight and again after any
+ * weight update. */
+int vnr_finalize_weights(vnr_handle h);
+
+/* ---- modules: the reference call surface -------------------------------------------------- */
+/* TransformerEncoder.call (modules/encoder.py:79-93), training=False.
+ * d_ids [B,T] int32, d_lengths [B] int32 -> d_out [B,T,enc_pre_hidden]. */
+int vnr_text_encoder_fwd(vnr_handle h, const int32_t *d_ids, const int32_t *d_lengths, int B,
+                         int T, float pos_step, float *d_out);
+/* DenseLengthPredictor.call (modules/length_predictor.py:35-42): d_out [B] float. */
+int vnr_length_predictor_fwd(vnr_handle h, const float *d_text_embd, const int32_t *d_lengths,
+                             int B, int T, float *d_out);
+/* TransformerPrior.sample (modules/prior.py:154-169).  d_eps [B,Tz,latent] is the initial
+ * noise already multiplied by the temperature (prior.py:35); NULL = zeros (temperature 0,
+ * inference.py:95).  d_z [B,Tz,latent]; d_logprobs [B] may be NULL. */
+int vnr_prior_sample(vnr_handle h, const int32_t *d_z_lengths, const float *d_text_embd,
+                     const int32_t *d_text_lengths, int B, int Tz, int Tt, const float *d_eps,
+                     float *d_z, float *d_logprobs);
+/* TransformerDecoder.call (modules/decoder.py:181-199), training=False.
+ * d_initial, d_outputs [B, Tz*rf, output_dim]; d_alignments NULL or
+ * [dec_nblk][B, heads, Tz, Tt] (the dict decoder-attention-{i}, decoder.py:172,192). */
+int vnr_decoder_fwd(vnr_handle h, const float *d_z, const float *d_text_embd,
+                    const int32_t *d_z_lengths, const int32_t *d_text_lengths, int B, int Tz,
+                    int Tt, int reduction_factor, float *d_initial, float *d_outputs,
+                    float *d_alignments);
+/* TransformerPosterior.call (modules/posterior.py:115-130), training=False (no dropout).
+ * d_mels [B,Tz,num_mels] -> d_mu, d_logvar [B,Tz,latent] in the reference's RETURN order
+ * (mu_projection output first). */
+int vnr_posterior_fwd(vnr_handle h, const float *d_mels, const float *d_text_embd,
+                      const int32_t *d_text_lengths, const int32_t *d_target_lengths, int B,
+                      int Tz, int Tt, float *d_mu, float *d_logvar);
+/* VAENAR.inference (models/models.py:199-210): encoder -> prior.sample -> decoder on one
+ * stream, no host synchronisation.  d_reduced_lengths = ceil(mel_lengths / rf) (models.py:200),
+ * Tz = max of them.  d_mel [B, Tz*rf, output_dim]; d_alignments as vnr_decoder_fwd;
+ * d_text_embd_out NULL or [B,Tt,enc_pre_hidden]. */
+int vnr_inference(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
+                  const int32_t *d_reduced_lengths, int B, int Tt, int Tz, int reduction_factor,
+                  float pos_step, const float *d_eps, float *d_mel, float *d_alignments,
+                  float *d_text_embd_out);
+
+/* ---- single operators (kernel-level parity tests and micro-benchmarks) ---------------------- */
+/* tf.keras.layers.Dense on [M,K] (+ optional second input panel = tf.concat on the last axis,
+ * attention.py:410-412,440-449): C = epilogue(A1.W[0:K1] + A2.W[K1:K] + bias).
+ * d_w is the Keras kernel [K,N] row-major.  Epilogue order: +bias -> activation ->
+ * *bn_scale+bn_shift -> +pe_weight*pe[m % pe_T] -> +residual -> LayerNorm(gamma,beta,eps 1e-3).
+ * Any optional pointer may be NULL. */
+typedef struct vnr_dense_desc {
+  const float *d_a1; int32_t lda1; int32_t k1;
+  const float *d_a2; int32_t lda2; int32_t k2;
+  const float *d_w;                       /* [k1+k2, n] */
+  const float *d_bias;                    /* [n] */
+  int32_t activation;
+  const float *d_residual; int32_t ldr;   /* [m, n] */
+  const float *d_ln_gamma, *d_ln_beta;    /* [n] */
+  const float *d_pe; int32_t pe_T; float pe_weight;   /* [pe_T, n] */
+  float *d_c; int32_t ldc;
+  int32_t m, n;
+} vnr_dense_desc;
+int vnr_op_dense(vnr_handle h, const vnr_dense_desc *desc);
+/* modules/utils.py Conv1D.call (:76-85) at inference: Conv1D(k, 'same') + bias -> activation
+ * -> BatchNormalization(moving stats) (bn_before_act=0) or BN -> activation (=1).
+ * d_x [B,T,Cin], d_kernel [k,Cin,Cout] (Keras), bn vectors [Cout] -> d_y [B,T,Cout]. */
+int vnr_op_conv1d_bn(vnr_handle h, const float *d_x, int B, int T, int Cin, const float *d_kernel,
+                     int k, int Cout, const float *d_bias, int activation, int bn_before_act,
+                     const float *d_gamma, const float *d_beta, const float *d_mean,
+                     const float *d_var, float *d_y);
+/* MultiHeadScaledProductAttention.call core (modules/attention.py:224-246) on projected
+ * Q [B,Tq,H*64], K/V [B,Tk,H*64] (row strides ldq/ldk/ldv floats): masked softmax(QK^T /
+ * sqrt(64) / temperature) V with key AND query length masks (NULL = full) and optional causal
+ * mask; masked logits are filled with -2^32 (attention.py:240).  d_ctx [B,Tq,H*64] (stride ldo);
+ * d_alignments NULL or [B,H,Tq,Tk]. */
+int vnr_op_attention(vnr_handle h, const float *d_q, int ldq, const float *d_k, int ldk,
+                     const float *d_v, int ldv, const int32_t *d_q_lengths,
+                     const int32_t *d_k_lengths, int B, int H, int Tq, int Tk, int causal,
+                     float temperature, float *d_ctx, int ldo, float *d_alignments);
+/* tf.keras.layers.LayerNormalization() over the last axis (eps 1e-3): rows x dim. */
+int vnr_op_layer_norm(vnr_handle h, const float *d_x, const float *d_gamma, const float *d_beta,
+                      int rows, int dim, float *d_y);
+/* PositionalEncoding.positional_encoding (modules/utils.py:333-355): d_out [T,dim]. */
+int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *d_out);
+
+/* ---- instrumentation ------------------------------------------------------------------------ */
+/* When enabled every kernel launch is bracketed by HIP events on the handle's stream and
+ * accumulated per kernel class ("gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm",
+ * "misc").  vnr_profile_get synchronises.  flops/bytes are the ALGORITHMIC counts of the
+ * launches (2*M*N*K per GEMM; Q+K+V+ctx(+alignments) bytes per attention). */
+int vnr_profile_enable(vnr_handle h, int on);
+int vnr_profile_reset(vnr_handle h);
+int vnr_profile_get(vnr_handle h, const char *kernel_class, double *total_ms, int64_t *launches,
+                    double *flops, double *bytes);
+/* number of kernel launches issued since creation (all classes) */
+int vnr_launch_count(vnr_handle h, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAENAR_HIP_H */

@@ -1,0 +1,156 @@
+"""Module- and model-level parity of the HIP path (through the Python mirror of the reference call
+surface -> ctypes -> C ABI) against the float64 NumPy oracle on the same seeded inputs.
+
+north_star tolerance: mels within 1e-3 max-abs (fp32), integer frame counts bit-exact.
+Observed differences are ~1e-5; the asserts use 2e-4 so that a real regression is caught long
+before the contractual 1e-3."""
+import numpy as np
+import pytest
+
+from oracle.vaenar_numpy import Oracle
+from vaenar_tts_amd.configs import LJHPS, tiny_hps
+from vaenar_tts_amd.models import VAENAR
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights
+
+pytestmark = pytest.mark.gpu
+
+MEL_TOL = 2e-4          # asserted; contract is 1e-3
+CONTRACT_TOL = 1e-3
+
+
+def _setup(name):
+    hps = tiny_hps() if name == "tiny" else LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    model = VAENAR(hps, weights=w)
+    oracle = Oracle(hps, w, np.float64)
+    return hps, model, oracle
+
+
+@pytest.fixture(scope="module", params=["tiny", "lj"])
+def setup(request):
+    hps, model, oracle = _setup(request.param)
+    yield request.param, hps, model, oracle
+    model.engine.close()
+
+
+def _batch(hps, name, temperature=1.0):
+    if name == "tiny":
+        return make_batch(3, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size,
+                          latent_dim=hps.Common.latent_dim, ragged=True, temperature=temperature,
+                          text_step=3, mel_step=7)
+    return make_batch(4, 37, 150, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                      ragged=True, temperature=temperature, text_step=5, mel_step=23)
+
+
+def test_text_encoder_and_length_predictor(setup):
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    pos_step = np.float32(hps.Common.mel_text_len_ratio) / np.float32(2)
+    got = model.text_encoder(b["ids"], b["text_lengths"], pos_step=pos_step, training=False)
+    ref = oracle.text_encoder(b["ids"], b["text_lengths"], pos_step=pos_step)
+    np.testing.assert_allclose(got.numpy(), ref, atol=1e-4, rtol=0)
+    # length predictor on the GPU's own encoding, compared with the oracle on the oracle's encoding
+    pl = model.length_predictor(got, b["text_lengths"]).numpy()
+    rl = oracle.length_predictor(ref, b["text_lengths"])
+    np.testing.assert_allclose(pl, rl, rtol=2e-5)
+    # integer frame counts (inference.py:135): bit-exact whenever the oracle is not within the fp32
+    # noise band of an integer boundary
+    margin = np.minimum(rl - np.floor(rl), np.ceil(rl) - rl)
+    safe = margin > 1e-3 * np.maximum(1.0, rl) * 1e-1
+    assert np.array_equal(pl.astype(np.int32)[safe], rl.astype(np.float32).astype(np.int32)[safe])
+    assert safe.sum() >= 1
+
+
+def test_prior_sample(setup):
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    rf = 2
+    reduced = (b["mel_lengths"] + rf - 1) // rf
+    pos_step = np.float32(hps.Common.mel_text_len_ratio) / np.float32(rf)
+    text_embd = oracle.text_encoder(b["ids"], b["text_lengths"], pos_step=pos_step)
+    z, logp = model.prior.sample(reduced, text_embd.astype(np.float32), b["text_lengths"], training=False,
+                                 eps=b["eps"])
+    rz, rlogp = oracle.prior_sample(reduced, text_embd.astype(np.float32).astype(np.float64), b["text_lengths"],
+                                    b["eps"])
+    np.testing.assert_allclose(z.numpy(), rz, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(logp.numpy(), rlogp, rtol=2e-5, atol=1e-2)
+    # temperature 0 (inference.py:95 default): eps = None means exact zeros
+    z0, _ = model.prior.sample(reduced, text_embd.astype(np.float32), b["text_lengths"], temperature=0.0)
+    rz0, _ = oracle.prior_sample(reduced, text_embd.astype(np.float32).astype(np.float64), b["text_lengths"],
+                                 np.zeros_like(b["eps"]))
+    np.testing.assert_allclose(z0.numpy(), rz0, atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("rf", [2, 5])
+def test_decoder(setup, rf):
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    r = np.random.Generator(np.random.PCG64(7))
+    reduced = (b["mel_lengths"] + rf - 1) // rf
+    Tz = int(reduced.max())
+    z = r.standard_normal((len(reduced), Tz, hps.Common.latent_dim)).astype(np.float32)
+    mem = r.standard_normal((len(reduced), b["ids"].shape[1], hps.Encoder.Transformer.pre_hidden)).astype(np.float32)
+    ini, out, ali = model.decoder(z, mem, reduced, b["text_lengths"], reduction_factor=rf, training=False)
+    rini, rout, rali = oracle.decoder(z.astype(np.float64), mem.astype(np.float64), reduced, b["text_lengths"], rf)
+    np.testing.assert_allclose(ini.numpy(), rini, atol=MEL_TOL, rtol=0)
+    np.testing.assert_allclose(out.numpy(), rout, atol=MEL_TOL, rtol=0)
+    assert sorted(ali.keys()) == sorted(rali.keys())
+    for k in rali:
+        np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("temperature", [0.0, 1.0])
+def test_inference_matches_oracle(setup, fused, temperature):
+    """VAENAR.inference (models.py:199-210) end to end on a ragged batch; padded rectangle included."""
+    name, hps, model, oracle = setup
+    b = _batch(hps, name, temperature)
+    eps = b["eps"] if temperature else None
+    mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=eps,
+                               temperature=temperature, fused=fused)
+    rmel, rali = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+    got = mel.numpy()
+    err_all = np.abs(got - rmel).max()
+    valid = np.arange(got.shape[1])[None, :] < b["mel_lengths"][:, None]
+    err_valid = np.abs(got - rmel)[valid].max()
+    print(f"[{name}] fused={fused} T={temperature} max-abs mel err: valid {err_valid:.3e} rectangle {err_all:.3e}")
+    assert err_all < MEL_TOL < CONTRACT_TOL
+    for k in rali:
+        np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+
+
+def test_test_step_frame_counts(setup):
+    """inference.py:128-143: length predictor -> int32 trunc -> +80 -> ceil(/2) -> prior -> decoder."""
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    rf = hps.Common.final_reduction_factor
+    pos_step = np.float32(model.mel_text_len_ratio) / np.float32(rf)
+    text_embd = model.text_encoder(b["ids"], b["text_lengths"], pos_step=pos_step, training=False)
+    pred = model.length_predictor(text_embd, b["text_lengths"], training=False).numpy()
+    pred_ml = pred.astype(np.int32)
+    reduced = (pred_ml + 80 + rf - 1) // rf
+    z, _ = model.prior.sample(reduced, text_embd, b["text_lengths"], training=False, temperature=0.0)
+    _, outs, _ = model.decoder(z, text_embd, reduced, b["text_lengths"], training=False, reduction_factor=rf)
+    rmel, rlen, _ = oracle.test_step(b["ids"], b["text_lengths"])
+    rf64 = oracle.last["pred_float"]
+    margin = np.minimum(rf64 - np.floor(rf64), np.ceil(rf64) - rf64)
+    print(f"[{name}] predicted frames {pred_ml + 80} oracle {rlen} integer margins {margin}")
+    assert np.all(margin > 1e-4), "fixture sits on an integer boundary; pick another seed"
+    assert np.array_equal(pred_ml + 80, rlen)            # bit-exact integer frame counts
+    assert outs.shape == rmel.shape
+    np.testing.assert_allclose(outs.numpy(), rmel, atol=MEL_TOL, rtol=0)
+
+
+def test_posterior(setup):
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    r = np.random.Generator(np.random.PCG64(3))
+    reduced = (b["mel_lengths"] + 1) // 2
+    Tz = int(reduced.max())
+    mels = r.standard_normal((len(reduced), Tz, hps.Audio.num_mels)).astype(np.float32)
+    mem = r.standard_normal((len(reduced), b["ids"].shape[1], hps.Encoder.Transformer.pre_hidden)).astype(np.float32)
+    mu, logvar, _ = model.posterior(mels, mem, src_lengths=b["text_lengths"], target_lengths=reduced, training=False)
+    rmu, rlv = oracle.posterior(mels.astype(np.float64), mem.astype(np.float64), b["text_lengths"], reduced)
+    np.testing.assert_allclose(mu.numpy(), rmu, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(logvar.numpy(), rlv, atol=1e-4, rtol=0)

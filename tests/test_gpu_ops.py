@@ -1,0 +1,190 @@
+"""Kernel-level parity: every HIP operator, called through the C ABI, against the NumPy oracle
+(float64) on the same seeded inputs.  Tolerances are stated per test; fp32 MFMA is an exact
+fp32 fma chain, so differences are fp32 round-off of the contraction length."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vaenar_numpy as O
+from vaenar_tts_amd import _lib
+from vaenar_tts_amd.configs import tiny_hps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = _lib.Engine(tiny_hps(), 0)
+    yield e
+    e.close()
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def dense_gpu(eng, a1, w, a2=None, bias=None, act=None, residual=None, ln=None, pe=None, pe_w=0.0):
+    m = a1.shape[0]
+    n = w.shape[1]
+    d = _lib.vnr_dense_desc()
+    keep = []
+
+    def dev(x):
+        if x is None:
+            return None
+        t = eng.to_device(np.asarray(x, np.float32)); keep.append(t); return t.ptr
+    d.d_a1, d.lda1, d.k1 = dev(a1), a1.shape[1], a1.shape[1]
+    if a2 is not None:
+        d.d_a2, d.lda2, d.k2 = dev(a2), a2.shape[1], a2.shape[1]
+    d.d_w, d.d_bias, d.activation = dev(w), dev(bias), _lib.ACT[act]
+    if residual is not None:
+        d.d_residual, d.ldr = dev(residual), n
+    if ln is not None:
+        d.d_ln_gamma, d.d_ln_beta = dev(ln[0]), dev(ln[1])
+    if pe is not None:
+        d.d_pe, d.pe_T, d.pe_weight = dev(pe), pe.shape[0], pe_w
+    out = eng.empty((m, n))
+    d.d_c, d.ldc, d.m, d.n = out.ptr, n, m, n
+    _lib.check(eng.lib.vnr_op_dense(eng.handle, C.byref(d)), eng.handle)
+    return out.numpy()
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4, 1), (37, 64, 80), (200, 512, 256), (300, 100, 513), (6400, 256, 1024),
+                                   (2048, 512, 768), (129, 1024, 160)])
+def test_dense_plain(eng, m, k, n):
+    r = rng(m * 7 + n)
+    a, w, b = r.standard_normal((m, k)), r.standard_normal((k, n)) / np.sqrt(k), r.standard_normal(n)
+    got = dense_gpu(eng, a, w, bias=b, act="relu")
+    ref = O.dense(a.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64),
+                  b.astype(np.float32).astype(np.float64), "relu")
+    np.testing.assert_allclose(got, ref, atol=2e-5 * np.sqrt(k / 64 + 1), rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,k1,k2,n", [(70, 96, 128, 96), (400, 256, 256, 256), (333, 512, 256, 512)])
+def test_dense_concat_residual_layernorm(eng, m, k1, k2, n):
+    """LN(x + Dense(concat(x, ctx))) -- attention.py:410-413 / 440-443 -- fused (n<=256) and two-pass."""
+    r = rng(m + k1)
+    a1, a2 = r.standard_normal((m, k1)), r.standard_normal((m, k2))
+    w, b = r.standard_normal((k1 + k2, n)) / np.sqrt(k1 + k2), r.standard_normal(n) * 0.1
+    res = r.standard_normal((m, n))
+    g, be = 1 + 0.1 * r.standard_normal(n), 0.1 * r.standard_normal(n)
+    f = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    got = dense_gpu(eng, a1, w, a2=a2, bias=b, residual=res, ln=(g, be))
+    ref = O.layer_norm(f(res) + O.dense(np.concatenate([f(a1), f(a2)], -1), f(w), f(b)), f(g), f(be))
+    np.testing.assert_allclose(got, ref, atol=3e-5, rtol=1e-5)
+
+
+def test_dense_pe_epilogue(eng):
+    r = rng(5)
+    T, B, k, n = 13, 3, 64, 128
+    a, w, b = r.standard_normal((B * T, k)), r.standard_normal((k, n)) / 8, r.standard_normal(n)
+    pe = O.positional_encoding(T, n, 1.0)
+    got = dense_gpu(eng, a, w, bias=b, pe=pe, pe_w=1.25)
+    f = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    ref = O.dense(f(a), f(w), f(b)) + np.float64(np.float32(1.25)) * np.tile(pe.astype(np.float64), (B, 1))
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,T,cin,cout,k,act,bn_first", [(2, 9, 16, 48, 5, "tanh", 0), (3, 40, 96, 96, 5, "relu", 0),
+                                                          (1, 3, 80, 256, 5, "identity", 0), (2, 17, 48, 48, 3, "relu", 1),
+                                                          (16, 128, 512, 512, 5, "relu", 0)])
+def test_conv1d_bn(eng, B, T, cin, cout, k, act, bn_first):
+    """Conv1D('same') + bias -> act -> BN(moving stats) (utils.py:76-85), incl. zero padding at the
+    tensor edges and sequences shorter than the kernel."""
+    r = rng(B * 100 + T)
+    x = r.standard_normal((B, T, cin))
+    w = r.standard_normal((k, cin, cout)) / np.sqrt(k * cin)
+    b, g, be = r.standard_normal(cout) * 0.1, 1 + 0.1 * r.standard_normal(cout), 0.1 * r.standard_normal(cout)
+    mu, var = 0.1 * r.standard_normal(cout), r.uniform(0.5, 1.5, cout)
+    dv = lambda a: eng.to_device(np.asarray(a, np.float32))
+    xs = [dv(t) for t in (x, w, b, g, be, mu, var)]
+    y = eng.empty((B, T, cout))
+    _lib.check(eng.lib.vnr_op_conv1d_bn(eng.handle, xs[0].ptr, B, T, cin, xs[1].ptr, k, cout, xs[2].ptr, _lib.ACT[act],
+                                        bn_first, xs[3].ptr, xs[4].ptr, xs[5].ptr, xs[6].ptr, y.ptr), eng.handle)
+    f = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    c = O.conv1d_same(f(x), f(w), f(b))
+    if bn_first:
+        ref = O.act(O.batch_norm_infer(c, f(g), f(be), f(mu), f(var)), act)
+    else:
+        ref = O.batch_norm_infer(O.act(c, act), f(g), f(be), f(mu), f(var))
+    np.testing.assert_allclose(y.numpy(), ref, atol=3e-5, rtol=1e-5)
+
+
+def attention_ref(q, k, v, ql, kl, H, causal, tau):
+    """attention.py:221-246 on projected tensors, float64."""
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dh = D // H
+    qh = q.reshape(B, Tq, H, dh).transpose(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, H, dh).transpose(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, H, dh).transpose(0, 2, 1, 3)
+    lg = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(float(dh)) / tau
+    mask = O.sequence_mask(kl, Tk)[:, None, :] & O.sequence_mask(ql, Tq)[:, :, None]
+    if causal:
+        mask = mask & np.tril(np.ones((Tq, Tk), bool))[None]
+    lg = np.where(mask[:, None], lg, np.float64(O.MASK_FILL))
+    ali = O.softmax_last(lg)
+    ctx = (ali @ vh).transpose(0, 2, 1, 3).reshape(B, Tq, D)
+    return ctx, ali
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,want_ali,tau,ragged", [
+    (2, 2, 7, 7, 0, 0, 1.0, True),        # tiny, padded queries -> uniform rows
+    (2, 2, 45, 45, 1, 0, 1.0, True),      # causal, ragged
+    (3, 4, 400, 400, 1, 0, 1.0, True),    # S1-shaped causal self attention, multi-tile + skipping
+    (3, 4, 400, 128, 0, 1, 1.0, True),    # S1-shaped decoder cross attention with alignments
+    (2, 4, 130, 200, 0, 1, 1.0, True),    # Tk > 128 with alignments (two-pass path)
+    (2, 1, 33, 129, 0, 0, 0.7, True),     # odd sizes, temperature != 1
+    (1, 2, 64, 64, 1, 1, 1.0, False),     # causal with alignments requested
+    (2, 4, 128, 128, 0, 0, 1.0, False),   # encoder-shaped, full lengths
+])
+def test_attention(eng, B, H, Tq, Tk, causal, want_ali, tau, ragged):
+    r = rng(Tq * 3 + Tk)
+    D = 64 * H
+    q, k, v = r.standard_normal((B, Tq, D)), r.standard_normal((B, Tk, D)), r.standard_normal((B, Tk, D))
+    q *= 1.5   # sharper softmax
+    if ragged:
+        ql = np.maximum(1, Tq - np.arange(B) * max(1, Tq // 3)).astype(np.int32)
+        kl = np.maximum(1, Tk - np.arange(B) * max(1, Tk // 4)).astype(np.int32)
+    else:
+        ql, kl = np.full(B, Tq, np.int32), np.full(B, Tk, np.int32)
+    if causal:
+        kl = ql.copy()   # self attention: memory_lengths = query_lengths (attention.py:437-439)
+    dq, dk, dv_ = (eng.to_device(t.astype(np.float32)) for t in (q, k, v))
+    dql, dkl = eng.to_device(ql), eng.to_device(kl)
+    ctx = eng.empty((B, Tq, D))
+    ali = eng.empty((B, H, Tq, Tk)) if want_ali else None
+    _lib.check(eng.lib.vnr_op_attention(eng.handle, dq.ptr, D, dk.ptr, D, dv_.ptr, D, dql.ptr, dkl.ptr, B, H, Tq, Tk,
+                                        causal, tau, ctx.ptr, D, None if ali is None else ali.ptr), eng.handle)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    rctx, rali = attention_ref(f(q), f(k), f(v), ql, kl, H, causal, np.float64(np.float32(tau)))
+    np.testing.assert_allclose(ctx.numpy(), rctx, atol=2e-5, rtol=1e-5)
+    if want_ali:
+        got = ali.numpy()
+        np.testing.assert_allclose(got, rali, atol=2e-6, rtol=1e-5)
+        # fully masked (padded-query) rows are exactly uniform over all Tk keys
+        for b in range(B):
+            if ql[b] < Tq:
+                assert np.all(got[b, :, ql[b]:, :] == np.float32(1.0) / np.float32(Tk))
+
+
+@pytest.mark.parametrize("rows,dim", [(5, 96), (6400, 256), (2048, 512), (3, 1024)])
+def test_layer_norm(eng, rows, dim):
+    r = rng(rows + dim)
+    x, g, b = 3 * r.standard_normal((rows, dim)) + 1.0, 1 + 0.1 * r.standard_normal(dim), r.standard_normal(dim)
+    dx, dg, db = (eng.to_device(t.astype(np.float32)) for t in (x, g, b))
+    y = eng.empty((rows, dim))
+    _lib.check(eng.lib.vnr_op_layer_norm(eng.handle, dx.ptr, dg.ptr, db.ptr, rows, dim, y.ptr), eng.handle)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(y.numpy(), O.layer_norm(f(x), f(g), f(b)), atol=5e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("T,dim,step", [(128, 512, 5.59 / 2), (400, 256, 1.0), (7, 96, 5.59 / 5)])
+def test_positional_encoding(eng, T, dim, step):
+    """utils.py:333-355.  Arguments reach ~360 rad in fp32 (ulp 3e-5): the table is compared with the
+    oracle's correctly-rounded fp32 staging; tolerance = one ulp of the largest argument."""
+    out = eng.empty((T, dim))
+    _lib.check(eng.lib.vnr_op_positional_encoding(eng.handle, T, dim, float(np.float32(step)), out.ptr), eng.handle)
+    ref = O.positional_encoding(T, dim, np.float32(step))
+    np.testing.assert_allclose(out.numpy(), ref, atol=4e-5, rtol=0)

@@ -1,0 +1,300 @@
+"""ctypes binding of libvaenar_hip.so (C ABI: include/vaenar_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no AMD GPU is
+visible when an engine is created, an exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
+ABI_VERSION = 1
+
+ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
+
+
+class VnrError(RuntimeError):
+    pass
+
+
+class vnr_config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("latent_dim", C.c_int32), ("output_dim", C.c_int32), ("max_reduction_factor", C.c_int32),
+        ("num_mels", C.c_int32),
+        ("enc_vocab_size", C.c_int32), ("enc_embd_dim", C.c_int32), ("enc_n_conv", C.c_int32),
+        ("enc_pre_hidden", C.c_int32), ("enc_conv_kernel", C.c_int32),
+        ("enc_pre_activation", C.c_int32), ("enc_bn_before_act", C.c_int32), ("enc_n_blk", C.c_int32),
+        ("enc_attention_dim", C.c_int32), ("enc_attention_heads", C.c_int32),
+        ("enc_ffn_hidden", C.c_int32), ("enc_attention_temperature", C.c_float),
+        ("dec_nblk", C.c_int32), ("dec_attention_dim", C.c_int32), ("dec_attention_heads", C.c_int32),
+        ("dec_ffn_hidden", C.c_int32), ("dec_post_n_conv", C.c_int32),
+        ("dec_post_conv_filters", C.c_int32), ("dec_post_conv_kernel", C.c_int32),
+        ("dec_attention_temperature", C.c_float),
+        ("prior_n_blk", C.c_int32), ("prior_n_transformer_blk", C.c_int32),
+        ("prior_attention_dim", C.c_int32), ("prior_attention_heads", C.c_int32),
+        ("prior_ffn_hidden", C.c_int32), ("prior_temperature", C.c_float),
+        ("post_pre_hidden", C.c_int32), ("post_pre_activation", C.c_int32), ("post_nblk", C.c_int32),
+        ("post_attention_dim", C.c_int32), ("post_attention_heads", C.c_int32),
+        ("post_ffn_hidden", C.c_int32), ("post_temperature", C.c_float),
+        ("lenpred_activation", C.c_int32),
+    ]
+
+
+class vnr_dense_desc(C.Structure):
+    _fields_ = [
+        ("d_a1", C.c_void_p), ("lda1", C.c_int32), ("k1", C.c_int32),
+        ("d_a2", C.c_void_p), ("lda2", C.c_int32), ("k2", C.c_int32),
+        ("d_w", C.c_void_p), ("d_bias", C.c_void_p), ("activation", C.c_int32),
+        ("d_residual", C.c_void_p), ("ldr", C.c_int32),
+        ("d_ln_gamma", C.c_void_p), ("d_ln_beta", C.c_void_p),
+        ("d_pe", C.c_void_p), ("pe_T", C.c_int32), ("pe_weight", C.c_float),
+        ("d_c", C.c_void_p), ("ldc", C.c_int32), ("m", C.c_int32), ("n", C.c_int32),
+    ]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_pd, _pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+
+# name -> argtypes; every function returns int (vnr_status) unless noted
+PROTOTYPES = {
+    "vnr_abi_version": [],
+    "vnr_device_count": [C.POINTER(C.c_int)],
+    "vnr_create": [C.POINTER(vnr_config), _i, C.POINTER(_vp)],
+    "vnr_destroy": [_vp],
+    "vnr_device_info": [_vp, C.c_char_p, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "vnr_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "vnr_free": [_vp, _vp],
+    "vnr_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "vnr_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "vnr_memcpy_d2d": [_vp, _vp, _vp, _sz],
+    "vnr_memset": [_vp, _vp, _i, _sz],
+    "vnr_synchronize": [_vp],
+    "vnr_set_weight": [_vp, C.c_char_p, _vp, _pi64, _i],
+    "vnr_get_weight": [_vp, C.c_char_p, _vp, C.c_int64],
+    "vnr_finalize_weights": [_vp],
+    "vnr_text_encoder_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "vnr_length_predictor_fwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "vnr_prior_sample": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "vnr_decoder_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vnr_posterior_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "vnr_inference": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "vnr_op_dense": [_vp, C.POINTER(vnr_dense_desc)],
+    "vnr_op_conv1d_bn": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
+    "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
+    "vnr_profile_enable": [_vp, _i],
+    "vnr_profile_reset": [_vp],
+    "vnr_profile_get": [_vp, C.c_char_p, _pd, _pi64, _pd, _pd],
+    "vnr_launch_count": [_vp, _pi64],
+}
+
+_lib = None
+
+
+def load():
+    """Load libvaenar_hip.so and declare every prototype; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VnrError(
+            "libvaenar_hip.so not found at %s -- build it with `python __graft_entry__.py` or "
+            "`make -C vaenar_tts_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.vnr_last_error.argtypes = [_vp]
+    lib.vnr_last_error.restype = C.c_char_p
+    if lib.vnr_abi_version() != ABI_VERSION:
+        raise VnrError("libvaenar_hip.so ABI version %d != binding %d" % (lib.vnr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().vnr_last_error(handle)
+        raise VnrError("libvaenar_hip error %d: %s" % (rc, (msg or b"?").decode()))
+
+
+def config_from_hps(hps):
+    e, d, p, q = hps.Encoder.Transformer, hps.Decoder.Transformer, hps.Prior.Transformer, hps.Posterior.Transformer
+    c = vnr_config()
+    c.abi_version = ABI_VERSION
+    c.latent_dim, c.output_dim = hps.Common.latent_dim, hps.Common.output_dim
+    c.max_reduction_factor, c.num_mels = hps.Common.max_reduction_factor, hps.Audio.num_mels
+    c.enc_vocab_size, c.enc_embd_dim, c.enc_n_conv = e.vocab_size, e.embd_dim, e.n_conv
+    c.enc_pre_hidden, c.enc_conv_kernel = e.pre_hidden, e.conv_kernel
+    c.enc_pre_activation, c.enc_bn_before_act = ACT[e.pre_activation], int(bool(e.bn_before_act))
+    c.enc_n_blk, c.enc_attention_dim, c.enc_attention_heads = e.n_blk, e.attention_dim, e.attention_heads
+    c.enc_ffn_hidden, c.enc_attention_temperature = e.ffn_hidden, e.attention_temperature
+    c.dec_nblk, c.dec_attention_dim, c.dec_attention_heads = d.nblk, d.attention_dim, d.attention_heads
+    c.dec_ffn_hidden, c.dec_post_n_conv = d.ffn_hidden, d.post_n_conv
+    c.dec_post_conv_filters, c.dec_post_conv_kernel = d.post_conv_filters, d.post_conv_kernel
+    c.dec_attention_temperature = d.attention_temperature
+    c.prior_n_blk, c.prior_n_transformer_blk = p.n_blk, p.n_transformer_blk
+    c.prior_attention_dim, c.prior_attention_heads = p.attention_dim, p.attention_heads
+    c.prior_ffn_hidden, c.prior_temperature = p.ffn_hidden, p.temperature
+    c.post_pre_hidden, c.post_pre_activation, c.post_nblk = q.pre_hidden, ACT[q.pre_activation], q.nblk
+    c.post_attention_dim, c.post_attention_heads = q.attention_dim, q.attention_heads
+    c.post_ffn_hidden, c.post_temperature = q.ffn_hidden, q.temperature
+    c.lenpred_activation = ACT[hps.LengthPredictor.Dense.activation]
+    return c
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().vnr_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class DeviceArray:
+    """A typed view of device memory owned by one engine.  ``.numpy()`` copies to the host
+    (the reference's tensors expose the same method, inference.py:156)."""
+
+    __slots__ = ("engine", "ptr", "shape", "dtype", "_owner", "nbytes")
+
+    def __init__(self, engine, shape, dtype=np.float32, ptr=None, owner=None):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if ptr is None:
+            p = C.c_void_p()
+            check(engine.lib.vnr_malloc(engine.handle, max(self.nbytes, 4), C.byref(p)), engine.handle)
+            self.ptr = p.value
+            self._owner = True
+        else:
+            self.ptr = ptr
+            self._owner = owner        # keeps the parent allocation alive for views
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(self.engine.lib.vnr_memcpy_d2h(self.engine.handle, out.ctypes.data, self.ptr, self.nbytes),
+                  self.engine.handle)
+        return out
+
+    def copy_from(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.shape == self.shape, (host.shape, self.shape)
+        if self.nbytes:
+            check(self.engine.lib.vnr_memcpy_h2d(self.engine.handle, self.ptr, host.ctypes.data, self.nbytes),
+                  self.engine.handle)
+        return self
+
+    def view(self, offset_elems, shape):
+        return DeviceArray(self.engine, shape, self.dtype, self.ptr + offset_elems * self.dtype.itemsize,
+                           owner=self)
+
+    def __del__(self):
+        if getattr(self, "_owner", None) is True and self.engine is not None and self.engine.handle:
+            try:
+                self.engine.lib.vnr_free(self.engine.handle, self.ptr)
+            except Exception:
+                pass
+
+
+class Engine:
+    """One HIP engine = one device = one stream (vnr_handle)."""
+
+    def __init__(self, hps, device=0):
+        self.lib = load()
+        self.hps = hps
+        self.handle = None
+        h = C.c_void_p()
+        cfg = config_from_hps(hps)
+        check(self.lib.vnr_create(C.byref(cfg), int(device), C.byref(h)))
+        self.handle = h.value
+        self.device = device
+        self._weights_loaded = set()
+
+    # -- memory -----------------------------------------------------------------
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DeviceArray(self, shape, dtype)
+        check(self.lib.vnr_memset(self.handle, a.ptr, 0, max(a.nbytes, 1)), self.handle)
+        return a
+
+    def to_device(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DeviceArray(self, host.shape, host.dtype).copy_from(host)
+
+    def asarray(self, x, dtype):
+        """Accept a DeviceArray (checked) or anything numpy can convert."""
+        if isinstance(x, DeviceArray):
+            assert x.dtype == np.dtype(dtype), (x.dtype, dtype)
+            return x
+        if hasattr(x, "numpy") and not isinstance(x, np.ndarray):
+            x = x.numpy()
+        return self.to_device(np.asarray(x), dtype)
+
+    def synchronize(self):
+        check(self.lib.vnr_synchronize(self.handle), self.handle)
+
+    def device_info(self):
+        buf = C.create_string_buffer(128)
+        cu, wf = C.c_int(0), C.c_int(0)
+        check(self.lib.vnr_device_info(self.handle, buf, 128, C.byref(cu), C.byref(wf)), self.handle)
+        return dict(name=buf.value.decode(), compute_units=cu.value, wavefront=wf.value)
+
+    # -- weights ----------------------------------------------------------------
+    def set_weight(self, path, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        check(self.lib.vnr_set_weight(self.handle, path.encode(), a.ctypes.data, shape, a.ndim), self.handle)
+        self._weights_loaded.add(path)
+
+    def get_weight(self, path, shape):
+        out = np.empty(shape, np.float32)
+        check(self.lib.vnr_get_weight(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
+        return out
+
+    def load_weights(self, weights):
+        for k, v in weights.items():
+            self.set_weight(k, v)
+        self.finalize()
+
+    def finalize(self):
+        check(self.lib.vnr_finalize_weights(self.handle), self.handle)
+
+    # -- instrumentation ----------------------------------------------------------
+    def profile(self, on):
+        check(self.lib.vnr_profile_enable(self.handle, int(bool(on))), self.handle)
+
+    def profile_reset(self):
+        check(self.lib.vnr_profile_reset(self.handle), self.handle)
+
+    def profile_get(self, cls):
+        ms, n, fl, by = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+        check(self.lib.vnr_profile_get(self.handle, cls.encode(), C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)),
+              self.handle)
+        return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+    def launch_count(self):
+        n = C.c_int64(0)
+        check(self.lib.vnr_launch_count(self.handle, C.byref(n)), self.handle)
+        return n.value
+
+    def close(self):
+        if self.handle:
+            self.lib.vnr_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,87 @@
+// Shared declarations of the gfx950 kernels behind libvaenar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kMaskFill = -4294967296.0f;   // fp32(-2**32 + 1), attention.py:240
+constexpr float kLnEps = 1e-3f;               // Keras LayerNormalization default
+constexpr float kBnEps = 1e-3f;               // Keras BatchNormalization default
+
+enum { ACT_IDENTITY = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+// C[M,N] = epilogue( A[M,K] . W[K,N] ), W given transposed as Wt[N][K] (k contiguous).
+// A is assembled on the fly:
+//   plain   : k <  K1 -> A1[m*lda1 + k] ; k >= K1 -> A2[m*lda2 + k-K1]     (tf.concat, K8)
+//   conv    : taps > 0, K = taps*conv_C, k = j*conv_C + c ->
+//             A1[(b*T + t + j - taps/2)*lda1 + c] or 0 outside [0,T)        ('same' Conv1D, K2)
+//   gather  : row index is looked up in gather_ids first (Embedding, K1)
+// Epilogue order: +bias -> act -> *bn_scale+bn_shift -> +pe_w*pe[m % pe_T] -> +residual
+//                 -> (optional, separate pass) LayerNorm.
+struct GemmArgs {
+  const float* A1 = nullptr; int lda1 = 0; int K1 = 0;
+  const float* A2 = nullptr; int lda2 = 0;
+  const float* Wt = nullptr; int ldw = 0;
+  const float* bias = nullptr;
+  int act = ACT_IDENTITY;
+  const float* bn_scale = nullptr; const float* bn_shift = nullptr;
+  int bn_first = 0;                 // 1: BN before the activation (Conv1D bn_before_act=True)
+  const float* pe = nullptr; int pe_T = 1; float pe_w = 0.f;
+  const float* residual = nullptr; int ldr = 0;
+  float* C = nullptr; int ldc = 0;
+  int M = 0, N = 0, K = 0;
+  int taps = 0, conv_T = 1, conv_C = 0;
+  const int32_t* gather_ids = nullptr;
+  // fused LayerNorm epilogue (row-panel kernel, requires N <= 256; wider rows use launch_layer_norm)
+  const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
+};
+
+struct AttnArgs {
+  const float* Q; int ldq;          // [B,Tq,H*64], row stride ldq
+  const float* K; int ldk;          // [B,Tk,H*64]
+  const float* V; int ldv;
+  const int32_t* q_len;             // [B] or null
+  const int32_t* k_len;             // [B] or null
+  float* ctx; int ldo;              // [B,Tq,H*64]
+  float* ali;                       // [B,H,Tq,Tk] or null
+  int B, H, Tq, Tk;
+  int causal;
+  float temperature;
+  // batch strides in floats (rows * ld by default); allow K/V shared panels
+  long long q_bs, k_bs, v_bs, o_bs;
+};
+
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
+                             int dim, float* y, hipStream_t s);
+hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s);
+hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int ldo,
+                            hipStream_t s);   // out[c*ldo + r] = in[r*cols + c]
+// zp <- sigmoid(ls+2)*zp + shift on one half of z; rowsum[m] = sum_c log(scale) (flow.py:223-239)
+hipError_t launch_coupling_fwd(const float* heads /*[M,2*half]: log_scale | shift*/, float* z,
+                               int M, int half, int zp_off, float* row_logdet, hipStream_t s);
+// out[b] = sum_{t < len[b]} rows[b*T + t]   (deterministic order)
+hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T,
+                                    float scale, float* out, int accumulate, hipStream_t s);
+// DenseLengthPredictor: out[b] = sum_{t<len} exp(act(x[b,t,:].w + bias))
+hipError_t launch_length_predictor(const float* x, const float* w, const float* bias,
+                                   const int32_t* len, int B, int T, int D, int act, float* out,
+                                   hipStream_t s);
+// out[b] = sum_{t<len[b]} sum_c -0.5*(log(2pi) + eps^2)     (prior.py:36-41)
+hipError_t launch_gauss_logprob(const float* eps, const int32_t* len, int B, int T, int C,
+                                float* out, hipStream_t s);
+// y[b] = a[b] + alpha * float(len[b])
+hipError_t launch_axpy_len(float* y, const int32_t* len, float alpha, int B, hipStream_t s);
+// folded ActNorm o InvertibleLinear: Wt_out[n][k] = exp(ls[k]) * W[k][n]; b_out[n] = sum_k b[k] W[k][n]
+hipError_t launch_fold_actnorm_linear(const float* log_scale, const float* bias, const float* W,
+                                      int C, float* Wt_out, float* b_out, hipStream_t s);
+// BN inference affine: scale = gamma * rsqrt(var + eps); shift = beta - mean * scale
+hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* mean,
+                            const float* var, int C, float* scale, float* shift, hipStream_t s);
+
+}  // namespace vnr

@@ -1,0 +1,969 @@
+// libvaenar_hip.so host side: context, weight store and packing, module orchestration on one HIP
+// stream, and the extern "C" ABI declared in include/vaenar_hip.h.
+#include "../../include/vaenar_hip.h"
+#include "common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <tuple>
+#include <utility>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace vnr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Tensor {
+  float* d = nullptr;
+  std::vector<int64_t> shape;
+  int64_t n = 0;
+  float scalar = 0.f;   // host copy for rank-0 variables (pos_weight)
+};
+
+struct XBlk {   // CrossAttentionBLK (attention.py:418-452), packed
+  const float *qkv_wt, *proj1_wt, *proj1_b, *ln1_g, *ln1_b, *q_wt, *proj2_wt, *proj2_b, *ln2_g, *ln2_b,
+      *ffn1_wt, *ffn1_b, *ffn2_wt, *ffn2_b, *ffn_g, *ffn_b;
+  int kv_col;        // column offset of this block's K|V inside its cross-K/V panel output
+  int D, F;
+};
+struct SBlk {   // SelfAttentionBLK (attention.py:392-415), packed
+  const float *qkv_wt, *proj_wt, *proj_b, *ln_g, *ln_b, *ffn1_wt, *ffn1_b, *ffn2_wt, *ffn2_b, *ffn_g, *ffn_b;
+};
+struct ConvL {  // Conv1D + BN (utils.py:56-85), packed
+  const float *wt, *bias, *bn_scale, *bn_shift;
+  int cin, cout, k;
+};
+struct FlowStep {
+  const float *fold_wt, *fold_b;         // ActNorm o InvertibleLinear
+  double logdet_per_frame;               // sum(log_scale) + log|det W|  (flow.py:168,127-129)
+  const float *pre_wt, *pre_b;           // transform pre_projection
+  float pos_weight;
+  const float *heads_wt, *heads_b;       // log_scale_proj | shift_proj
+  std::vector<XBlk> blks;
+};
+
+struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
+enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_COUNT };
+const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc"};
+
+}  // namespace
+
+struct vnr_context {
+  vnr_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::unordered_map<std::string, Tensor> w;
+  std::vector<float*> packed_allocs;
+  bool finalized = false;
+
+  // packed model
+  const float* emb = nullptr;
+  float enc_pos_weight = 1.f;
+  std::vector<ConvL> enc_convs, post_convs;
+  const float *enc_proj_wt = nullptr, *enc_proj_b = nullptr;
+  std::vector<SBlk> enc_blks;
+  const float *lp_w = nullptr, *lp_b = nullptr;
+  std::vector<FlowStep> flow;
+  const float* prior_kv_wt = nullptr; int prior_kv_n = 0;     // all prior cross K|V panels
+  const float* dec_kv_wt = nullptr; int dec_kv_n = 0;         // contiguous after the prior panels
+  const float *dec_pre_wt = nullptr, *dec_pre_b = nullptr, *dec_out_wt = nullptr, *dec_out_b = nullptr,
+              *dec_res_wt = nullptr, *dec_res_b = nullptr;
+  std::vector<XBlk> dec_blks;
+  bool has_posterior = false;
+  const float *post_d1_wt = nullptr, *post_d1_b = nullptr, *post_d2_wt = nullptr, *post_d2_b = nullptr,
+              *post_mu_wt = nullptr, *post_mu_b = nullptr, *post_lv_wt = nullptr, *post_lv_b = nullptr,
+              *post_kv_wt = nullptr;
+  int post_kv_n = 0;
+  float post_pos_weight = 1.f;
+  std::vector<XBlk> post_blks;
+
+  // workspace arena (chunks; bump allocation, reset at every top-level call)
+  struct Chunk { char* p; size_t cap, off; };
+  std::vector<Chunk> chunks;
+  // positional-encoding tables, keyed by (T, dim, step bits)
+  std::map<std::tuple<int, int, uint32_t>, float*> pe_cache;
+
+  // instrumentation
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+  int64_t launches = 0;
+};
+
+namespace {
+
+int fail(vnr_handle h, int code, const std::string& msg) {
+  g_last_error = msg;
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return fail(h, VNR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+#define TRY(expr)                      \
+  do {                                 \
+    int _rc = (expr);                  \
+    if (_rc != VNR_OK) return _rc;     \
+  } while (0)
+
+// ---- arena --------------------------------------------------------------------------------------
+void ws_reset(vnr_handle h) { for (auto& c : h->chunks) c.off = 0; }
+
+float* ws_alloc(vnr_handle h, size_t nfloats) {
+  size_t bytes = ((nfloats * sizeof(float)) + 255) & ~(size_t)255;
+  for (auto& c : h->chunks)
+    if (c.off + bytes <= c.cap) { float* p = (float*)(c.p + c.off); c.off += bytes; return p; }
+  size_t cap = bytes > ((size_t)64 << 20) ? bytes : ((size_t)64 << 20);
+  char* p = nullptr;
+  if (hipMalloc((void**)&p, cap) != hipSuccess) { h->err = "workspace hipMalloc failed"; return nullptr; }
+  h->chunks.push_back({p, cap, bytes});
+  return (float*)p;
+}
+#define WS(var, n)                                                            \
+  float* var = ws_alloc(h, (size_t)(n));                                      \
+  if (!var) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed")
+
+// ---- instrumented launches ------------------------------------------------------------------------
+hipEvent_t get_event(vnr_handle h) {
+  if (!h->event_pool.empty()) { hipEvent_t e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  vnr_handle h; ProfRec rec; bool on;
+  ProfScope(vnr_handle h_, int cls, double flops, double bytes) : h(h_), on(h_->profiling) {
+    h->launches++;
+    if (on) { rec = {cls, get_event(h), get_event(h), flops, bytes}; hipEventRecord(rec.e0, h->stream); }
+  }
+  ~ProfScope() { if (on) { hipEventRecord(rec.e1, h->stream); h->prof.push_back(rec); } }
+};
+
+int run_gemm(vnr_handle h, const GemmArgs& g) {
+  ProfScope ps(h, CLS_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0);
+  hipError_t e = launch_gemm(g, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e) +
+                                   " (M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) + " K=" + std::to_string(g.K) + ")");
+  return VNR_OK;
+}
+int run_attention(vnr_handle h, const AttnArgs& a, bool cross) {
+  const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
+                    (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
+  const double fl = 4.0 * (double)a.B * a.H * a.Tq * (double)a.Tk * 64;
+  ProfScope ps(h, cross ? (a.ali ? CLS_ATTN_CROSS_ALI : CLS_ATTN_CROSS) : CLS_ATTN_SELF, fl, io);
+  hipError_t e = launch_attention(a, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(e));
+  return VNR_OK;
+}
+int run_ln(vnr_handle h, const float* x, const float* g, const float* b, int rows, int dim, float* y) {
+  ProfScope ps(h, CLS_LN, 0.0, 8.0 * rows * (double)dim);
+  hipError_t e = launch_layer_norm(x, g, b, rows, dim, y, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("layer_norm launch: ") + hipGetErrorString(e));
+  return VNR_OK;
+}
+#define RUN_MISC(h, call)                                                                       \
+  do {                                                                                          \
+    ProfScope _ps(h, CLS_MISC, 0.0, 0.0);                                                       \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// ---- weights --------------------------------------------------------------------------------------
+const Tensor* find_w(vnr_handle h, const std::string& path) {
+  auto it = h->w.find(path);
+  return it == h->w.end() ? nullptr : &it->second;
+}
+
+struct Packer {
+  vnr_handle h;
+  int rc = VNR_OK;
+  std::string missing;
+  const float* raw(const std::string& path, std::initializer_list<int64_t> shape) {
+    const Tensor* t = find_w(h, path);
+    if (!t) { if (rc == VNR_OK) { rc = VNR_ERR_WEIGHT; missing = "missing weight " + path; } return nullptr; }
+    if (std::vector<int64_t>(shape) != t->shape) {
+      if (rc == VNR_OK) { rc = VNR_ERR_WEIGHT; missing = "shape mismatch for " + path; }
+      return nullptr;
+    }
+    return t->d;
+  }
+  float scalar(const std::string& path) {
+    const Tensor* t = find_w(h, path);
+    if (!t || t->n != 1) { if (rc == VNR_OK) { rc = VNR_ERR_WEIGHT; missing = "missing scalar " + path; } return 0.f; }
+    return t->scalar;
+  }
+  float* alloc(size_t n) {
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, n * sizeof(float)) != hipSuccess) { if (rc == VNR_OK) { rc = VNR_ERR_NOMEM; missing = "hipMalloc packed"; } return nullptr; }
+    h->packed_allocs.push_back(p);
+    return p;
+  }
+  // Keras kernel [K,N] -> Wt [N][K] written at row offset n_off of a panel with row length K
+  void transpose_into(const float* src, int K, int N, float* panel, int n_off) {
+    if (!src || !panel || rc != VNR_OK) return;
+    if (launch_transpose(src, K, N, panel + (size_t)n_off * K, K, h->stream) != hipSuccess) { rc = VNR_ERR_HIP; missing = "transpose launch"; }
+  }
+  const float* wt(const std::string& path, int K, int N) {
+    const float* src = raw(path, {K, N});
+    float* p = alloc((size_t)K * N);
+    transpose_into(src, K, N, p, 0);
+    return p;
+  }
+  void copy_into(const float* src, float* dst, size_t n) {
+    if (!src || !dst || rc != VNR_OK) return;
+    if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) { rc = VNR_ERR_HIP; missing = "d2d copy"; }
+  }
+};
+
+void pack_xblk(Packer& P, const std::string& p, int D, int mem, int F, float* kv_panel, int kv_row, XBlk& o) {
+  o.D = D; o.F = F;
+  float* qkv = P.alloc((size_t)3 * D * D);
+  P.transpose_into(P.raw(p + "/self_attention/query_layer/kernel", {D, D}), D, D, qkv, 0);
+  P.transpose_into(P.raw(p + "/self_attention/key_layer/kernel", {D, D}), D, D, qkv, D);
+  P.transpose_into(P.raw(p + "/self_attention/value_layer/kernel", {D, D}), D, D, qkv, 2 * D);
+  o.qkv_wt = qkv;
+  o.proj1_wt = P.wt(p + "/att_proj1/kernel", 2 * D, D);
+  o.proj1_b = P.raw(p + "/att_proj1/bias", {D});
+  o.ln1_g = P.raw(p + "/layer_norm1/gamma", {D});
+  o.ln1_b = P.raw(p + "/layer_norm1/beta", {D});
+  o.q_wt = P.wt(p + "/cross_attention/query_layer/kernel", D, D);
+  P.transpose_into(P.raw(p + "/cross_attention/key_layer/kernel", {mem, D}), mem, D, kv_panel, kv_row);
+  P.transpose_into(P.raw(p + "/cross_attention/value_layer/kernel", {mem, D}), mem, D, kv_panel, kv_row + D);
+  o.kv_col = kv_row;
+  o.proj2_wt = P.wt(p + "/att_proj2/kernel", 2 * D, D);
+  o.proj2_b = P.raw(p + "/att_proj2/bias", {D});
+  o.ln2_g = P.raw(p + "/layer_norm2/gamma", {D});
+  o.ln2_b = P.raw(p + "/layer_norm2/beta", {D});
+  o.ffn1_wt = P.wt(p + "/ffn/dense1/kernel", D, F);
+  o.ffn1_b = P.raw(p + "/ffn/dense1/bias", {F});
+  o.ffn2_wt = P.wt(p + "/ffn/dense2/kernel", F, D);
+  o.ffn2_b = P.raw(p + "/ffn/dense2/bias", {D});
+  o.ffn_g = P.raw(p + "/ffn/layer_norm/gamma", {D});
+  o.ffn_b = P.raw(p + "/ffn/layer_norm/beta", {D});
+}
+
+void pack_conv(Packer& P, const std::string& p, int k, int cin, int cout, ConvL& o) {
+  o.k = k; o.cin = cin; o.cout = cout;
+  const float* src = P.raw(p + "/conv1d/kernel", {k, cin, cout});
+  float* wt = P.alloc((size_t)k * cin * cout);
+  P.transpose_into(src, k * cin, cout, wt, 0);      // [k*cin, cout] -> [cout][k*cin]
+  o.wt = wt;
+  o.bias = P.raw(p + "/conv1d/bias", {cout});
+  float* sc = P.alloc(cout); float* sh = P.alloc(cout);
+  const float* g = P.raw(p + "/bn/gamma", {cout});
+  const float* b = P.raw(p + "/bn/beta", {cout});
+  const float* m = P.raw(p + "/bn/moving_mean", {cout});
+  const float* v = P.raw(p + "/bn/moving_variance", {cout});
+  if (P.rc == VNR_OK && launch_bn_affine(g, b, m, v, cout, sc, sh, P.h->stream) != hipSuccess) { P.rc = VNR_ERR_HIP; P.missing = "bn_affine launch"; }
+  o.bn_scale = sc; o.bn_shift = sh;
+}
+
+// log|det W| of a CxC matrix in float64 (LU with partial pivoting) -- tf.linalg.slogdet(float64(W))[1]
+double slogdet_abs(std::vector<double> a, int n) {
+  double acc = 0.0;
+  for (int c = 0; c < n; ++c) {
+    int piv = c; double best = fabs(a[(size_t)c * n + c]);
+    for (int r = c + 1; r < n; ++r) { double v = fabs(a[(size_t)r * n + c]); if (v > best) { best = v; piv = r; } }
+    if (best == 0.0) return -INFINITY;
+    if (piv != c) for (int k = 0; k < n; ++k) std::swap(a[(size_t)c * n + k], a[(size_t)piv * n + k]);
+    const double d = a[(size_t)c * n + c];
+    acc += log(fabs(d));
+    for (int r = c + 1; r < n; ++r) {
+      const double f = a[(size_t)r * n + c] / d;
+      if (f != 0.0) for (int k = c + 1; k < n; ++k) a[(size_t)r * n + k] -= f * a[(size_t)c * n + k];
+    }
+  }
+  return acc;
+}
+
+int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
+  uint32_t bits; memcpy(&bits, &step, 4);
+  auto key = std::make_tuple(T, dim, bits);
+  auto it = h->pe_cache.find(key);
+  if (it != h->pe_cache.end()) { *out = it->second; return VNR_OK; }
+  float* p = nullptr;
+  HIP_TRY(h, hipMalloc((void**)&p, (size_t)T * dim * sizeof(float)));
+  RUN_MISC(h, launch_positional_encoding(T, dim, step, p, h->stream));
+  h->pe_cache[key] = p;
+  *out = p;
+  return VNR_OK;
+}
+
+// ---- module bodies ----------------------------------------------------------------------------------
+// CrossAttentionBLK.call (attention.py:436-452).  x [M,D] -> out [M,D]; kv = cross K|V panel output
+// [B*Tt, kv_ld] of the memory; ali (optional) [B,H,Tq,Tt].
+int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const float* kv, int kv_ld,
+             const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau,
+             float* ali) {
+  const int M = B * Tq, D = k.D, F = k.F;
+  WS(qkv, (size_t)M * 3 * D); WS(sa, (size_t)M * D); WS(y, (size_t)M * D); WS(q, (size_t)M * D);
+  WS(ca, (size_t)M * D); WS(o, (size_t)M * D); WS(hid, (size_t)M * F);
+  GemmArgs g;
+  // self attention: fused Q|K|V projection (no bias, attention.py:154-159)
+  g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.qkv_wt; g.ldw = D; g.C = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D;
+  TRY(run_gemm(h, g));
+  AttnArgs a;
+  a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.ldk = 3 * D; a.V = qkv + 2 * D; a.ldv = 3 * D;
+  a.q_len = q_len; a.k_len = q_len; a.ctx = sa; a.ldo = D; a.ali = nullptr; a.B = B; a.H = heads; a.Tq = Tq; a.Tk = Tq;
+  a.causal = 1; a.temperature = tau;
+  a.q_bs = (long long)Tq * 3 * D; a.k_bs = a.q_bs; a.v_bs = a.q_bs; a.o_bs = (long long)Tq * D;
+  TRY(run_attention(h, a, false));
+  // LN1(att_proj1(concat(x, sa)) + x)
+  g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.A2 = sa; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj1_wt; g.ldw = 2 * D;
+  g.bias = k.proj1_b; g.residual = x; g.ldr = D; g.ln_gamma = k.ln1_g; g.ln_beta = k.ln1_b; g.C = y; g.ldc = D; g.M = M; g.N = D;
+  if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, y, k.ln1_g, k.ln1_b, M, D, y)); }
+  else TRY(run_gemm(h, g));
+  // cross attention
+  g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.q_wt; g.ldw = D; g.C = q; g.ldc = D; g.M = M; g.N = D;
+  TRY(run_gemm(h, g));
+  a.Q = q; a.ldq = D; a.K = kv + k.kv_col; a.ldk = kv_ld; a.V = kv + k.kv_col + D; a.ldv = kv_ld;
+  a.q_len = q_len; a.k_len = m_len; a.ctx = ca; a.ldo = D; a.ali = ali; a.Tq = Tq; a.Tk = Tt; a.causal = 0;
+  a.q_bs = (long long)Tq * D; a.k_bs = (long long)Tt * kv_ld; a.v_bs = a.k_bs; a.o_bs = (long long)Tq * D;
+  TRY(run_attention(h, a, true));
+  // LN2(att_proj2(concat(y, ca)) + y)
+  g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.A2 = ca; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj2_wt; g.ldw = 2 * D;
+  g.bias = k.proj2_b; g.residual = y; g.ldr = D; g.ln_gamma = k.ln2_g; g.ln_beta = k.ln2_b; g.C = o; g.ldc = D; g.M = M; g.N = D;
+  if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, o, k.ln2_g, k.ln2_b, M, D, o)); }
+  else TRY(run_gemm(h, g));
+  // FFN (utils.py:48-53)
+  g = GemmArgs(); g.A1 = o; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.ffn1_wt; g.ldw = D; g.bias = k.ffn1_b; g.act = ACT_RELU;
+  g.C = hid; g.ldc = F; g.M = M; g.N = F;
+  TRY(run_gemm(h, g));
+  g = GemmArgs(); g.A1 = hid; g.lda1 = F; g.K1 = F; g.K = F; g.Wt = k.ffn2_wt; g.ldw = F; g.bias = k.ffn2_b; g.residual = o; g.ldr = D;
+  g.ln_gamma = k.ffn_g; g.ln_beta = k.ffn_b; g.C = out; g.ldc = D; g.M = M; g.N = D;
+  if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, out, k.ffn_g, k.ffn_b, M, D, out)); }
+  else TRY(run_gemm(h, g));
+  return VNR_OK;
+}
+
+int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather, int B, int T, int act,
+             int bn_first, float* y) {
+  GemmArgs g;
+  g.A1 = x; g.lda1 = c.cin; g.K1 = c.k * c.cin; g.K = c.k * c.cin; g.Wt = c.wt; g.ldw = c.k * c.cin;
+  g.bias = c.bias; g.act = act; g.bn_scale = c.bn_scale; g.bn_shift = c.bn_shift; g.bn_first = bn_first;
+  g.C = y; g.ldc = c.cout; g.M = B * T; g.N = c.cout; g.taps = c.k; g.conv_T = T; g.conv_C = c.cin;
+  g.gather_ids = gather;
+  return run_gemm(h, g);
+}
+
+// cross-attention K|V of the memory for a group of blocks: one GEMM over a stacked panel
+int run_kv(vnr_handle h, const float* text_embd, int rows, int mem, const float* panel, int n, float* out) {
+  GemmArgs g;
+  g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = rows; g.N = n;
+  return run_gemm(h, g);
+}
+
+int encoder_body(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out) {
+  const vnr_config& c = h->cfg;
+  const int M = B * T, Dm = c.enc_pre_hidden, A = c.enc_attention_dim, F = c.enc_ffn_hidden;
+  WS(xa, (size_t)M * Dm); WS(xb, (size_t)M * Dm);
+  float* cur = xa; float* nxt = xb;
+  // Embedding gather fused into the first conv's A loader (encoder.py:81 + utils.py:33-38)
+  for (size_t i = 0; i < h->enc_convs.size(); ++i) {
+    TRY(run_conv(h, h->enc_convs[i], i == 0 ? h->emb : cur, i == 0 ? ids : nullptr, B, T,
+                 c.enc_pre_activation, c.enc_bn_before_act, i == 0 ? cur : nxt));
+    if (i > 0) std::swap(cur, nxt);
+  }
+  const float* pe = nullptr;
+  TRY(get_pe(h, T, Dm, pos_step, &pe));
+  GemmArgs g;
+  g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = h->enc_proj_wt; g.ldw = Dm; g.bias = h->enc_proj_b;
+  g.pe = pe; g.pe_T = T; g.pe_w = h->enc_pos_weight; g.C = nxt; g.ldc = Dm; g.M = M; g.N = Dm;
+  TRY(run_gemm(h, g));                                       // prenet.projection + pos_weight*PE (encoder.py:85-86)
+  std::swap(cur, nxt);
+  WS(qkv, (size_t)M * 3 * A); WS(att, (size_t)M * A); WS(y, (size_t)M * Dm); WS(hid, (size_t)M * F);
+  for (size_t i = 0; i < h->enc_blks.size(); ++i) {
+    const SBlk& k = h->enc_blks[i];
+    g = GemmArgs(); g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = k.qkv_wt; g.ldw = Dm; g.C = qkv; g.ldc = 3 * A; g.M = M; g.N = 3 * A;
+    TRY(run_gemm(h, g));
+    AttnArgs a;
+    a.Q = qkv; a.ldq = 3 * A; a.K = qkv + A; a.ldk = 3 * A; a.V = qkv + 2 * A; a.ldv = 3 * A;
+    a.q_len = lens; a.k_len = lens; a.ctx = att; a.ldo = A; a.ali = nullptr; a.B = B; a.H = c.enc_attention_heads;
+    a.Tq = T; a.Tk = T; a.causal = 0; a.temperature = c.enc_attention_temperature;
+    a.q_bs = (long long)T * 3 * A; a.k_bs = a.q_bs; a.v_bs = a.q_bs; a.o_bs = (long long)T * A;
+    TRY(run_attention(h, a, false));
+    // LN(x + att_proj(concat(x, att)))  (attention.py:410-413)
+    g = GemmArgs(); g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.A2 = att; g.lda2 = A; g.K = Dm + A; g.Wt = k.proj_wt; g.ldw = Dm + A;
+    g.bias = k.proj_b; g.residual = cur; g.ldr = Dm; g.C = y; g.ldc = Dm; g.M = M; g.N = Dm;
+    if (Dm <= 256) { g.ln_gamma = k.ln_g; g.ln_beta = k.ln_b; TRY(run_gemm(h, g)); }
+    else { TRY(run_gemm(h, g)); TRY(run_ln(h, y, k.ln_g, k.ln_b, M, Dm, y)); }
+    g = GemmArgs(); g.A1 = y; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = k.ffn1_wt; g.ldw = Dm; g.bias = k.ffn1_b; g.act = ACT_RELU;
+    g.C = hid; g.ldc = F; g.M = M; g.N = F;
+    TRY(run_gemm(h, g));
+    float* dst = (i + 1 == h->enc_blks.size()) ? out : nxt;
+    g = GemmArgs(); g.A1 = hid; g.lda1 = F; g.K1 = F; g.K = F; g.Wt = k.ffn2_wt; g.ldw = F; g.bias = k.ffn2_b; g.residual = y; g.ldr = Dm;
+    g.C = dst; g.ldc = Dm; g.M = M; g.N = Dm;
+    if (Dm <= 256) { g.ln_gamma = k.ffn_g; g.ln_beta = k.ffn_b; TRY(run_gemm(h, g)); }
+    else { TRY(run_gemm(h, g)); TRY(run_ln(h, dst, k.ffn_g, k.ffn_b, M, Dm, dst)); }
+    std::swap(cur, nxt);
+  }
+  if (h->enc_blks.empty()) HIP_TRY(h, hipMemcpyAsync(out, cur, (size_t)M * Dm * 4, hipMemcpyDeviceToDevice, h->stream));
+  return VNR_OK;
+}
+
+// TransformerPrior.sample (prior.py:154-169); kv = prior cross K|V panel output [B*Tt, kv_ld]
+int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B,
+               int Tz, int Tt, const float* eps, float* z_out, float* logprobs) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  WS(za, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M);
+  if (eps) HIP_TRY(h, hipMemcpyAsync(za, eps, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  else HIP_TRY(h, hipMemsetAsync(za, 0, (size_t)M * C * 4, h->stream));
+  if (logprobs) RUN_MISC(h, launch_gauss_logprob(eps, z_len, B, Tz, C, logprobs, h->stream));
+  const float* pe = nullptr;
+  TRY(get_pe(h, Tz, D, 1.0f, &pe));                       // transform.py:51
+  WS(zb, (size_t)M * C);
+  float* zc = za;
+  const int nsteps = (int)h->flow.size();
+  for (int s = 0; s < nsteps; ++s) {
+    const FlowStep& f = h->flow[s];
+    float* dst = (s == nsteps - 1) ? z_out : (zc == za ? zb : za);
+    GemmArgs g;   // actnorm o invertible linear
+    g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = f.fold_wt; g.ldw = C; g.bias = f.fold_b; g.C = dst; g.ldc = C; g.M = M; g.N = C;
+    TRY(run_gemm(h, g));
+    if (logprobs) RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)(-f.logdet_per_frame), B, h->stream));
+    const bool upper = (s % 2) == 0;                      // prior.py:85-87
+    const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;   // flow.py:227-228
+    g = GemmArgs(); g.A1 = dst + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
+    g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+    float* xc = xa; float* xn = xb;
+    for (size_t b = 0; b < f.blks.size(); ++b) {
+      TRY(run_xblk(h, f.blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads,
+                   c.prior_temperature, nullptr));
+      std::swap(xc, xn);
+    }
+    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
+    g.C = heads; g.ldc = C; g.M = M; g.N = C;
+    TRY(run_gemm(h, g));
+    RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, logprobs ? rowld : nullptr, h->stream));
+    if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));
+    zc = dst;
+  }
+  if (nsteps == 0) HIP_TRY(h, hipMemcpyAsync(z_out, za, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  return VNR_OK;
+}
+
+// TransformerDecoder.call (decoder.py:181-199); kv = decoder cross K|V panel output
+int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const int32_t* z_len,
+                 const int32_t* t_len, int B, int Tz, int Tt, int rf, float* initial, float* outputs,
+                 float* alignments) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, C = c.latent_dim, D = c.dec_attention_dim, od = c.output_dim;
+  if (rf < 1 || rf > c.max_reduction_factor) return fail(h, VNR_ERR_ARG, "reduction_factor out of range");
+  WS(xa, (size_t)M * D); WS(xb, (size_t)M * D);
+  GemmArgs g;
+  g.A1 = z; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = h->dec_pre_wt; g.ldw = C; g.bias = h->dec_pre_b; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+  TRY(run_gemm(h, g));
+  float* xc = xa; float* xn = xb;
+  const size_t ali_sz = (size_t)B * c.dec_attention_heads * Tz * Tt;
+  for (size_t b = 0; b < h->dec_blks.size(); ++b) {
+    TRY(run_xblk(h, h->dec_blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.dec_attention_heads,
+                 c.dec_attention_temperature, alignments ? alignments + b * ali_sz : nullptr));
+    std::swap(xc, xn);
+  }
+  // out_projection[:, :, :rf*out_dim] -> reshape [B, Tz*rf, out_dim] (decoder.py:193-195): only the live
+  // columns are computed; the [M, rf*od] result IS the reshaped tensor.
+  float* init = initial;
+  if (!init) { WS(tmp, (size_t)M * rf * od); init = tmp; }
+  g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->dec_out_wt; g.ldw = D; g.bias = h->dec_out_b;
+  g.C = init; g.ldc = rf * od; g.M = M; g.N = rf * od;
+  TRY(run_gemm(h, g));
+  const int Tm = Tz * rf, Mm = B * Tm, Fp = c.dec_post_conv_filters;
+  WS(pa, (size_t)Mm * Fp); WS(pb, (size_t)Mm * Fp);
+  const float* cur = init; float* nxt = pa;
+  const int nconv = (int)h->post_convs.size();
+  for (int i = 0; i < nconv; ++i) {   // PostNet (utils.py:98-115): tanh x (n-1), identity; BN after act
+    TRY(run_conv(h, h->post_convs[i], cur, nullptr, B, Tm, i < nconv - 1 ? ACT_TANH : ACT_IDENTITY, 0, nxt));
+    cur = nxt; nxt = (nxt == pa) ? pb : pa;
+  }
+  const int kres = nconv > 0 ? Fp : od;
+  g = GemmArgs(); g.A1 = cur; g.lda1 = kres; g.K1 = kres; g.K = kres; g.Wt = h->dec_res_wt; g.ldw = kres; g.bias = h->dec_res_b;
+  g.residual = init; g.ldr = od; g.C = outputs; g.ldc = od; g.M = Mm; g.N = od;
+  TRY(run_gemm(h, g));               // residual_projection + initial_outs (decoder.py:197-198)
+  return VNR_OK;
+}
+
+int posterior_body(vnr_handle h, const float* mels, const float* kv, int kv_ld, const int32_t* t_len,
+                   const int32_t* z_len, int B, int Tz, int Tt, float* mu, float* logvar) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, P = c.post_pre_hidden, C = c.latent_dim;
+  WS(xa, (size_t)M * P); WS(xb, (size_t)M * P);
+  GemmArgs g;   // PreNet (utils.py:13-18), dropout inactive
+  g.A1 = mels; g.lda1 = c.num_mels; g.K1 = c.num_mels; g.K = c.num_mels; g.Wt = h->post_d1_wt; g.ldw = c.num_mels; g.bias = h->post_d1_b;
+  g.act = c.post_pre_activation; g.C = xa; g.ldc = P; g.M = M; g.N = P;
+  TRY(run_gemm(h, g));
+  const float* pe = nullptr;
+  TRY(get_pe(h, Tz, P, 1.0f, &pe));
+  g = GemmArgs(); g.A1 = xa; g.lda1 = P; g.K1 = P; g.K = P; g.Wt = h->post_d2_wt; g.ldw = P; g.bias = h->post_d2_b; g.act = c.post_pre_activation;
+  g.pe = pe; g.pe_T = Tz; g.pe_w = h->post_pos_weight; g.C = xb; g.ldc = P; g.M = M; g.N = P;
+  TRY(run_gemm(h, g));               // + pos_weight * PE (posterior.py:120-121)
+  float* xc = xb; float* xn = xa;
+  for (size_t b = 0; b < h->post_blks.size(); ++b) {
+    TRY(run_xblk(h, h->post_blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.post_attention_heads,
+                 c.post_temperature, nullptr));
+    std::swap(xc, xn);
+  }
+  const int D = c.post_attention_dim;
+  g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->post_mu_wt; g.ldw = D; g.bias = h->post_mu_b; g.C = mu; g.ldc = C; g.M = M; g.N = C;
+  TRY(run_gemm(h, g));
+  g.Wt = h->post_lv_wt; g.bias = h->post_lv_b; g.C = logvar;
+  TRY(run_gemm(h, g));
+  return VNR_OK;
+}
+
+int check_ready(vnr_handle h) {
+  if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
+  if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
+  HIP_TRY(h, hipSetDevice(h->device));
+  return VNR_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int vnr_abi_version(void) { return VNR_ABI_VERSION; }
+
+const char* vnr_last_error(vnr_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int vnr_device_count(int* count) {
+  if (!count) return fail(nullptr, VNR_ERR_ARG, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(nullptr, VNR_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *count = n;
+  return VNR_OK;
+}
+
+int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
+  if (!cfg || !out) return fail(nullptr, VNR_ERR_ARG, "null argument");
+  if (cfg->abi_version != VNR_ABI_VERSION) return fail(nullptr, VNR_ERR_ARG, "vnr_config.abi_version mismatch");
+  auto bad = [&](const char* m) { return fail(nullptr, VNR_ERR_ARG, std::string("unsupported configuration: ") + m); };
+  if (cfg->enc_attention_dim != 64 * cfg->enc_attention_heads || cfg->dec_attention_dim != 64 * cfg->dec_attention_heads ||
+      cfg->prior_attention_dim != 64 * cfg->prior_attention_heads || cfg->post_attention_dim != 64 * cfg->post_attention_heads)
+    return bad("attention head width must be 64");
+  if ((cfg->latent_dim & 7) || (cfg->output_dim & 3) || (cfg->num_mels & 3) || (cfg->enc_embd_dim & 3) || (cfg->enc_pre_hidden & 3) ||
+      (cfg->enc_ffn_hidden & 3) || (cfg->dec_ffn_hidden & 3) || (cfg->prior_ffn_hidden & 3) || (cfg->post_ffn_hidden & 3) ||
+      (cfg->dec_post_conv_filters & 3) || (cfg->post_pre_hidden & 3))
+    return bad("channel counts must be multiples of 4 (latent_dim of 8)");
+  if (cfg->enc_n_conv < 1) return bad("the encoder prenet needs at least one conv layer");
+  if (!(cfg->enc_conv_kernel & 1) || !(cfg->dec_post_conv_kernel & 1)) return bad("conv kernels must be odd");
+  if (cfg->post_pre_hidden != cfg->post_attention_dim) return bad("posterior pre_hidden must equal attention_dim");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, VNR_ERR_HIP, "no HIP device available (libvaenar_hip needs an AMD GPU)");
+  if (device < 0 || device >= n) return fail(nullptr, VNR_ERR_ARG, "device index out of range");
+  vnr_handle h = new vnr_context();
+  h->cfg = *cfg;
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, VNR_ERR_HIP, "hipSetDevice / hipStreamCreate failed");
+  }
+  *out = h;
+  return VNR_OK;
+}
+
+int vnr_destroy(vnr_handle h) {
+  if (!h) return VNR_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  for (auto& kv : h->w) hipFree(kv.second.d);
+  for (auto p : h->packed_allocs) hipFree(p);
+  for (auto& c : h->chunks) hipFree(c.p);
+  for (auto& kv : h->pe_cache) hipFree(kv.second);
+  for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto e : h->event_pool) hipEventDestroy(e);
+  hipStreamDestroy(h->stream);
+  delete h;
+  return VNR_OK;
+}
+
+int vnr_device_info(vnr_handle h, char* name, int name_len, int* compute_units, int* wavefront) {
+  if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
+  hipDeviceProp_t p;
+  HIP_TRY(h, hipGetDeviceProperties(&p, h->device));
+  if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (wavefront) *wavefront = p.warpSize;
+  return VNR_OK;
+}
+
+int vnr_malloc(vnr_handle h, size_t bytes, void** d_ptr) {
+  if (!h || !d_ptr) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMalloc(d_ptr, bytes ? bytes : 4));
+  return VNR_OK;
+}
+int vnr_free(vnr_handle h, void* d_ptr) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  if (!d_ptr) return VNR_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipFree(d_ptr));
+  return VNR_OK;
+}
+int vnr_memcpy_h2d(vnr_handle h, void* d, const void* s, size_t n) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // pageable host memory may be reused by the caller
+  return VNR_OK;
+}
+int vnr_memcpy_d2h(vnr_handle h, void* dst, const void* s, size_t n) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(dst, s, n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VNR_OK;
+}
+int vnr_memcpy_d2d(vnr_handle h, void* dst, const void* s, size_t n) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(dst, s, n, hipMemcpyDeviceToDevice, h->stream));
+  return VNR_OK;
+}
+int vnr_memset(vnr_handle h, void* d, int value, size_t n) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemsetAsync(d, value, n, h->stream));
+  return VNR_OK;
+}
+int vnr_synchronize(vnr_handle h) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return VNR_OK;
+}
+
+int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int64_t* shape, int ndim) {
+  if (!h || !path || !host || ndim < 0 || ndim > 4 || (ndim > 0 && !shape)) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int64_t n = 1;
+  std::vector<int64_t> shp;
+  for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(h, VNR_ERR_ARG, "bad shape"); n *= shape[i]; shp.push_back(shape[i]); }
+  Tensor& t = h->w[path];
+  if (t.d && t.n != n) { hipFree(t.d); t.d = nullptr; }
+  if (!t.d) HIP_TRY(h, hipMalloc((void**)&t.d, (size_t)n * sizeof(float)));
+  t.n = n; t.shape = shp;
+  if (n == 1) t.scalar = host[0];
+  HIP_TRY(h, hipMemcpyAsync(t.d, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->finalized = false;
+  return VNR_OK;
+}
+
+int vnr_get_weight(vnr_handle h, const char* path, float* host, int64_t count) {
+  if (!h || !path || !host) return fail(h, VNR_ERR_ARG, "bad argument");
+  const Tensor* t = find_w(h, path);
+  if (!t) return fail(h, VNR_ERR_WEIGHT, std::string("unknown weight ") + path);
+  if (count != t->n) return fail(h, VNR_ERR_WEIGHT, std::string("element count mismatch for ") + path);
+  return vnr_memcpy_d2h(h, host, t->d, (size_t)count * sizeof(float));
+}
+
+int vnr_finalize_weights(vnr_handle h) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (auto p : h->packed_allocs) hipFree(p);
+  h->packed_allocs.clear();
+  h->enc_convs.clear(); h->post_convs.clear(); h->enc_blks.clear(); h->flow.clear(); h->dec_blks.clear(); h->post_blks.clear();
+  const vnr_config& c = h->cfg;
+  Packer P{h};
+  const int Dm = c.enc_pre_hidden, A = c.enc_attention_dim;
+  // ---- text encoder --------------------------------------------------------------------------------
+  h->emb = P.raw("text_encoder/emb_layer/embeddings", {c.enc_vocab_size, c.enc_embd_dim});
+  h->enc_pos_weight = P.scalar("text_encoder/pos_weight");
+  int cin = c.enc_embd_dim;
+  for (int i = 0; i < c.enc_n_conv; ++i) {
+    ConvL L; pack_conv(P, "text_encoder/prenet/conv_stack/" + std::to_string(i), c.enc_conv_kernel, cin, Dm, L);
+    h->enc_convs.push_back(L); cin = Dm;
+  }
+  h->enc_proj_wt = P.wt("text_encoder/prenet/projection/kernel", Dm, Dm);
+  h->enc_proj_b = P.raw("text_encoder/prenet/projection/bias", {Dm});
+  for (int i = 0; i < c.enc_n_blk; ++i) {
+    const std::string p = "text_encoder/self_attentions/" + std::to_string(i);
+    SBlk k;
+    float* qkv = P.alloc((size_t)3 * A * Dm);
+    P.transpose_into(P.raw(p + "/attention/query_layer/kernel", {Dm, A}), Dm, A, qkv, 0);
+    P.transpose_into(P.raw(p + "/attention/key_layer/kernel", {Dm, A}), Dm, A, qkv, A);
+    P.transpose_into(P.raw(p + "/attention/value_layer/kernel", {Dm, A}), Dm, A, qkv, 2 * A);
+    k.qkv_wt = qkv;
+    k.proj_wt = P.wt(p + "/att_proj/kernel", Dm + A, Dm);
+    k.proj_b = P.raw(p + "/att_proj/bias", {Dm});
+    k.ln_g = P.raw(p + "/layer_norm/gamma", {Dm}); k.ln_b = P.raw(p + "/layer_norm/beta", {Dm});
+    k.ffn1_wt = P.wt(p + "/ffn/dense1/kernel", Dm, c.enc_ffn_hidden); k.ffn1_b = P.raw(p + "/ffn/dense1/bias", {c.enc_ffn_hidden});
+    k.ffn2_wt = P.wt(p + "/ffn/dense2/kernel", c.enc_ffn_hidden, Dm); k.ffn2_b = P.raw(p + "/ffn/dense2/bias", {Dm});
+    k.ffn_g = P.raw(p + "/ffn/layer_norm/gamma", {Dm}); k.ffn_b = P.raw(p + "/ffn/layer_norm/beta", {Dm});
+    h->enc_blks.push_back(k);
+  }
+  h->lp_w = P.raw("length_predictor/projection/kernel", {Dm, 1});
+  h->lp_b = P.raw("length_predictor/projection/bias", {1});
+  // ---- prior + decoder: one stacked cross-attention K|V panel (prior blocks first, decoder after) ------
+  const int C = c.latent_dim, half = C / 2, Dp = c.prior_attention_dim, Dd = c.dec_attention_dim;
+  h->prior_kv_n = c.prior_n_blk * c.prior_n_transformer_blk * 2 * Dp;
+  h->dec_kv_n = c.dec_nblk * 2 * Dd;
+  float* kv_panel = P.alloc((size_t)(h->prior_kv_n + h->dec_kv_n) * Dm);
+  h->prior_kv_wt = kv_panel;
+  h->dec_kv_wt = kv_panel ? kv_panel + (size_t)h->prior_kv_n * Dm : nullptr;
+  std::vector<double> Wh((size_t)C * C);
+  std::vector<float> Wf((size_t)C * C), lsf(C);
+  for (int s = 0; s < c.prior_n_blk; ++s) {
+    const std::string p = "prior/glow/" + std::to_string(s);
+    FlowStep f;
+    const float* ls = P.raw(p + "/0/log_scale", {C});
+    const float* ab = P.raw(p + "/0/bias", {C});
+    const float* W = P.raw(p + "/1/weight", {C, C});
+    float* fw = P.alloc((size_t)C * C); float* fb = P.alloc(C);
+    if (P.rc == VNR_OK) {
+      if (launch_fold_actnorm_linear(ls, ab, W, C, fw, fb, h->stream) != hipSuccess) { P.rc = VNR_ERR_HIP; P.missing = "fold launch"; }
+      if (hipMemcpy(Wf.data(), W, (size_t)C * C * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(lsf.data(), ls, (size_t)C * 4, hipMemcpyDeviceToHost) != hipSuccess) { P.rc = VNR_ERR_HIP; P.missing = "d2h for slogdet"; }
+      for (size_t i = 0; i < Wf.size(); ++i) Wh[i] = (double)Wf[i];
+      float lssum = 0.f;   // tf.reduce_sum(log_scale) in fp32 (flow.py:168)
+      for (int i = 0; i < C; ++i) lssum += lsf[i];
+      f.logdet_per_frame = (double)lssum + (double)(float)slogdet_abs(Wh, C);   // cast to fp32, flow.py:127-129
+    }
+    f.fold_wt = fw; f.fold_b = fb;
+    f.pos_weight = P.scalar(p + "/2/net/pos_weight");
+    f.pre_wt = P.wt(p + "/2/net/pre_projection/kernel", half, Dp);
+    f.pre_b = P.raw(p + "/2/net/pre_projection/bias", {Dp});
+    float* hw = P.alloc((size_t)C * Dp); float* hb = P.alloc(C);
+    P.transpose_into(P.raw(p + "/2/net/log_scale_proj/kernel", {Dp, half}), Dp, half, hw, 0);
+    P.transpose_into(P.raw(p + "/2/net/shift_proj/kernel", {Dp, half}), Dp, half, hw, half);
+    P.copy_into(P.raw(p + "/2/net/log_scale_proj/bias", {half}), hb, half);
+    P.copy_into(P.raw(p + "/2/net/shift_proj/bias", {half}), hb ? hb + half : nullptr, half);
+    f.heads_wt = hw; f.heads_b = hb;
+    for (int b = 0; b < c.prior_n_transformer_blk; ++b) {
+      XBlk k;
+      pack_xblk(P, p + "/2/net/attentions/" + std::to_string(b), Dp, Dm, c.prior_ffn_hidden, kv_panel,
+                (s * c.prior_n_transformer_blk + b) * 2 * Dp, k);
+      f.blks.push_back(k);
+    }
+    h->flow.push_back(f);
+  }
+  h->dec_pre_wt = P.wt("decoder/pre_projection/kernel", C, Dd);
+  h->dec_pre_b = P.raw("decoder/pre_projection/bias", {Dd});
+  for (int b = 0; b < c.dec_nblk; ++b) {
+    XBlk k;
+    pack_xblk(P, "decoder/attentions/" + std::to_string(b), Dd, Dm, c.dec_ffn_hidden, kv_panel, h->prior_kv_n + b * 2 * Dd, k);
+    k.kv_col = b * 2 * Dd;   // relative to the decoder panel; vnr_inference adds prior_kv_n
+    h->dec_blks.push_back(k);
+  }
+  const int od = c.output_dim, nout = od * c.max_reduction_factor;
+  h->dec_out_wt = P.wt("decoder/out_projection/kernel", Dd, nout);
+  h->dec_out_b = P.raw("decoder/out_projection/bias", {nout});
+  cin = od;
+  for (int i = 0; i < c.dec_post_n_conv; ++i) {
+    ConvL L; pack_conv(P, "decoder/postnet/conv_stack/" + std::to_string(i), c.dec_post_conv_kernel, cin, c.dec_post_conv_filters, L);
+    h->post_convs.push_back(L); cin = c.dec_post_conv_filters;
+  }
+  h->dec_res_wt = P.wt("decoder/residual_projection/kernel", cin, od);
+  h->dec_res_b = P.raw("decoder/residual_projection/bias", {od});
+  // ---- posterior (optional: only present for training / ELBO evaluation) ---------------------------------
+  h->has_posterior = find_w(h, "posterior/pos_weight") != nullptr;
+  if (h->has_posterior) {
+    const int Pq = c.post_pre_hidden, Dq = c.post_attention_dim;
+    h->post_pos_weight = P.scalar("posterior/pos_weight");
+    h->post_d1_wt = P.wt("posterior/prenet/dense1/kernel", c.num_mels, Pq); h->post_d1_b = P.raw("posterior/prenet/dense1/bias", {Pq});
+    h->post_d2_wt = P.wt("posterior/prenet/dense2/kernel", Pq, Pq); h->post_d2_b = P.raw("posterior/prenet/dense2/bias", {Pq});
+    h->post_kv_n = c.post_nblk * 2 * Dq;
+    float* pkv = P.alloc((size_t)h->post_kv_n * Dm);
+    h->post_kv_wt = pkv;
+    for (int b = 0; b < c.post_nblk; ++b) {
+      XBlk k; pack_xblk(P, "posterior/attentions/" + std::to_string(b), Dq, Dm, c.post_ffn_hidden, pkv, b * 2 * Dq, k);
+      h->post_blks.push_back(k);
+    }
+    h->post_mu_wt = P.wt("posterior/mu_projection/kernel", Dq, C); h->post_mu_b = P.raw("posterior/mu_projection/bias", {C});
+    h->post_lv_wt = P.wt("posterior/logvar_projection/kernel", Dq, C); h->post_lv_b = P.raw("posterior/logvar_projection/bias", {C});
+  }
+  if (P.rc != VNR_OK) return fail(h, P.rc, P.missing);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->finalized = true;
+  return VNR_OK;
+}
+
+// ---- modules ------------------------------------------------------------------------------------------
+int vnr_text_encoder_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_lengths, int B, int T, float pos_step, float* d_out) {
+  TRY(check_ready(h));
+  if (!d_ids || !d_out || B <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  return encoder_body(h, d_ids, d_lengths, B, T, pos_step, d_out);
+}
+
+int vnr_length_predictor_fwd(vnr_handle h, const float* d_text_embd, const int32_t* d_lengths, int B, int T, float* d_out) {
+  TRY(check_ready(h));
+  if (!d_text_embd || !d_out || B <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  RUN_MISC(h, launch_length_predictor(d_text_embd, h->lp_w, h->lp_b, d_lengths, B, T, h->cfg.enc_pre_hidden,
+                                      h->cfg.lenpred_activation, d_out, h->stream));
+  return VNR_OK;
+}
+
+int vnr_prior_sample(vnr_handle h, const int32_t* d_z_lengths, const float* d_text_embd, const int32_t* d_text_lengths,
+                     int B, int Tz, int Tt, const float* d_eps, float* d_z, float* d_logprobs) {
+  TRY(check_ready(h));
+  if (!d_z_lengths || !d_text_embd || !d_z || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  WS(kv, (size_t)B * Tt * h->prior_kv_n);
+  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv));
+  return prior_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs);
+}
+
+int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+                    const int32_t* d_text_lengths, int B, int Tz, int Tt, int reduction_factor, float* d_initial,
+                    float* d_outputs, float* d_alignments) {
+  TRY(check_ready(h));
+  if (!d_z || !d_text_embd || !d_outputs || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  WS(kv, (size_t)B * Tt * h->dec_kv_n);
+  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->dec_kv_wt, h->dec_kv_n, kv));
+  return decoder_body(h, d_z, kv, h->dec_kv_n, d_z_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, d_initial,
+                      d_outputs, d_alignments);
+}
+
+int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_embd, const int32_t* d_text_lengths,
+                      const int32_t* d_target_lengths, int B, int Tz, int Tt, float* d_mu, float* d_logvar) {
+  TRY(check_ready(h));
+  if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
+  if (!d_mels || !d_text_embd || !d_mu || !d_logvar || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  WS(kv, (size_t)B * Tt * h->post_kv_n);
+  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->post_kv_wt, h->post_kv_n, kv));
+  return posterior_body(h, d_mels, kv, h->post_kv_n, d_text_lengths, d_target_lengths, B, Tz, Tt, d_mu, d_logvar);
+}
+
+int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths,
+                  int B, int Tt, int Tz, int reduction_factor, float pos_step, const float* d_eps, float* d_mel,
+                  float* d_alignments, float* d_text_embd_out) {
+  TRY(check_ready(h));
+  if (!d_ids || !d_reduced_lengths || !d_mel || B <= 0 || Tt <= 0 || Tz <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  const int Dm = h->cfg.enc_pre_hidden, C = h->cfg.latent_dim;
+  float* text_embd = d_text_embd_out;
+  if (!text_embd) { WS(t, (size_t)B * Tt * Dm); text_embd = t; }
+  TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
+  // every cross-attention K|V of the memory (all prior blocks + decoder blocks) in one GEMM
+  const int kv_n = h->prior_kv_n + h->dec_kv_n;
+  WS(kv, (size_t)B * Tt * kv_n);
+  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, kv_n, kv));
+  WS(z, (size_t)B * Tz * C);
+  TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kv, kv_n, B, Tz, Tt, d_eps, z, nullptr));
+  return decoder_body(h, z, kv + h->prior_kv_n, kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor,
+                      nullptr, d_mel, d_alignments);
+}
+
+// ---- single operators ---------------------------------------------------------------------------------------
+int vnr_op_dense(vnr_handle h, const vnr_dense_desc* d) {
+  if (!h || !d) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int K = d->k1 + d->k2;
+  if (!d->d_a1 || !d->d_w || !d->d_c || d->m <= 0 || d->n <= 0 || K <= 0) return fail(h, VNR_ERR_ARG, "bad dense descriptor");
+  ws_reset(h);
+  WS(wt, (size_t)K * d->n);
+  RUN_MISC(h, launch_transpose(d->d_w, K, d->n, wt, K, h->stream));
+  GemmArgs g;
+  g.A1 = d->d_a1; g.lda1 = d->lda1; g.K1 = d->k1; g.A2 = d->k2 > 0 ? d->d_a2 : nullptr; g.lda2 = d->lda2; g.K = K;
+  g.Wt = wt; g.ldw = K; g.bias = d->d_bias; g.act = d->activation; g.residual = d->d_residual; g.ldr = d->ldr;
+  g.pe = d->d_pe; g.pe_T = d->pe_T > 0 ? d->pe_T : 1; g.pe_w = d->pe_weight; g.C = d->d_c; g.ldc = d->ldc; g.M = d->m; g.N = d->n;
+  if (d->d_ln_gamma && d->d_ln_beta) {
+    if (d->n <= 256 && !d->d_pe) { g.ln_gamma = d->d_ln_gamma; g.ln_beta = d->d_ln_beta; return run_gemm(h, g); }
+    if (d->ldc != d->n) return fail(h, VNR_ERR_ARG, "LayerNorm epilogue needs a dense output (ldc == n)");
+    TRY(run_gemm(h, g));
+    return run_ln(h, d->d_c, d->d_ln_gamma, d->d_ln_beta, d->m, d->n, d->d_c);
+  }
+  return run_gemm(h, g);
+}
+
+int vnr_op_conv1d_bn(vnr_handle h, const float* d_x, int B, int T, int Cin, const float* d_kernel, int k, int Cout,
+                     const float* d_bias, int activation, int bn_before_act, const float* d_gamma, const float* d_beta,
+                     const float* d_mean, const float* d_var, float* d_y) {
+  if (!h || !d_x || !d_kernel || !d_y || !(k & 1)) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  ws_reset(h);
+  WS(wt, (size_t)k * Cin * Cout); WS(sc, Cout); WS(sh, Cout);
+  RUN_MISC(h, launch_transpose(d_kernel, k * Cin, Cout, wt, k * Cin, h->stream));
+  ConvL L; L.wt = wt; L.bias = d_bias; L.bn_scale = nullptr; L.bn_shift = nullptr; L.k = k; L.cin = Cin; L.cout = Cout;
+  if (d_gamma) {
+    RUN_MISC(h, launch_bn_affine(d_gamma, d_beta, d_mean, d_var, Cout, sc, sh, h->stream));
+    L.bn_scale = sc; L.bn_shift = sh;
+  }
+  return run_conv(h, L, d_x, nullptr, B, T, activation, bn_before_act, d_y);
+}
+
+int vnr_op_attention(vnr_handle h, const float* d_q, int ldq, const float* d_k, int ldk, const float* d_v, int ldv,
+                     const int32_t* d_q_lengths, const int32_t* d_k_lengths, int B, int H, int Tq, int Tk, int causal,
+                     float temperature, float* d_ctx, int ldo, float* d_alignments) {
+  if (!h || !d_q || !d_k || !d_v || !d_ctx) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  AttnArgs a;
+  a.Q = d_q; a.ldq = ldq; a.K = d_k; a.ldk = ldk; a.V = d_v; a.ldv = ldv; a.q_len = d_q_lengths; a.k_len = d_k_lengths;
+  a.ctx = d_ctx; a.ldo = ldo; a.ali = d_alignments; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.temperature = temperature;
+  a.q_bs = (long long)Tq * ldq; a.k_bs = (long long)Tk * ldk; a.v_bs = (long long)Tk * ldv; a.o_bs = (long long)Tq * ldo;
+  return run_attention(h, a, !causal);
+}
+
+int vnr_op_layer_norm(vnr_handle h, const float* d_x, const float* d_gamma, const float* d_beta, int rows, int dim, float* d_y) {
+  if (!h || !d_x || !d_gamma || !d_beta || !d_y) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  return run_ln(h, d_x, d_gamma, d_beta, rows, dim, d_y);
+}
+
+int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* d_out) {
+  if (!h || !d_out) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  RUN_MISC(h, launch_positional_encoding(T, dim, step, d_out, h->stream));
+  return VNR_OK;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------------------
+int vnr_profile_enable(vnr_handle h, int on) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  h->profiling = on != 0;
+  return VNR_OK;
+}
+int vnr_profile_reset(vnr_handle h) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (auto& r : h->prof) { h->event_pool.push_back(r.e0); h->event_pool.push_back(r.e1); }
+  h->prof.clear();
+  return VNR_OK;
+}
+int vnr_profile_get(vnr_handle h, const char* kernel_class, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!h || !kernel_class) return fail(h, VNR_ERR_ARG, "null argument");
+  int cls = -1;
+  for (int i = 0; i < CLS_COUNT; ++i) if (!strcmp(kernel_class, kClsNames[i])) cls = i;
+  if (cls < 0) return fail(h, VNR_ERR_ARG, std::string("unknown kernel class ") + kernel_class);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double ms = 0, fl = 0, by = 0; int64_t n = 0;
+  for (auto& r : h->prof) {
+    if (r.cls != cls) continue;
+    float t = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t; fl += r.flops; by += r.bytes; ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return VNR_OK;
+}
+int vnr_launch_count(vnr_handle h, int64_t* count) {
+  if (!h || !count) return fail(h, VNR_ERR_ARG, "null argument");
+  *count = h->launches;
+  return VNR_OK;
+}
+
+}  // extern "C"

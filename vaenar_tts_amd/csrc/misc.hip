@@ -1,0 +1,294 @@
+// Small HBM-bound kernels of the VAENAR-TTS path (gfx950): LayerNorm, positional-encoding table,
+// flow coupling, length predictor, masked reductions and weight preparation.
+// Wavefront = 64 lanes everywhere; row reductions use wave shuffles.
+#include "common.h"
+#include <math.h>
+
+namespace vnr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- tf.keras.layers.LayerNormalization(): one wave per row, two-pass statistics in registers ---
+// (attention.py:402,428,433; utils.py:46).  dim % 4 == 0, dim <= 64*4*VPT.
+template <int VPT>   // float4 per lane
+__global__ void __launch_bounds__(256)
+layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, int rows, int dim, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * dim;
+  float4 v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (lane + i * 64) * 4;
+    v[i] = (c < dim) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < dim) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + kLnEps);
+  float* yr = y + (size_t)row * dim;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < dim) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+    }
+  }
+}
+
+hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
+                             int dim, float* y, hipStream_t s) {
+  if (rows <= 0 || dim <= 0 || (dim & 3) || dim > 2048) return hipErrorInvalidValue;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (dim <= 256) hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else if (dim <= 512) hipLaunchKernelGGL(layer_norm_kernel<2>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else if (dim <= 1024) hipLaunchKernelGGL(layer_norm_kernel<4>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else hipLaunchKernelGGL(layer_norm_kernel<8>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  return hipGetLastError();
+}
+
+// ---- PositionalEncoding.positional_encoding (utils.py:333-355) ----------------------------------
+// The reference evaluates every stage in float32; each stage here is the correctly rounded
+// float32 value (transcendentals evaluated in double, then rounded).
+__global__ void pe_kernel(int T, int dim, float step, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * dim) return;
+  const int t = idx / dim, d = idx - t * dim;
+  const float pos = (float)t * step;                                  // utils.py:342
+  const float df = (float)d;
+  const bool even = (d & 1) == 0;                                     // utils.py:351-352
+  const float e = (even ? df : df - 1.0f) / (float)dim;               // utils.py:353-354
+  const float w = (float)pow(10000.0, (double)e);
+  const float arg = pos / w;
+  out[idx] = even ? (float)sin((double)arg) : (float)cos((double)arg);
+}
+
+hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s) {
+  if (T <= 0 || dim <= 0) return hipErrorInvalidValue;
+  const int n = T * dim;
+  hipLaunchKernelGGL(pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, T, dim, step, out);
+  return hipGetLastError();
+}
+
+// ---- weight layout: out[c*ldo + r] = in[r*cols + c] ----------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols,
+                                 float* __restrict__ out, int ldo) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = by + i, c = bx + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = bx + i, r = by + threadIdx.x;
+    if (c < cols && r < rows) out[(size_t)c * ldo + r] = tile[threadIdx.x][i];
+  }
+}
+
+hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int ldo, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s,
+                     in, rows, cols, out, ldo);
+  return hipGetLastError();
+}
+
+// ---- TransformerCoupling._forward tail (flow.py:231-237) -----------------------------------------
+// heads [M, 2*half] = log_scale | shift ; zp = z[:, zp_off : zp_off+half] updated in place;
+// row_logdet[m] = sum_c log(sigmoid(log_scale + 2)).  One wave per row.
+__global__ void __launch_bounds__(256)
+coupling_fwd_kernel(const float* __restrict__ heads, float* __restrict__ z, int M, int half,
+                    int ldz, int zp_off, float* __restrict__ row_logdet) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* hr = heads + (size_t)row * 2 * half;
+  float* zr = z + (size_t)row * ldz + zp_off;
+  float acc = 0.f;
+  for (int c = lane; c < half; c += 64) {
+    const float ls = hr[c], sh = hr[half + c];
+    const float scale = 1.0f / (1.0f + expf(-(ls + 2.0f)));            // tf.math.sigmoid(log_scale + 2)
+    zr[c] = scale * zr[c] + sh;                                        // _affine, flow.py:216
+    acc += logf(scale);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && row_logdet) row_logdet[row] = acc;
+}
+
+hipError_t launch_coupling_fwd(const float* heads, float* z, int M, int half, int zp_off,
+                               float* row_logdet, hipStream_t s) {
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
+                     2 * half, zp_off, row_logdet);
+  return hipGetLastError();
+}
+
+// ---- out[b] (+)= scale * sum_{t < len[b]} rows[b*T + t]; fixed summation order, fp64 accumulate ---
+__global__ void __launch_bounds__(64)
+masked_row_reduce_kernel(const float* __restrict__ rows, const int32_t* __restrict__ len, int T,
+                         float scale, float* __restrict__ out, int accumulate) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = len ? min(len[b], T) : T;
+  double acc = 0.0;
+  for (int t = lane; t < n; t += 64) acc += (double)rows[(size_t)b * T + t];
+  acc = wave_sum_d(acc);
+  if (lane == 0) {
+    const float v = scale * (float)acc;
+    out[b] = accumulate ? out[b] + v : v;
+  }
+}
+
+hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T, float scale,
+                                    float* out, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(masked_row_reduce_kernel, dim3(B), dim3(64), 0, s, rows, len, T, scale, out,
+                     accumulate);
+  return hipGetLastError();
+}
+
+// ---- DenseLengthPredictor.call (length_predictor.py:35-42) ----------------------------------------
+// One workgroup (4 waves) per utterance; a wave takes rows t = wave, wave+4, ...; the dot product
+// x[b,t,:].w is a wave reduction; exp in fp32 like the reference; the final masked sum over time is
+// accumulated in fp64 (it feeds an int32 truncation, inference.py:135).
+__global__ void __launch_bounds__(256)
+length_predictor_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                        const float* __restrict__ bias, const int32_t* __restrict__ len, int T,
+                        int D, int act, float* __restrict__ out) {
+  __shared__ double part[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = len ? min(len[b], T) : T;
+  double acc = 0.0;
+  for (int t = wave; t < n; t += 4) {
+    const float* xr = x + ((size_t)b * T + t) * D;
+    float d = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+      const float4 wv = *reinterpret_cast<const float4*>(w + c);
+      d += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+    }
+    d = wave_sum(d) + bias[0];
+    if (act == ACT_RELU) d = fmaxf(d, 0.f);
+    else if (act == ACT_TANH) d = tanhf(d);
+    acc += (double)expf(d);
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (float)((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+hipError_t launch_length_predictor(const float* x, const float* w, const float* bias,
+                                   const int32_t* len, int B, int T, int D, int act, float* out,
+                                   hipStream_t s) {
+  if (D & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(length_predictor_kernel, dim3(B), dim3(256), 0, s, x, w, bias, len, T, D, act, out);
+  return hipGetLastError();
+}
+
+// ---- BasePrior._initial_sample log-probability (prior.py:36-41) -----------------------------------
+__global__ void __launch_bounds__(256)
+gauss_logprob_kernel(const float* __restrict__ eps, const int32_t* __restrict__ len, int T, int C,
+                     float* __restrict__ out) {
+  __shared__ double part[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = len ? min(len[b], T) : T;
+  const float log2pi = 1.8378770664093453f;
+  double acc = 0.0;
+  const size_t total = (size_t)n * C;
+  const float* e = eps ? eps + (size_t)b * T * C : nullptr;
+  for (size_t i = threadIdx.x; i < total; i += 256) {
+    const float v = e ? e[i] : 0.f;
+    acc += (double)(-0.5f * (log2pi + v * v));
+  }
+  acc = wave_sum_d(acc);
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (float)((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+hipError_t launch_gauss_logprob(const float* eps, const int32_t* len, int B, int T, int C, float* out,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(gauss_logprob_kernel, dim3(B), dim3(256), 0, s, eps, len, T, C, out);
+  return hipGetLastError();
+}
+
+__global__ void axpy_len_kernel(float* y, const int32_t* len, float alpha, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) y[b] += alpha * (float)len[b];
+}
+hipError_t launch_axpy_len(float* y, const int32_t* len, float alpha, int B, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, B);
+  return hipGetLastError();
+}
+
+// ---- ActNorm o InvertibleLinear folding (flow.py:166-175 then 123-135) ----------------------------
+// (z*exp(ls) + b).W == z.(diag(exp(ls)) W) + b.W  ->  Wt_out[n][k] = exp(ls[k]) W[k][n], b_out = b.W
+__global__ void fold_actnorm_linear_kernel(const float* __restrict__ ls, const float* __restrict__ bias,
+                                           const float* __restrict__ W, int C, float* __restrict__ Wt,
+                                           float* __restrict__ bout) {
+  const int n = blockIdx.x;            // output channel
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < C; k += blockDim.x) {
+    const float w = W[(size_t)k * C + n];
+    Wt[(size_t)n * C + k] = expf(ls[k]) * w;
+    acc += (double)bias[k] * (double)w;
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+    bout[n] = (float)t;
+  }
+}
+hipError_t launch_fold_actnorm_linear(const float* log_scale, const float* bias, const float* W, int C,
+                                      float* Wt_out, float* b_out, hipStream_t s) {
+  hipLaunchKernelGGL(fold_actnorm_linear_kernel, dim3(C), dim3(128), 0, s, log_scale, bias, W, C,
+                     Wt_out, b_out);
+  return hipGetLastError();
+}
+
+// ---- BatchNormalization inference affine (tf.nn.batch_normalization): -----------------------------
+// inv = gamma * rsqrt(var + eps); y = x*inv + (beta - mean*inv)
+__global__ void bn_affine_kernel(const float* gamma, const float* beta, const float* mean,
+                                 const float* var, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = gamma[c] * (1.0f / sqrtf(var[c] + kBnEps));
+  scale[c] = inv;
+  shift[c] = beta[c] - mean[c] * inv;
+}
+hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* mean, const float* var,
+                            int C, float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, s, gamma, beta, mean, var,
+                     C, scale, shift);
+  return hipGetLastError();
+}
+
+}  // namespace vnr

@@ -1,0 +1,115 @@
+"""models.VAENAR mirror (/root/reference/models/models.py:9-226) on the MI355X engine.
+
+Same constructor reads of ``hps`` and the same public attributes the reference scripts reach
+into (inference.py:129-142: text_encoder, length_predictor, prior, decoder, mel_text_len_ratio).
+Returned tensors are device arrays exposing ``.numpy()``.
+"""
+import numpy as np
+
+from ._lib import Engine, check
+from .modules import (TransformerEncoder, TransformerDecoder, TransformerPrior, TransformerPosterior,
+                      DenseLengthPredictor)
+
+
+class VAENAR:
+    def __init__(self, hps, name='VAENAR', device=0, weights=None, **kwargs):
+        self.name = name
+        self.hps = hps
+        self.engine = Engine(hps, device)
+        eng = self.engine
+        self.n_sample = hps.Train.num_samples                                   # models.py:13
+        self.mel_text_len_ratio = hps.Common.mel_text_len_ratio                 # models.py:14
+        self.max_reduction_factor = hps.Common.max_reduction_factor             # models.py:15
+        e = hps.Encoder.Transformer
+        self.text_encoder = TransformerEncoder(                                 # models.py:16-30
+            vocab_size=e.vocab_size, embd_dim=e.embd_dim, pre_nconv=e.n_conv, pre_hidden=e.pre_hidden,
+            pre_conv_kernel=e.conv_kernel, pre_activation=e.pre_activation,
+            prenet_drop_rate=e.pre_drop_rate, bn_before_act=e.bn_before_act,
+            pos_drop_rate=e.pos_drop_rate, nblk=e.n_blk, attention_dim=e.attention_dim,
+            attention_heads=e.attention_heads, attention_temperature=e.attention_temperature,
+            ffn_hidden=e.ffn_hidden, engine=eng)
+        d = hps.Decoder.Transformer
+        self.decoder = TransformerDecoder(                                      # models.py:31-43
+            nblk=d.nblk, attention_dim=d.attention_dim, attention_heads=d.attention_heads,
+            temperature=d.attention_temperature, ffn_hidden=d.ffn_hidden, post_n_conv=d.post_n_conv,
+            post_conv_filters=d.post_conv_filters, post_conv_kernel=d.post_conv_kernel,
+            post_drop_rate=d.post_drop_rate, out_dim=hps.Common.output_dim,
+            max_reduction_factor=hps.Common.max_reduction_factor, name='transformer_decoder', engine=eng)
+        self.length_predictor = DenseLengthPredictor(                           # models.py:44-45
+            activation=hps.LengthPredictor.Dense.activation, engine=eng)
+        q = hps.Posterior.Transformer
+        self.posterior = TransformerPosterior(                                  # models.py:46-56
+            pre_hidden=q.pre_hidden, pos_drop_rate=q.pos_drop_rate, pre_drop_rate=q.pre_drop_rate,
+            pre_activation=q.pre_activation, nblk=q.nblk, attention_dim=q.attention_dim,
+            attention_heads=q.attention_heads, temperature=q.temperature, ffn_hidden=q.ffn_hidden,
+            latent_dim=hps.Common.latent_dim, engine=eng)
+        p = hps.Prior.Transformer
+        self.prior = TransformerPrior(                                          # models.py:57-65
+            n_blk=p.n_blk, channels=hps.Common.latent_dim, n_transformer_blk=p.n_transformer_blk,
+            attention_dim=p.attention_dim, attention_heads=p.attention_heads,
+            temperature=p.temperature, ffn_hidden=p.ffn_hidden, inverse=p.inverse, engine=eng)
+        if weights is not None:
+            self.load_weights(weights)
+
+    # weights (replaces tf.train.Checkpoint(model=model).restore, inference.py:122-123) -------------
+    def load_weights(self, weights):
+        """``weights``: {path: ndarray} (vaenar_tts_amd.weights) or a path to an .npz of it."""
+        if isinstance(weights, str):
+            from .weights import load_npz
+            weights = load_npz(weights)
+        self.engine.load_weights(weights)
+
+    # models.py:199-210 ----------------------------------------------------------------------------
+    def inference(self, inputs, mel_lengths, text_lengths=None, reduction_factor=2, eps=None,
+                  temperature=1.0, return_alignments=True, fused=True):
+        """VAENAR.inference: (predicted_mel [B, Tz*rf, out_dim], {decoder-attention-i: alignments}).
+        ``eps``: injected prior noise (already times temperature) for parity runs; default: drawn
+        like prior.sample's tf.random.normal with temperature 1.0 (prior.py:154).
+        ``fused=True`` runs the whole path as ONE library call on one stream (vnr_inference);
+        ``fused=False`` goes module by module exactly like models.py:201-209."""
+        eng = self.engine
+        rf = int(reduction_factor)
+        ml = mel_lengths.numpy() if hasattr(mel_lengths, "numpy") and not isinstance(mel_lengths, np.ndarray) \
+            else np.asarray(mel_lengths)
+        reduced = ((ml.astype(np.int64) + rf - 1) // rf).astype(np.int32)       # models.py:200
+        pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:201
+        if not fused:
+            text_embd = self.text_encoder(inputs, text_lengths, pos_step=pos_step, training=False)
+            z, _ = self.prior.sample(reduced, text_embd, text_lengths, training=False,
+                                     temperature=temperature, eps=eps)
+            _, mel, ali = self.decoder(inputs=z, text_embd=text_embd, z_lengths=reduced,
+                                       text_lengths=text_lengths, training=False, reduction_factor=rf,
+                                       return_alignments=return_alignments)
+            return mel, ali
+        ids = eng.asarray(inputs, np.int32)
+        B, Tt = ids.shape
+        Tz = int(reduced.max())
+        tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
+        rl = eng.to_device(reduced, np.int32)
+        C = self.hps.Common.latent_dim
+        if eps is None and float(temperature) != 0.0:
+            eps = (np.float32(temperature) * self.prior.rng.standard_normal((B, Tz, C))).astype(np.float32)
+        eps_d = None if eps is None else eng.asarray(eps, np.float32)
+        if eps_d is not None:
+            assert eps_d.shape == (B, Tz, C), (eps_d.shape, (B, Tz, C))
+        dec = self.decoder
+        mel = eng.empty((B, Tz * rf, dec.out_dim))
+        ali = eng.empty((dec.nblk, B, dec.heads, Tz, Tt)) if return_alignments else None
+        check(eng.lib.vnr_inference(eng.handle, ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, rf, float(pos_step),
+                                    None if eps_d is None else eps_d.ptr, mel.ptr,
+                                    None if ali is None else ali.ptr, None), eng.handle)
+        alignments = {}
+        if ali is not None:
+            n = B * dec.heads * Tz * Tt
+            for i, nm in enumerate(dec.block_names):
+                alignments[nm] = ali.view(i * n, (B, dec.heads, Tz, Tt))
+        return mel, alignments
+
+    def __call__(self, inputs, mel_targets, mel_lengths, text_lengths=None, reduction_factor=2,
+                 training=None, reduce_loss=None):
+        raise NotImplementedError("VAENAR.call (ELBO forward/backward, models.py:105-197) is not built yet")
+
+    call = __call__
+
+    def init(self, text_inputs, mel_lengths, text_lengths=None):
+        raise NotImplementedError("VAENAR.init (data-dependent ActNorm init, models.py:212-226) is not built yet")

@@ -1,0 +1,43 @@
+"""TransformerPrior mirror (/root/reference/modules/prior.py:79-186)."""
+import numpy as np
+
+from ._base import EngineModule, check
+
+
+class TransformerPrior(EngineModule):
+    def __init__(self, n_blk, channels, n_transformer_blk, attention_dim, attention_heads,
+                 temperature, ffn_hidden, inverse=False, name='GlowPrior', engine=None, **kwargs):
+        super().__init__(name, engine)
+        if inverse:
+            raise NotImplementedError("inverse=True flows are not used by LJHPS/DataBakerHPS (hparams.py:344)")
+        self.channels = channels
+        self.rng = np.random.Generator(np.random.PCG64(0))
+
+    def sample(self, targets_lengths, condition_inputs, condition_lengths=None, training=None,
+               temperature=1.0, eps=None, return_logprobs=True):
+        """prior.py:154-169.  ``eps`` (already scaled by the temperature, [B, max(len), C]) replaces
+        tf.random.normal (prior.py:35) when given; otherwise it is drawn on the host from
+        ``self.rng`` (temperature 0 -> exact zeros, the inference.py:95 default)."""
+        self._no_training(training)
+        e = self.engine
+        lens_h = targets_lengths.numpy() if hasattr(targets_lengths, "numpy") and not isinstance(
+            targets_lengths, np.ndarray) else np.asarray(targets_lengths)
+        lens_h = lens_h.astype(np.int32)
+        B, Tz = len(lens_h), int(lens_h.max())                  # prior.py:33-34
+        cond = self._f32(condition_inputs)
+        Tt = cond.shape[1]
+        zl = e.asarray(targets_lengths if not isinstance(targets_lengths, np.ndarray) else lens_h, np.int32)
+        tl = self._i32(condition_lengths, B, Tt)
+        if eps is None and float(temperature) != 0.0:
+            eps = (np.float32(temperature) * self.rng.standard_normal((B, Tz, self.channels))).astype(np.float32)
+        eps_d = None if eps is None else self._f32(eps)
+        if eps_d is not None:
+            assert eps_d.shape == (B, Tz, self.channels), (eps_d.shape, (B, Tz, self.channels))
+        z = e.empty((B, Tz, self.channels))
+        logp = e.empty((B,)) if return_logprobs else None
+        check(e.lib.vnr_prior_sample(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr,
+                                     self._ptr(logp)), e.handle)
+        return z, logp
+
+    def log_probability(self, z, condition_inputs, z_lengths=None, condition_lengths=None, training=None):
+        raise NotImplementedError("prior.log_probability (training path, prior.py:119-152) is not built yet")

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- mel-frames/sec of VAENAR.inference on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the text->mel hot path (text encoder -> flow prior sample -> decoder,
+models.py:199-210) over one synthetic batch S1 = (B=16, T_text=128, T_mel=800, 80 bins, rf=2) whose
+inputs (token ids, lengths, prior noise) are already resident in HBM.  With N GPUs every rank runs
+its own S1 batch (weak scaling, utterances are independent -> no data-path collective; the only
+cross-rank traffic is the timing barrier / max, done over gloo).
+
+Output: ONE JSON line on rank 0 (see the contract in the task description) with, besides the
+throughput, a `roofline` object for the dominant kernel (the fp32-MFMA GEMM family), a
+`roofline_cross_attention` object for the decoder cross-attention core (HBM-bound kernel named by
+the north star), a `cpu_baseline` (the NumPy oracle, fp32, timed on this box's host cores) and a
+`parity` object (max-abs mel error of the measured GPU output vs that CPU run).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+S1 = dict(B=16, T_text=128, T_mel=800, rf=2)
+ALG_GFLOP_S1 = 343.2           # algorithmic FLOPs of one S1 inference batch
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    from vaenar_tts_amd import dist as vdist
+    rank, local_rank, world = vdist.init("gloo")      # control plane only; no data-path collective
+    barrier = vdist.barrier if world > 1 else (lambda: None)
+
+    from vaenar_tts_amd import _lib
+    from vaenar_tts_amd.configs import LJHPS
+    from vaenar_tts_amd.models import VAENAR
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.weights import init_weights
+
+    hps = LJHPS
+    ndev = _lib.device_count()
+    if ndev <= 0:
+        raise SystemExit("bench.py needs an AMD GPU (libvaenar_hip has no CPU fallback)")
+    device = local_rank % ndev
+    weights = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    model = VAENAR(hps, device=device, weights=weights)
+    eng = model.engine
+
+    B, Tt, Tm, rf = S1["B"], S1["T_text"], S1["T_mel"], S1["rf"]
+    batch = make_batch(B, Tt, Tm, ragged=False, seed=1234 + rank, temperature=1.0)
+    Tz = (Tm + rf - 1) // rf
+    # inputs resident in HBM before the timed region
+    d_ids = eng.to_device(batch["ids"], np.int32)
+    d_tl = eng.to_device(batch["text_lengths"], np.int32)
+    d_ml = batch["mel_lengths"]                      # host: only its max decides the launch shapes
+    d_eps = eng.to_device(batch["eps"], np.float32)
+
+    def step():
+        return model.inference(d_ids, d_ml, d_tl, reduction_factor=rf, eps=d_eps, return_alignments=True)
+
+    for _ in range(args.warmup):
+        mel, ali = step()
+    eng.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mel, ali = step()
+    eng.synchronize()
+    barrier()
+    dt = vdist.max_over_ranks(time.perf_counter() - t0)
+
+    ms_per_step = 1e3 * dt / args.steps
+    frames_per_step = B * Tm * world
+    value = frames_per_step / (dt / args.steps)
+
+    out = {
+        "metric": "mel-frames/sec", "value": value, "unit": "mel-frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "S1 VAENAR.inference: B=16 per GPU, T_text=128, T_mel=800, 80-bin, rf=2, "
+                               "LJHPS architecture, random-init weights, prior noise temperature 1.0, "
+                               "decoder alignments returned", "global_batch": B * world,
+                   "parallelism": "batch-sharded x%d (no collective)" % world},
+    }
+
+    if rank == 0:
+        # ---- per-kernel roofline: HIP events around every launch on the engine's stream -----------
+        eng.profile(True)
+        eng.profile_reset()
+        launches0 = eng.launch_count()
+        for _ in range(args.profile_steps):
+            step()
+        eng.synchronize()
+        launches = (eng.launch_count() - launches0) // max(1, args.profile_steps)
+        prof = {c: eng.profile_get(c) for c in ("gemm", "attn_self", "attn_cross", "attn_cross_ali",
+                                                "layer_norm", "misc")}
+        eng.profile(False)
+        eng.profile_reset()
+        g = prof["gemm"]
+        gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "gemm_kernel / gemm_ln_kernel (fp32 MFMA 32x32x2)", "bound": "mfma",
+            "achieved": gemm_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": gemm_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": g["launches"] // max(1, args.profile_steps),
+            "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
+            "flops_per_step": g["flops"] / max(1, args.profile_steps),
+        }
+        a = prof["attn_cross_ali"]
+        if a["launches"]:
+            gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            out["roofline_cross_attention"] = {
+                "kernel": "attn_kernel<128,true> (decoder cross-attention core, alignments stored)",
+                "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
+                "avg_launch_us": 1e3 * a["ms"] / a["launches"],
+            }
+        out["end_to_end"] = {
+            "algorithmic_gflop_per_step": ALG_GFLOP_S1,
+            "achieved_tflops": ALG_GFLOP_S1 * 1e9 / (ms_per_step * 1e-3) / 1e12,
+            "frac_of_fp32_mfma_peak": ALG_GFLOP_S1 * 1e9 / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "kernel_launches_per_step": launches,
+            "kernel_ms_per_step": {c: p["ms"] / max(1, args.profile_steps) for c, p in prof.items()},
+        }
+        out["device"] = eng.device_info()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the NumPy oracle (fp32) on the same S1 batch, host cores of this box ----
+        from oracle.vaenar_numpy import Oracle
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count() or 1
+        orc = Oracle(hps, weights, np.float32)
+        ref = None
+        t_cpu = []
+        for _ in range(args.cpu_iters):
+            t1 = time.perf_counter()
+            ref, _ = orc.inference(batch["ids"], batch["mel_lengths"], batch["text_lengths"], rf, batch["eps"])
+            t_cpu.append(time.perf_counter() - t1)
+        best = min(t_cpu)
+        out["cpu_baseline"] = {
+            "value": B * Tm / best, "unit": "mel-frames/s", "cores": int(threads), "kind": "port",
+            "sample": "the full S1 batch (16 x 800 frames), best of %d runs of oracle/vaenar_numpy.py in fp32 "
+                      "(NumPy/OpenBLAS); the reference's TF2-CPU path cannot run here (no TensorFlow)"
+                      % args.cpu_iters,
+            "seconds_per_batch": best, "host_cpus": os.cpu_count(),
+        }
+        got = mel.numpy()
+        out["parity"] = {"max_abs_mel_err": float(np.abs(got - ref).max()),
+                         "against": "oracle fp32 on the same batch", "tolerance": 1e-3}
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

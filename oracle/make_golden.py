@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ (test infrastructure).
+
+    python oracle/make_golden.py            # oracle fixtures (float64 oracle, stored as float32)
+
+Each fixture holds inputs and expected outputs of VAENAR.inference and of inference.py's test_step
+on a small ragged batch; weights are NOT stored -- they are regenerated from (config, seed, mode) by
+vaenar_tts_amd.weights.init_weights and pinned by a digest.  The reference itself cannot produce
+vectors (it imports TensorFlow 2.2, absent here): PARITY UNPINNED, see oracle/vaenar_numpy.py.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.vaenar_numpy import Oracle  # noqa: E402
+from vaenar_tts_amd.configs import LJHPS, tiny_hps  # noqa: E402
+from vaenar_tts_amd.synthetic import make_batch  # noqa: E402
+from vaenar_tts_amd.weights import init_weights  # noqa: E402
+
+CASES = {
+    # name: (hps factory, batch kwargs)
+    "tiny_ragged": (tiny_hps, dict(B=3, T_text=11, T_mel=40, ragged=True, temperature=1.0, text_step=3, mel_step=7)),
+    "lj_ragged": (lambda: LJHPS, dict(B=4, T_text=37, T_mel=150, ragged=True, temperature=1.0, text_step=5, mel_step=23)),
+    "lj_t0": (lambda: LJHPS, dict(B=2, T_text=21, T_mel=64, ragged=True, temperature=0.0, text_step=6, mel_step=14)),
+}
+SEED = 1234
+
+
+def weights_digest(w):
+    h = hashlib.sha256()
+    for k in w:
+        h.update(k.encode()); h.update(np.ascontiguousarray(w[k]).tobytes())
+    return h.hexdigest()
+
+
+def build(name):
+    mk, kw = CASES[name]
+    hps = mk()
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    o = Oracle(hps, w, np.float64)
+    b = make_batch(vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, seed=SEED, **kw)
+    mel, ali = o.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+    out = dict(ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], eps=b["eps"],
+               text_embd=o.last["text_embd"], z=o.last["z"], prior_logprobs=o.last["prior_logprobs"],
+               initial=o.last["initial"], mel=mel)
+    for k, v in ali.items():
+        out["ali_" + k] = v
+    tmel, tlen, _ = o.test_step(b["ids"], b["text_lengths"])
+    out.update(ts_pred_float=o.last["pred_float"], ts_lengths=tlen, ts_mel=tmel)
+    out = {k: (v.astype(np.float32) if v.dtype == np.float64 and k != "ts_pred_float" else v) for k, v in out.items()}
+    out["weights_sha256"] = np.frombuffer(weights_digest(w).encode(), dtype=np.uint8)
+    return out
+
+
+def main():
+    d = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(d, exist_ok=True)
+    for name in CASES:
+        np.savez_compressed(os.path.join(d, name + ".npz"), **build(name))
+        print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -596,7 +596,7 @@ int vnr_device_info(vnr_handle h, char* name, int name_len, int* compute_units, 
   if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
   hipDeviceProp_t p;
   HIP_TRY(h, hipGetDeviceProperties(&p, h->device));
-  if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+  if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName); }
   if (compute_units) *compute_units = p.multiProcessorCount;
   if (wavefront) *wavefront = p.warpSize;
   return VNR_OK;

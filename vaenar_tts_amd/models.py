@@ -48,6 +48,7 @@ class VAENAR:
             n_blk=p.n_blk, channels=hps.Common.latent_dim, n_transformer_blk=p.n_transformer_blk,
             attention_dim=p.attention_dim, attention_heads=p.attention_heads,
             temperature=p.temperature, ffn_hidden=p.ffn_hidden, inverse=p.inverse, engine=eng)
+        self._len_cache = {}
         if weights is not None:
             self.load_weights(weights)
 
@@ -85,7 +86,14 @@ class VAENAR:
         B, Tt = ids.shape
         Tz = int(reduced.max())
         tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
-        rl = eng.to_device(reduced, np.int32)
+        # the reduced lengths live on the device; identical length vectors reuse the resident copy so a
+        # steady-state call issues no host->device copy (and therefore no stream synchronisation)
+        key = (reduced.tobytes(), rf)
+        rl = self._len_cache.get(key)
+        if rl is None:
+            if len(self._len_cache) > 64:
+                self._len_cache.clear()
+            rl = self._len_cache[key] = eng.to_device(reduced, np.int32)
         C = self.hps.Common.latent_dim
         if eps is None and float(temperature) != 0.0:
             eps = (np.float32(temperature) * self.prior.rng.standard_normal((B, Tz, C))).astype(np.float32)

@@ -38,6 +38,7 @@ struct GemmArgs {
   const int32_t* gather_ids = nullptr;
   // fused LayerNorm epilogue (row-panel kernel, requires N <= 256; wider rows use launch_layer_norm)
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
+  unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]
 };
 
 struct AttnArgs {
@@ -56,6 +57,8 @@ struct AttnArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
+bool gemm2_supported(const GemmArgs& g);          // LDS-DMA ring kernel (gemm2.hip) can take it
+hipError_t launch_gemm2(const GemmArgs& g, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);

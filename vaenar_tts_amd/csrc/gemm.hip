@@ -10,6 +10,7 @@
 // are read from LDS as k-contiguous 16-byte vectors.  K is consumed in a permuted order
 // (lane-half h owns k = 8c+4h+s) which is legal because both operands use the same permutation.
 #include "common.h"
+#include <stdlib.h>
 
 namespace vnr {
 
@@ -399,6 +400,9 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if ((g.K & 3) || (g.K1 & 3) || (g.lda1 & 3) || (g.A2 && (g.lda2 & 3)) || (g.ldw & 3))
     return hipErrorInvalidValue;
   if (g.taps > 0 && ((g.conv_C & 3) || g.K != g.taps * g.conv_C)) return hipErrorInvalidValue;
+
+  static const bool force_v1 = getenv("VNR_GEMM_V1") != nullptr;   // A/B switch for measurements
+  if (!force_v1 && gemm2_supported(g)) return launch_gemm2(g, s);
 
   if (g.ln_gamma) {
     if (g.taps > 0 || g.gather_ids || g.bn_scale || g.pe || g.N > 256) return hipErrorInvalidValue;

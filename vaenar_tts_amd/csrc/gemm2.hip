@@ -1,0 +1,516 @@
+// fp32-MFMA GEMM, second generation: LDS-DMA (buffer_load ... lds) multi-stage ring.
+//
+// Same contract as gemm.hip (GemmArgs: Dense / concat-Dense / Conv1D implicit GEMM + fused epilogues,
+// optional fused LayerNorm for row panels) but the global->LDS traffic never passes through VGPRs and is
+// issued NSTAGE-1 k-tiles ahead with counted s_waitcnt vmcnt(N) and a raw s_barrier, so a single wave per
+// SIMD keeps the matrix pipe busy (the S1 GEMMs are mid-sized: 200..1800 workgroups, i.e. about one
+// workgroup per CU, where the register-staged kernel exposes the L2 latency of every k-tile).
+//
+// LDS image: k-tile rows of 32 floats (128 B) UNPADDED -- one DMA wave-instruction writes 8 rows x 128 B
+// lane-linearly -- with a 16-byte-chunk XOR swizzle applied on the SOURCE side (lane l fetches logical
+// chunk (l&7) ^ ((row>>1)&7) of its row) and the same XOR on the ds_read_b128 side: every 16-lane read
+// group then touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+// Out-of-range rows / k / conv taps are mapped to a byte offset beyond the buffer descriptor's
+// num_records, for which the hardware returns zeros.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace vnr {
+
+namespace {
+
+constexpr unsigned kOobOffset = 0x80000000u;   // beyond any descriptor we build (< 2 GiB)
+
+__device__ __forceinline__ float act2(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+}  // namespace
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN>
+__global__ void __launch_bounds__(WM* WN * 64)
+gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int AQ = BM / 8 / NW, BQ = BN / 8 / NW, LPW = AQ + BQ;   // DMA instructions per wave per stage
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "stage rows must split evenly over the waves");
+  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // XCD-aware tile order (speed only), bijective
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 8 : nullptr;
+  auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+  if (ts && tid == 0) { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ts[6] = hwid; ts[7] = xcc; }
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // ---- buffer descriptors (wave-uniform: built from kernel arguments only) ---------------------------
+  // ONE descriptor covers both A panels (base = the lower of the two pointers; the launcher checks that
+  // the span fits the 2 GiB offset range), so the panel switch is an offset, not a different SRD.
+  const size_t a1_span = ((size_t)(g.M - 1) * g.lda1 + (MODE == 1 ? g.conv_C : g.K1)) * 4;
+  const size_t a2_span = g.A2 ? ((size_t)(g.M - 1) * g.lda2 + (g.K - g.K1)) * 4 : 0;
+  const char* abase = (g.A2 && (const char*)g.A2 < (const char*)g.A1) ? (const char*)g.A2 : (const char*)g.A1;
+  const unsigned delta1 = (unsigned)((const char*)g.A1 - abase);
+  const unsigned delta2 = g.A2 ? (unsigned)((const char*)g.A2 - abase) : 0u;
+  const size_t a_end = (delta1 + a1_span > delta2 + a2_span) ? delta1 + a1_span : delta2 + a2_span;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, (unsigned)a_end, 0x00020000);
+  const unsigned b_bytes = (unsigned)(((size_t)(g.N - 1) * g.ldw + g.K) * 4);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.Wt, 0, b_bytes, 0x00020000);
+
+  // ---- per-lane DMA source descriptions ------------------------------------------------------------------
+  // instruction x of this wave covers stage rows 8*(wave + NW*x) .. +7; lane -> row (lane>>3), chunk (lane&7)
+  unsigned a_off1[AQ], a_off2[AQ];   // plain: byte offset of (row, logical chunk) at k0 = 0, or OOB
+  int a_c4[AQ];                      // 4 * logical chunk (k offset inside the tile)
+  int cv_t[AQ], cv_row[AQ], cv_cc[AQ], cv_j[AQ];   // conv: time index, b*T, channel offset, tap
+  bool a_ok[AQ];
+#pragma unroll
+  for (int x = 0; x < AQ; ++x) {
+    const int r = 8 * (wave + NW * x) + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    a_ok[x] = m < g.M;
+    a_c4[x] = 4 * c;
+    if (MODE == 0) {
+      a_off1[x] = a_ok[x] ? delta1 + (unsigned)(((size_t)m * g.lda1 + 4 * c) * 4) : kOobOffset;
+      a_off2[x] = (a_ok[x] && g.A2) ? delta2 + (unsigned)(((size_t)m * g.lda2 + 4 * c) * 4) : kOobOffset;
+    } else {
+      const int mm = a_ok[x] ? m : 0;
+      const int b = mm / g.conv_T;
+      cv_t[x] = mm - b * g.conv_T;
+      cv_row[x] = b * g.conv_T;
+      int cc = 4 * c, j = 0;
+      while (cc >= g.conv_C) { cc -= g.conv_C; ++j; }
+      cv_cc[x] = cc; cv_j[x] = j;
+      a_off1[x] = 0; a_off2[x] = 0;
+    }
+  }
+  unsigned b_off[BQ];
+  int b_c4[BQ];
+#pragma unroll
+  for (int x = 0; x < BQ; ++x) {
+    const int r = 8 * (wave + NW * x) + (lane >> 3);     // row inside the B tile
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int n = n0 + r;
+    b_c4[x] = 4 * c;
+    b_off[x] = (n < g.N) ? (unsigned)(((size_t)n * g.ldw + 4 * c) * 4) : kOobOffset;
+  }
+
+  // DMA instruction d (0 <= d < LPW) of k-tile `kt` into ring slot `slot`; d < AQ are A rows, the rest B rows.
+  // Tiles are issued strictly in order (the conv tap walker is incremental).  Splitting the tile's DMA into
+  // single instructions lets the main loop drop one into each MFMA issue gap.
+  auto issue_one = [&](int kt, int slot, int d) {
+    const int k0 = kt * 32;
+    char* sbase = smem + slot * STAGE_BYTES;
+    if (d < AQ) {
+      const int x = d;
+      lds_ptr_t dst = (lds_ptr_t)(sbase + (wave + NW * x) * 1024);
+      if (MODE == 0) {
+        const bool second = k0 >= g.K1;                  // tile-uniform: K1 % 32 == 0 (checked by the launcher)
+        const int lim = second ? g.K : g.K1;
+        const int soff = (second ? (k0 - g.K1) : k0) * 4;
+        unsigned off = second ? a_off2[x] : a_off1[x];
+        if (k0 + a_c4[x] >= lim) off = kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, soff, 0, 0);
+      } else {
+        const int tt = cv_t[x] + cv_j[x] - (g.taps >> 1);
+        const bool ok = a_ok[x] && cv_j[x] < g.taps && tt >= 0 && tt < g.conv_T;
+        const unsigned off = ok ? (unsigned)(((size_t)(cv_row[x] + tt) * g.lda1 + cv_cc[x]) * 4) : kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, 0, 0, 0);
+        cv_cc[x] += 32;                                  // advance to the next k-tile
+        while (cv_cc[x] >= g.conv_C) { cv_cc[x] -= g.conv_C; ++cv_j[x]; }
+      }
+    } else {
+      const int x = d - AQ;
+      unsigned off = b_off[x];
+      if (k0 + b_c4[x] >= g.K) off = kOobOffset;
+      lds_ptr_t dst = (lds_ptr_t)(sbase + BM * 128 + (wave + NW * x) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, off, k0 * 4, 0, 0);
+    }
+  };
+  auto issue = [&](int kt, int slot) {
+#pragma unroll
+    for (int d = 0; d < LPW; ++d) issue_one(kt, slot, d);
+  };
+
+  // ---- LDS read offsets (bytes): row l31 of a 32-row block, logical chunk 2*c8 + half -----------------------
+  const int swz = (l31 >> 1) & 7;
+  int rd_off[4];
+#pragma unroll
+  for (int c8 = 0; c8 < 4; ++c8) rd_off[c8] = l31 * 128 + (((2 * c8 + half) ^ swz) << 4);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- epilogue parameters are fetched NOW so that their latency hides under the main loop ------------------
+  const bool vec_ok = !(g.N & 3) && !(g.ldc & 3) && (!g.residual || !(g.ldr & 3));
+  float4 p_bias[NI][4], p_sc[NI][4], p_sh[NI][4];     // per-lane column groups: col = .. + j*32 + 8q + 4*half
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = (LN ? 0 : n0) + wn * TN + j * 32 + 8 * q + 4 * half;
+      p_bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      p_sc[j][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+      p_sh[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && col < g.N) {
+        if (g.bias) p_bias[j][q] = *reinterpret_cast<const float4*>(g.bias + col);
+        if (LN) {
+          p_sc[j][q] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
+          p_sh[j][q] = *reinterpret_cast<const float4*>(g.ln_beta + col);
+        } else if (g.bn_scale) {
+          p_sc[j][q] = *reinterpret_cast<const float4*>(g.bn_scale + col);
+          p_sh[j][q] = *reinterpret_cast<const float4*>(g.bn_shift + col);
+        }
+      }
+    }
+
+  // Software pipeline over k-tiles (32 k each = four 8-k groups G0..G3):
+  //   * the DMA of tile kt+NSTAGE-1 is issued in EVERY iteration, one instruction per MFMA issue gap of G0
+  //     (tiles past the end resolve to out-of-range offsets = zero fill into a free slot), so the body is
+  //     branch-free and the wait is a constant;
+  //   * MFMA operand fragments are double-buffered one group ahead;
+  //   * the "tile kt+1 has landed" wait + barrier sits between G2 and G3 of tile kt, so the first two
+  //     fragment groups of tile kt+1 are fetched under G3 and the next iteration starts on the matrix pipe.
+  // Slot reuse: tile kt+NSTAGE-1 overwrites the slot of tile kt-1, whose LDS reads every wave completed
+  // (lgkmcnt(0)) before it passed the barrier of iteration kt-1.
+  const int nk = (g.K + 31) >> 5;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  f32x4 fa[2][MI], fb[2][NI];
+  auto frag = [&](const char* As, const char* Bs, int c8, int set) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + i * 4096 + rd_off[c8]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + rd_off[c8]);
+  };
+  auto mfma_group = [&](int set, int kt_dma, int ns, bool with_dma) {
+    int d = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][s], fa[set][i][s], acc[i][j], 0, 0, 0);   // D^T: lane <-> row m
+          if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
+        }
+    if (with_dma)
+#pragma unroll
+      for (; d < LPW; ++d) issue_one(kt_dma, ns, d);       // more DMA instructions than MFMAs in one group
+  };
+  stamp(1);
+  wait_vmcnt<(NSTAGE - 2) * LPW>();                   // tile 0 landed
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    const char* As = smem + wm * TM * 128;
+    const char* Bs = smem + BM * 128 + wn * TN * 128;
+    frag(As, Bs, 0, 0);
+    frag(As, Bs, 1, 1);
+  }
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
+    const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
+    int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;   // slot of tile kt-1 == slot of tile kt+NSTAGE-1
+    int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;             // slot of tile kt+1
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, kt + NSTAGE - 1, ns, true);          // G0 + DMA of tile kt+NSTAGE-1
+    frag(As, Bs, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1, 0, 0, false);                        // G1
+    frag(As, Bs, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, 0, 0, false);                        // G2
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");   // tile kt+1 landed; my reads of tile kt done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const char* An = smem + nx * STAGE_BYTES + wm * TM * 128;
+      const char* Bn = smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128;
+      frag(An, Bn, 0, 0);                              // first group of tile kt+1 (set 0 is free after G2)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(1, 0, 0, false);                      // G3
+      frag(An, Bn, 1, 1);
+    }
+    slot = nx;
+  }
+  wait_vmcnt<0>();                                    // drain the dummy tail tiles before LDS is reused / exit
+
+  // Result layout (operands swapped, D^T): lane (l31, half) owns output ROW m = .. + l31 and, per 32x32 block,
+  // the 4-column groups n = .. + 8*q + 4*half + {0,1,2,3}, q = 0..3 (register 4q + e): 16-byte stores, and a
+  // row's LayerNorm statistics are an in-lane sum plus one cross-half shuffle.
+  stamp(3);
+  if (!LN) {
+    if (vec_ok) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * TM + i * 32 + l31;
+        const bool rok = row < g.M;
+        const float* perow = g.pe ? g.pe + (size_t)(row % g.pe_T) * g.N : nullptr;
+        float4 res[NI][4], pev[NI][4];
+        // batch every dependent load of this row block first ...
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = n0 + wn * TN + j * 32 + 8 * q + 4 * half;
+            res[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pev[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rok && col < g.N) {
+              if (g.residual) res[j][q] = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+              if (perow) pev[j][q] = *reinterpret_cast<const float4*>(perow + col);
+            }
+          }
+        // ... then compute and store
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = n0 + wn * TN + j * 32 + 8 * q + 4 * half;
+            if (!rok || col >= g.N) continue;
+            const float4 bi = p_bias[j][q], sc = p_sc[j][q], sh = p_sh[j][q];
+            float v[4] = {acc[i][j][4 * q] + bi.x, acc[i][j][4 * q + 1] + bi.y, acc[i][j][4 * q + 2] + bi.z, acc[i][j][4 * q + 3] + bi.w};
+            if (g.bn_scale && g.bn_first) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act2(v[e], g.act);
+            if (g.bn_scale && !g.bn_first) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
+            const float4 pe4 = pev[j][q], r4 = res[j][q];
+            v[0] += g.pe_w * pe4.x + r4.x; v[1] += g.pe_w * pe4.y + r4.y; v[2] += g.pe_w * pe4.z + r4.z; v[3] += g.pe_w * pe4.w + r4.w;
+            *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+    } else {   // generic (unaligned N / strides): scalar path
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * TM + i * 32 + l31;
+        if (row >= g.M) continue;
+        const float* perow = g.pe ? g.pe + (size_t)(row % g.pe_T) * g.N : nullptr;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = n0 + wn * TN + j * 32 + 8 * q + 4 * half + e;
+              if (c >= g.N) continue;
+              float t = acc[i][j][4 * q + e] + (g.bias ? g.bias[c] : 0.f);
+              if (g.bn_scale && g.bn_first) t = t * g.bn_scale[c] + g.bn_shift[c];
+              t = act2(t, g.act);
+              if (g.bn_scale && !g.bn_first) t = t * g.bn_scale[c] + g.bn_shift[c];
+              if (perow) t += g.pe_w * perow[c];
+              if (g.residual) t += g.residual[(size_t)row * g.ldr + c];
+              g.C[(size_t)row * g.ldc + c] = t;
+            }
+      }
+    }
+  } else {
+    // ---- row-panel epilogue: v = act(acc + bias) + residual ; LayerNorm over the full row (BN >= N) ----------
+    static_assert(!LN || (WM == 1 && MI == 1), "LayerNorm epilogue: one 32-row panel per workgroup");
+    __syncthreads();                                  // all waves are done with the ring -> reuse it
+    float* red = reinterpret_cast<float*>(smem);      // [2][32][NW]
+    const int row = m0 + l31;
+    const bool rok = row < g.M;
+    float v[NI][16];
+    float s1 = 0.f;
+    if (vec_ok) {
+      float4 res[NI][4];
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn * TN + j * 32 + 8 * q + 4 * half;
+          res[j][q] = (rok && g.residual && col < g.N) ? *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn * TN + j * 32 + 8 * q + 4 * half;
+          const bool ok = rok && col < g.N;
+          const float4 bi = p_bias[j][q], r4 = res[j][q];
+          v[j][4 * q + 0] = ok ? act2(acc[0][j][4 * q + 0] + bi.x, g.act) + r4.x : 0.f;
+          v[j][4 * q + 1] = ok ? act2(acc[0][j][4 * q + 1] + bi.y, g.act) + r4.y : 0.f;
+          v[j][4 * q + 2] = ok ? act2(acc[0][j][4 * q + 2] + bi.z, g.act) + r4.z : 0.f;
+          v[j][4 * q + 3] = ok ? act2(acc[0][j][4 * q + 3] + bi.w, g.act) + r4.w : 0.f;
+          s1 += (v[j][4 * q] + v[j][4 * q + 1]) + (v[j][4 * q + 2] + v[j][4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = wn * TN + j * 32 + 8 * q + 4 * half + e;
+            float t = 0.f;
+            if (rok && col < g.N) {
+              t = act2(acc[0][j][4 * q + e] + (g.bias ? g.bias[col] : 0.f), g.act);
+              if (g.residual) t += g.residual[(size_t)row * g.ldr + col];
+            }
+            v[j][4 * q + e] = t;
+            s1 += t;
+          }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    if (half == 0) red[l31 * NW + wave] = s1;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mean += red[l31 * NW + w];
+    mean *= 1.f / (float)g.N;
+    float s2 = 0.f;                                   // centred (population) variance, as tf.nn.moments
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int col = wn * TN + j * 32 + 8 * q + 4 * half + e;
+          const float d = (col < g.N) ? v[j][4 * q + e] - mean : 0.f;
+          s2 += d * d;
+        }
+    s2 += __shfl_xor(s2, 32, 64);
+    if (half == 0) red[32 * NW + l31 * NW + wave] = s2;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) var += red[32 * NW + l31 * NW + w];
+    const float rstd = 1.0f / sqrtf(var * (1.f / (float)g.N) + kLnEps);
+    if (rok) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn * TN + j * 32 + 8 * q + 4 * half;
+          if (col >= g.N) continue;
+          if (vec_ok) {
+            const float4 ga = p_sc[j][q], be = p_sh[j][q];
+            *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) =
+                make_float4((v[j][4 * q + 0] - mean) * rstd * ga.x + be.x, (v[j][4 * q + 1] - mean) * rstd * ga.y + be.y,
+                            (v[j][4 * q + 2] - mean) * rstd * ga.z + be.z, (v[j][4 * q + 3] - mean) * rstd * ga.w + be.w);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N)
+                g.C[(size_t)row * g.ldc + col + e] = (v[j][4 * q + e] - mean) * rstd * g.ln_gamma[col + e] + g.ln_beta[col + e];
+          }
+        }
+    }
+  }
+  stamp(4);                                           // stores issued
+  if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(5); }   // stores complete
+}
+
+// ------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN>
+static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = LN ? 1 : (g.N + BN - 1) / BN;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+  const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  static const char* ts_path = getenv("VNR_GEMM_TS");
+  if (ts_path) {   // measurement only: synchronous launch + dump of the per-workgroup stamps
+    GemmArgs gg = g;
+    const size_t n = (size_t)grid.x * 8;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemset(d, 0, n * 8);
+    gg.dbg_ts = d;
+    const int mode = g.taps > 0 ? 1 : 0;
+    if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
+    else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN>;
+      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FILE* f = fopen(ts_path, "ab");
+    if (f) { int hdr[8] = {g.M, g.N, g.K, BM, BN, NSTAGE, (int)grid.x, LN ? 1 : 0}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); }
+    return hipGetLastError();
+  }
+  if (g.taps > 0) {
+    if (LN) return hipErrorInvalidValue;
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+  } else {
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+  }
+  return hipGetLastError();
+}
+
+// true when the DMA kernel can take this problem (otherwise gemm.hip's register-staged kernel runs)
+bool gemm2_supported(const GemmArgs& g) {
+  if (g.gather_ids) return false;
+  if (g.A2 && (g.K1 & 31)) return false;                                   // panel switch must be tile-uniform
+  const size_t lim = (size_t)1 << 31;
+  if (((size_t)g.M * g.lda1 + g.K) * 4 >= lim) return false;
+  if (g.A2) {
+    const char* lo = (const char*)g.A1 < (const char*)g.A2 ? (const char*)g.A1 : (const char*)g.A2;
+    const char* hi1 = (const char*)g.A1 + ((size_t)g.M * g.lda1 + g.K) * 4;
+    const char* hi2 = (const char*)g.A2 + ((size_t)g.M * g.lda2 + g.K) * 4;
+    if ((size_t)((hi1 > hi2 ? hi1 : hi2) - lo) >= lim) return false;     // both panels behind one descriptor
+  }
+  if (((size_t)g.N * g.ldw + g.K) * 4 >= lim) return false;
+  if (g.ln_gamma && (g.N > 256 || g.taps > 0 || g.bn_scale || g.pe)) return false;
+  return true;
+}
+
+hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
+  static const int force_tile = getenv("VNR_GEMM_TILE") ? atoi(getenv("VNR_GEMM_TILE")) : -1;
+  const GemmArgs& g = g_in;
+  if (g.ln_gamma) {
+    if (g.N <= 128) return launch2<32, 128, 1, 2, 4, true>(g, s);
+    return launch2<32, 256, 1, 4, 4, true>(g, s);
+  }
+  struct Cand { int bm, bn, blocks; };
+  const Cand cands[3] = {{128, 128, 4}, {64, 128, 2}, {64, 64, 1}};
+  int best = 0; long best_cost = -1;
+  for (int i = 0; i < 3; ++i) {
+    const long tiles = (long)((g.M + cands[i].bm - 1) / cands[i].bm) * ((g.N + cands[i].bn - 1) / cands[i].bn);
+    const long cost = ((tiles + 255) / 256) * cands[i].blocks;
+    if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
+  }
+  if (force_tile >= 0) best = force_tile;
+  switch (best) {
+    case 0: return launch2<128, 128, 2, 2, 3, false>(g, s);
+    case 1: return launch2<64, 128, 2, 2, 3, false>(g, s);
+    default: return launch2<64, 64, 2, 2, 4, false>(g, s);
+  }
+}
+
+}  // namespace vnr

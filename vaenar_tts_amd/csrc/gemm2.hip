@@ -493,9 +493,10 @@ bool gemm2_supported(const GemmArgs& g) {
 hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   static const int force_tile = getenv("VNR_GEMM_TILE") ? atoi(getenv("VNR_GEMM_TILE")) : -1;
   const GemmArgs& g = g_in;
+  static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
   if (g.ln_gamma) {
-    if (g.N <= 128) return launch2<32, 128, 1, 2, 4, true>(g, s);
-    return launch2<32, 256, 1, 4, 4, true>(g, s);
+    if (g.N <= 128) return st == 3 ? launch2<32, 128, 1, 2, 3, true>(g, s) : launch2<32, 128, 1, 2, 4, true>(g, s);
+    return st == 3 ? launch2<32, 256, 1, 4, 3, true>(g, s) : launch2<32, 256, 1, 4, 4, true>(g, s);
   }
   struct Cand { int bm, bn, blocks; };
   const Cand cands[3] = {{128, 128, 4}, {64, 128, 2}, {64, 64, 1}};
@@ -509,7 +510,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   switch (best) {
     case 0: return launch2<128, 128, 2, 2, 3, false>(g, s);
     case 1: return launch2<64, 128, 2, 2, 3, false>(g, s);
-    default: return launch2<64, 64, 2, 2, 4, false>(g, s);
+    default: return st == 4 ? launch2<64, 64, 2, 2, 4, false>(g, s) : launch2<64, 64, 2, 2, 3, false>(g, s);
   }
 }
 

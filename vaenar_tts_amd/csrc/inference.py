@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference harness /root/reference/inference.py (inference_test, :84-168) on the
+MI355X engine: same flags (:85-99), same call order in test_step (:128-143), one warm-up call then
+timing of test_step only (:145-155), RTF print (:165-168), mels written as
+``prior-{fid}-{step}.npy`` float32 [pred_len, 80] (audio/utils.py:16-22).
+
+Differences forced by the environment: no TensorFlow -> weights come from an ``.npz`` of the
+object-graph variable tree (``--ckpt_path``; ``synthetic`` = seeded random init) and batches come from
+an ``.npz`` with ``ids`` [N,T] / ``text_lengths`` [N] (``--data_dir``; ``synthetic`` = seeded random
+utterances) instead of TFRecords.  With torchrun (WORLD_SIZE > 1) the utterances are sharded over
+the ranks -- one engine per GPU, no collective on the data path.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from vaenar_tts_amd import dist as vdist
+from vaenar_tts_amd.configs import DataBakerHPS, LJHPS
+from vaenar_tts_amd.models import VAENAR
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights
+
+
+def inference_test():
+    parser = argparse.ArgumentParser('Inference parameters parser')
+    parser.add_argument('--dataset', type=str, choices=['ljspeech', 'databaker'], default='ljspeech')
+    parser.add_argument('--data_dir', type=str, default='synthetic', help=".npz with ids/text_lengths, or 'synthetic'")
+    parser.add_argument('--ckpt_path', type=str, default='synthetic-0', help=".npz weight tree, or 'synthetic-<step>'")
+    parser.add_argument('--test_dir', type=str, default='gpurun_out/test_dir')
+    parser.add_argument('--batch_size', type=int, default=1)
+    parser.add_argument('--temperature', type=float, default=0.)
+    parser.add_argument('--write_mels', type=int, default=1)
+    parser.add_argument('--num_utterances', type=int, default=8, help='synthetic data only')
+    parser.add_argument('--seed', type=int, default=1234)
+    args = parser.parse_args()
+    rank, local_rank, world = vdist.init('gloo')
+    ckpt_step = args.ckpt_path.split('-')[-1]                                     # inference.py:102
+    os.makedirs(args.test_dir, exist_ok=True)
+    hparams = {'ljspeech': LJHPS, 'databaker': DataBakerHPS}[args.dataset]        # inference.py:107
+    rf = hparams.Common.final_reduction_factor
+
+    if args.data_dir == 'synthetic':
+        data = make_batch(args.num_utterances, 96, 2 * rf, vocab_size=hparams.Encoder.Transformer.vocab_size,
+                          ragged=True, seed=args.seed, text_step=5)
+    else:
+        with np.load(args.data_dir) as z:
+            data = {k: z[k] for k in z.files}
+    n_total = len(data['text_lengths'])
+    lo, hi = vdist.shard_bounds(n_total, rank, world)
+    fids = np.arange(lo, hi)
+
+    model = VAENAR(hparams, device=local_rank)                                    # inference.py:121
+    if args.ckpt_path.startswith('synthetic'):
+        model.load_weights(init_weights(hparams, seed=args.seed, mode='synthetic', include_posterior=False))
+    else:
+        model.load_weights(args.ckpt_path)                                        # replaces Checkpoint.restore :122-123
+    rng = np.random.Generator(np.random.PCG64(args.seed + rank))
+
+    def test_step(t, t_l):                                                        # inference.py:128-143
+        text_pos_step = np.float32(model.mel_text_len_ratio) / np.float32(rf)
+        text_embd = model.text_encoder(t, t_l, pos_step=text_pos_step, training=False)
+        predicted_lengths = model.length_predictor(text_embd, t_l, training=False)
+        predicted_m_l = predicted_lengths.numpy().astype(np.int32)               # tf.cast(float, int32) :135
+        reduced_pred_ml = (predicted_m_l + 80 + rf - 1) // rf                    # :136-137
+        eps = None
+        if args.temperature:
+            eps = (np.float32(args.temperature) * rng.standard_normal(
+                (len(t_l), int(reduced_pred_ml.max()), hparams.Common.latent_dim))).astype(np.float32)
+        prior_latents, _ = model.prior.sample(reduced_pred_ml, text_embd, t_l, training=False,
+                                              temperature=args.temperature, eps=eps, return_logprobs=False)
+        _, prior_dec_outs, prior_dec_alignments = model.decoder(
+            prior_latents, text_embd, reduced_pred_ml, t_l, training=False, reduction_factor=rf)
+        return prior_dec_outs, predicted_m_l + 80, prior_dec_alignments
+
+    def batches():
+        for s in range(lo, hi, args.batch_size):
+            e = min(hi, s + args.batch_size)
+            tl = data['text_lengths'][s:e].astype(np.int32)
+            yield np.arange(s, e), data['ids'][s:e, :int(tl.max())].astype(np.int32), tl
+
+    for _, texts, t_lengths in batches():                                         # warm-up, inference.py:145-147
+        test_step(texts, t_lengths)
+        break
+    time_consumed, durations = 0., 0.
+    for ids, texts, t_lengths in batches():
+        time_begin = time.time()
+        prior_outs, pred_m_lens, prior_ali = test_step(texts, t_lengths)
+        outs = prior_outs.numpy()                                                 # device -> host ends the step
+        time_end = time.time()
+        time_consumed += time_end - time_begin
+        durations += np.sum(pred_m_lens) * 256 / 22050                            # frame_shift / sample_rate :155
+        if args.write_mels:                                                       # audio/utils.py:16-22
+            for i, fid in enumerate(ids):
+                np.save(os.path.join(args.test_dir, 'prior-{}-{}.npy'.format(fid, ckpt_step)),
+                        outs[i, :pred_m_lens[i]].astype(np.float32))
+    time_consumed = vdist.max_over_ranks(time_consumed)
+    durations = float(np.sum(vdist.gather_to_rank0(np.array([durations])))) if world > 1 else durations
+    if rank == 0:
+        print('Total time consumed is {} Secs,total synthesis duration is {} Secs,Average RTF is {}.'.format(
+            time_consumed, durations, time_consumed / max(durations, 1e-9)))
+
+
+if __name__ == '__main__':
+    inference_test()

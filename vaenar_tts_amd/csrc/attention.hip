@@ -23,6 +23,7 @@
 //   * keys >= Tk do not exist (weight 0, never counted in the uniform case).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace vnr {
 
@@ -298,6 +299,8 @@ static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return hipErrorInvalidValue;
   if ((a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3)) return hipErrorInvalidValue;
+  static const bool force_v1 = getenv("VNR_ATTN_V1") != nullptr;   // A/B switch for measurements
+  if (!force_v1 && attention2_supported(a)) return launch_attention2(a, s);
   if (a.ali) return launch_attn_cfg<128, true>(a, s);
   if (a.causal) return launch_attn_cfg<64, false>(a, s);
   return launch_attn_cfg<128, false>(a, s);

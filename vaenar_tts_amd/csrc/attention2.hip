@@ -1,0 +1,317 @@
+// Fused attention core, second generation (gfx950, fp32 MFMA 32x32x2): balanced, DMA-fed.
+//
+// Same contract as attention.hip (reference modules/attention.py:221-246) -- this kernel is the fast path
+// for every call without alignments and for alignment calls with Tk <= 128 (the decoder cross-attention).
+//
+// Decomposition.  grid = (ceil(Tq/64), H, B); a workgroup = 4 waves = one 64-row query block.
+//   wave w : query tile  qt = w & 1  (rows Q0 + 32*qt .. +31)
+//            key half    kh = w >> 1 (keys 32*kh .. 32*kh+31 of EVERY 64-key tile)
+// so the two waves that share a query tile split each K/V tile between them: every wave of a workgroup has
+// the same MFMA count (tiles * 64), causal blocks differ only by their tile count and are dispatched
+// heaviest-first, and 2 workgroups fit a CU (2 waves per SIMD overlap softmax VALU work with MFMAs).
+// The partial softmax states (m, l, O) of a wave pair are merged through LDS at the end.
+//
+// K/V tiles (64 keys x 64 floats each) arrive by LDS-DMA (buffer_load ... lds) into a 2-slot ring; keys beyond
+// Tk resolve to out-of-range offsets and are zero-filled by the hardware.  K rows are stored with a 16-byte
+// chunk XOR swizzle (source side) so the S^T = K.Q^T operand reads (ds_read_b128 down a column of chunks) are
+// conflict-free; V rows are linear (the P.V operand read is 32 consecutive floats per half-wave).
+//
+// Operand mapping as in attention.hip: S^T puts one query per lane (softmax reductions in-lane + one
+// cross-half shuffle) and leaves P in A-operand position for O = P.V.
+#include "common.h"
+#include <math.h>
+
+namespace vnr {
+
+namespace {
+constexpr unsigned kOob = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ int frow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+}  // namespace
+
+template <bool ALI>
+__global__ void __launch_bounds__(256, 2)
+attn2_kernel(const AttnArgs a, int nqb) {
+  constexpr int KT = 64;
+  constexpr int SLOT = 2 * KT * 256;                 // K tile + V tile, bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [0, 2*SLOT): K/V ring.  The 16 KB K region of slot 0 doubles as the per-wave 32x32 transpose staging (ALI,
+  // after every wave finished its S^T blocks) and as the merge scratch (after the last tile); a 2 KB exchange
+  // area for row statistics follows the ring.  67.5 KB per workgroup -> two workgroups per CU.
+  float* scratch = reinterpret_cast<float*>(smem);
+  float* xarea = reinterpret_cast<float*>(smem + 2 * SLOT);
+
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int qb = a.causal ? (nqb - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // heaviest causal blocks first
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = wave & 1, kh = wave >> 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Q0 = qb * 64, q0 = Q0 + qt * 32;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq;
+  const int klen = a.k_len ? a.k_len[b] : a.Tk;
+  const int ntiles_all = (a.Tk + KT - 1) / KT;
+  int ntiles = ntiles_all;
+  {
+    int row_hi = Q0 + 64; if (row_hi > a.Tq) row_hi = a.Tq;
+    if (!(row_hi > qlen || klen <= 0)) {              // all query rows valid: masked keys have weight exactly 0
+      int kmax = klen;
+      if (a.causal && row_hi < kmax) kmax = row_hi;
+      ntiles = (kmax + KT - 1) / KT;
+    }
+  }
+  const bool wave_active = q0 < a.Tq;
+
+  // ---- descriptors & per-lane DMA offsets --------------------------------------------------------------------
+  const unsigned kv_span = (unsigned)((((size_t)(a.Tk - 1)) * a.ldk + (size_t)a.H * 64) * 4);
+  const unsigned vv_span = (unsigned)((((size_t)(a.Tk - 1)) * a.ldv + (size_t)a.H * 64) * 4);
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(a.K + (size_t)b * a.k_bs), 0, kv_span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)(a.V + (size_t)b * a.v_bs), 0, vv_span, 0x00020000);
+  // instruction x (0..3) of this wave covers tile rows 4*(wave + 4x) .. +3 ; lane -> row (lane>>4), chunk (lane&15)
+  unsigned k_off[4], v_off[4];
+  int t_row[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int r = 4 * (wave + 4 * x) + (lane >> 4);
+    const int pc = lane & 15;
+    t_row[x] = r;
+    k_off[x] = (unsigned)(((size_t)r * a.ldk + hd * 64 + 4 * (pc ^ (r & 15))) * 4);
+    v_off[x] = (unsigned)(((size_t)r * a.ldv + hd * 64 + 4 * pc) * 4);
+  }
+  auto issue_tile = [&](int kt, int slot) {
+    char* sb = smem + slot * SLOT;
+    const unsigned ks = (unsigned)((size_t)kt * KT * a.ldk * 4), vs = (unsigned)((size_t)kt * KT * a.ldv * 4);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const bool ok = kt * KT + t_row[x] < a.Tk;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(sb + (wave + 4 * x) * 1024), 16, ok ? k_off[x] + ks : kOob, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(sb + KT * 256 + (wave + 4 * x) * 1024), 16, ok ? v_off[x] + vs : kOob, 0, 0, 0);
+    }
+  };
+
+  // ---- Q fragment: lane (i,h) keeps Q[q0+i][8c+4h .. +3], c = 0..7 (issued first; in flight with the first tiles) --------
+  f32x4 qf[8];
+  {
+    const int iq = q0 + l31;
+    const bool qok = iq < a.Tq;
+    const float* qp = a.Q + (size_t)b * a.q_bs + (size_t)(qok ? iq : 0) * a.ldq + hd * 64 + half * 4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (qok) qf[c] = *reinterpret_cast<const f32x4*>(qp + c * 8);
+      else { qf[c][0] = 0.f; qf[c][1] = 0.f; qf[c][2] = 0.f; qf[c][3] = 0.f; }
+    }
+  }
+  if (ntiles > 0) issue_tile(0, 0);                   // after the Q loads: vmcnt(8) then covers Q and tile 0
+  if (ntiles > 1) issue_tile(1, 1);
+  const float tau = a.temperature;
+  const bool use_tau = tau != 1.0f;
+  const int iq = q0 + l31;
+  const bool qvalid = iq < qlen;
+  // K operand read offsets (bytes) inside a tile: row 32*kh + l31, logical chunk 2c + half
+  int k_rd[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) k_rd[c] = (32 * kh + l31) * 256 + (((2 * c + half) ^ (l31 & 15)) << 4);
+
+  // S^T block of this wave for tile kt: keys kt*64 + 32*kh + frow(r, half), query l31
+  auto qk_block = [&](const char* Ks, int kt, f32x16& st) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + k_rd[c]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[c][s], st, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt * KT + 32 * kh + frow(r, half);
+      float s = st[r] * 0.125f;                       // / sqrt(64), exact
+      if (use_tau) s = s / tau;
+      const bool ok = qvalid && (j < klen) && (!a.causal || j <= iq);
+      s = ok ? s : kMaskFill;                         // attention.py:240
+      if (j >= a.Tk) s = -INFINITY;                   // key does not exist
+      st[r] = s;
+    }
+  };
+  f32x16 O[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+  auto pv_block = [&](const char* Vs, const f32x16& p) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* vrow = reinterpret_cast<const float*>(Vs) + (32 * kh + frow(r, half)) * 64 + l31;
+      const float v0 = vrow[0], v1 = vrow[32];
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v0, O[0], 0, 0, 0);
+      O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v1, O[1], 0, 0, 0);
+    }
+  };
+
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (!ALI) {
+    // ---- online softmax over this wave's half of every tile ------------------------------------------------------
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int slot = kt & 1;
+      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, kt+1 may fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* Ks = smem + slot * SLOT;
+      const char* Vs = Ks + KT * 256;
+      if (wave_active) {
+        f32x16 st;
+        qk_block(Ks, kt, st);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        // finite floor: a wave whose key half holds no existing key yet (all -inf) must produce p = 0, not NaN
+        const float m_new = fmaxf(fmaxf(m_run, mt), -3.0e38f);
+        const float alpha = expf(m_run - m_new);      // 0 on the first tile
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float p = expf(st[r] - m_new); st[r] = p; ps += p; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        if (kt > 0 && __any(m_new != m_run)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, frow(r, half), 64);
+            O[0][r] *= ar;
+            O[1][r] *= ar;
+          }
+        }
+        m_run = m_new;
+        pv_block(Vs, st);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                   // everyone is done with this slot
+      asm volatile("" ::: "memory");
+      if (kt + 2 < ntiles) issue_tile(kt + 2, slot);
+    }
+  } else {
+    // ---- alignments requested (Tk <= 128: at most two tiles, logits stay in registers) ------------------------------
+    f32x16 st0, st1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st0[r] = -INFINITY; st1[r] = -INFINITY; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave_active) {
+      qk_block(smem, 0, st0);
+      if (ntiles > 1) qk_block(smem + SLOT, 1, st1);
+    }
+    // row maximum over ALL keys: this wave's part, then the partner's (kh ^ 1) through LDS
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, fmaxf(st0[r], st1[r]));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float* xch = xarea;                               // [2 rounds][4 waves][32]
+    if (half == 0) xch[wave * 32 + l31] = mt;
+    __syncthreads();
+    m_run = fmaxf(fmaxf(mt, xch[(wave ^ 2) * 32 + l31]), -3.0e38f);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st0[r] = expf(st0[r] - m_run); st1[r] = expf(st1[r] - m_run);
+      ps += st0[r] + st1[r];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    if (half == 0) xch[128 + wave * 32 + l31] = ps;
+    __syncthreads();
+    l_run = ps + xch[128 + (wave ^ 2) * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st0[r] = st0[r] / l_run; st1[r] = st1[r] / l_run; }   // softmax, attention.py:242
+    if (wave_active) {
+      // alignment rows: transpose each 32x32 block through LDS, store 128-byte row pieces with 16-byte lanes
+      float* Pw = scratch + wave * 1024;              // [32 queries][32 keys], XOR-swizzled columns
+      for (int t = 0; t < ntiles_all; ++t) {
+        const f32x16& p = t == 0 ? st0 : st1;
+        const bool have = t < ntiles;                 // skipped tiles: weight exactly 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pw[l31 * 32 + (frow(r, half) ^ l31)] = have ? p[r] : 0.f;
+        // lane -> row rr = 8*x + (lane>>3), key chunk kc = lane&7 (4 keys)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int rr = 8 * x + (lane >> 3), kc = lane & 7;
+          float v4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = Pw[rr * 32 + ((4 * kc + e) ^ rr)];
+          const int qrow = q0 + rr, key = t * KT + 32 * kh + 4 * kc;
+          if (qrow < a.Tq) {
+            float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
+            if (key + 3 < a.Tk && !(a.Tk & 3)) *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            else
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
+          }
+        }
+      }
+      pv_block(smem + KT * 256, st0);
+      if (ntiles > 1) pv_block(smem + SLOT + KT * 256, st1);
+    }
+    m_run = 0.f;                                       // partials already share one scale: merge = plain sum
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- merge the wave pair (same query tile, other key half): each wave finalises dv block nb = kh ---------------------
+  // give = the block the partner finalises; layout [wave][16 regs][64 lanes]
+  float* mg = scratch;                                 // 4 waves x 1024 floats
+  float* ml = xarea + 256;                             // m,l of every wave: [4][2][32]
+  {
+    const int give = 1 - kh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mg[wave * 1024 + r * 64 + lane] = O[give][r];
+    if (half == 0) { ml[wave * 64 + l31] = m_run; ml[wave * 64 + 32 + l31] = l_run; }
+  }
+  __syncthreads();
+  if (wave_active) {
+    const int pw = wave ^ 2;
+    const float m_o = ml[pw * 64 + l31], l_o = ml[pw * 64 + 32 + l31];
+    float sa = 1.f, sb = 1.f, linv = 1.f;
+    if (!ALI) {
+      const float m_f = fmaxf(m_run, m_o);
+      sa = expf(m_run - m_f);                          // -inf - finite -> 0 when this half saw no tile
+      sb = expf(m_o - m_f);
+      linv = 1.0f / (l_run * sa + l_o * sb);
+    }
+    const int nb = kh;
+    float* ob = a.ctx + (size_t)b * a.o_bs + hd * 64 + nb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int src = frow(r, half);                   // per-query factors live in lane = query index
+      const float fa = __shfl(sa * linv, src, 64), fb = __shfl(sb * linv, src, 64);
+      const float o = O[nb][r] * fa + mg[pw * 1024 + r * 64 + lane] * fb;
+      const int row = q0 + src;
+      if (row < a.Tq) ob[(size_t)row * a.ldo] = o;
+    }
+  }
+}
+
+bool attention2_supported(const AttnArgs& a) {
+  if (a.ali && a.Tk > 128) return false;
+  const size_t lim = (size_t)1 << 31;
+  if (((size_t)a.Tk * a.ldk + 256) * 4 >= lim || ((size_t)a.Tk * a.ldv + 256) * 4 >= lim) return false;
+  return true;
+}
+
+hipError_t launch_attention2(const AttnArgs& a, hipStream_t s) {
+  const int nqb = (a.Tq + 63) / 64;
+  const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
+  dim3 grid(nqb, a.H, a.B);
+  if (a.ali) {
+    auto k = attn2_kernel<true>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, nqb);
+  } else {
+    auto k = attn2_kernel<false>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, nqb);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace vnr

@@ -60,6 +60,8 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
 bool gemm2_supported(const GemmArgs& g);          // LDS-DMA ring kernel (gemm2.hip) can take it
 hipError_t launch_gemm2(const GemmArgs& g, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+bool attention2_supported(const AttnArgs& a);      // balanced DMA-fed kernel (attention2.hip) can take it
+hipError_t launch_attention2(const AttnArgs& a, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);
 hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s);

@@ -20,6 +20,9 @@
 // cross-half shuffle) and leaves P in A-operand position for O = P.V.
 #include "common.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
 
 namespace vnr {
 
@@ -27,6 +30,17 @@ namespace {
 constexpr unsigned kOob = 0x80000000u;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ int frow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// exp(x) for x <= 0 on the hardware exp2 unit (v_exp_f32, ~1 ulp): t = x*log2(e) is rounded, the rounding error
+// and the low part of log2(e) are folded back to first order: exp(x) = 2^t * (1 + ln2 * e).  Relative error
+// ~2e-7 for |x| < 100; exp(-inf) = 0, large negative arguments flush to 0 like expf.
+__device__ __forceinline__ float fast_exp(float x) {
+  const float L2E = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+  const float t = x * L2E;
+  float e = __builtin_fmaf(x, L2E, -t);
+  e = __builtin_fmaf(x, L2E_LO, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return (x < -87.0f) ? ((x < -104.0f) ? 0.0f : expf(x)) : __builtin_fmaf(r, e * LN2, r);
+}
 }  // namespace
 
 template <bool ALI>
@@ -47,19 +61,11 @@ attn2_kernel(const AttnArgs a, int nqb) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qt = wave & 1, kh = wave >> 1;
   const int half = lane >> 5, l31 = lane & 31;
+  unsigned long long* ts = a.dbg_ts ? a.dbg_ts + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
+  auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   const int Q0 = qb * 64, q0 = Q0 + qt * 32;
-  const int qlen = a.q_len ? a.q_len[b] : a.Tq;
-  const int klen = a.k_len ? a.k_len[b] : a.Tk;
   const int ntiles_all = (a.Tk + KT - 1) / KT;
-  int ntiles = ntiles_all;
-  {
-    int row_hi = Q0 + 64; if (row_hi > a.Tq) row_hi = a.Tq;
-    if (!(row_hi > qlen || klen <= 0)) {              // all query rows valid: masked keys have weight exactly 0
-      int kmax = klen;
-      if (a.causal && row_hi < kmax) kmax = row_hi;
-      ntiles = (kmax + KT - 1) / KT;
-    }
-  }
   const bool wave_active = q0 < a.Tq;
 
   // ---- descriptors & per-lane DMA offsets --------------------------------------------------------------------
@@ -89,6 +95,12 @@ attn2_kernel(const AttnArgs a, int nqb) {
     }
   };
 
+  // The first two tiles are requested before anything depends on the length arrays (their loads would
+  // otherwise sit on the critical path: kernarg -> lengths -> first DMA).  A tile that turns out to be
+  // skippable is still drained by the vmcnt(0) of the last loop iteration.
+  issue_tile(0, 0);
+  if (ntiles_all > 1) issue_tile(1, 1);
+
   // ---- Q fragment: lane (i,h) keeps Q[q0+i][8c+4h .. +3], c = 0..7 (issued first; in flight with the first tiles) --------
   f32x4 qf[8];
   {
@@ -101,8 +113,17 @@ attn2_kernel(const AttnArgs a, int nqb) {
       else { qf[c][0] = 0.f; qf[c][1] = 0.f; qf[c][2] = 0.f; qf[c][3] = 0.f; }
     }
   }
-  if (ntiles > 0) issue_tile(0, 0);                   // after the Q loads: vmcnt(8) then covers Q and tile 0
-  if (ntiles > 1) issue_tile(1, 1);
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq;
+  const int klen = a.k_len ? a.k_len[b] : a.Tk;
+  int ntiles = ntiles_all;
+  {
+    int row_hi = Q0 + 64; if (row_hi > a.Tq) row_hi = a.Tq;
+    if (!(row_hi > qlen || klen <= 0)) {              // all query rows valid: masked keys have weight exactly 0
+      int kmax = klen;
+      if (a.causal && row_hi < kmax) kmax = row_hi;
+      ntiles = (kmax + KT - 1) / KT;
+    }
+  }
   const float tau = a.temperature;
   const bool use_tau = tau != 1.0f;
   const int iq = q0 + l31;
@@ -149,12 +170,15 @@ attn2_kernel(const AttnArgs a, int nqb) {
   };
 
   float m_run = -INFINITY, l_run = 0.f;
+  stamp(1);
 
   if (!ALI) {
     // ---- online softmax over this wave's half of every tile ------------------------------------------------------
     for (int kt = 0; kt < ntiles; ++kt) {
       const int slot = kt & 1;
-      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, kt+1 may fly
+      // kt = 0: the two prologue tiles and the Q fragment are all older than anything else -> drain;
+      // later: tile kt landed, tile kt+1 (8 DMA instructions of this wave) may stay in flight
+      if (kt > 0 && kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -169,10 +193,10 @@ attn2_kernel(const AttnArgs a, int nqb) {
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         // finite floor: a wave whose key half holds no existing key yet (all -inf) must produce p = 0, not NaN
         const float m_new = fmaxf(fmaxf(m_run, mt), -3.0e38f);
-        const float alpha = expf(m_run - m_new);      // 0 on the first tile
+        const float alpha = fast_exp(m_run - m_new);  // 0 on the first tile
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float p = expf(st[r] - m_new); st[r] = p; ps += p; }
+        for (int r = 0; r < 16; ++r) { const float p = fast_exp(st[r] - m_new); st[r] = p; ps += p; }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         if (kt > 0 && __any(m_new != m_run)) {
@@ -215,7 +239,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      st0[r] = expf(st0[r] - m_run); st1[r] = expf(st1[r] - m_run);
+      st0[r] = fast_exp(st0[r] - m_run); st1[r] = fast_exp(st1[r] - m_run);
       ps += st0[r] + st1[r];
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -257,6 +281,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
     __syncthreads();
   }
 
+  stamp(2);
   // ---- merge the wave pair (same query tile, other key half): each wave finalises dv block nb = kh ---------------------
   // give = the block the partner finalises; layout [wave][16 regs][64 lanes]
   float* mg = scratch;                                 // 4 waves x 1024 floats
@@ -274,8 +299,8 @@ attn2_kernel(const AttnArgs a, int nqb) {
     float sa = 1.f, sb = 1.f, linv = 1.f;
     if (!ALI) {
       const float m_f = fmaxf(m_run, m_o);
-      sa = expf(m_run - m_f);                          // -inf - finite -> 0 when this half saw no tile
-      sb = expf(m_o - m_f);
+      sa = fast_exp(m_run - m_f);                      // floor - finite -> 0 when this half saw no key
+      sb = fast_exp(m_o - m_f);
       linv = 1.0f / (l_run * sa + l_o * sb);
     }
     const int nb = kh;
@@ -289,6 +314,8 @@ attn2_kernel(const AttnArgs a, int nqb) {
       if (row < a.Tq) ob[(size_t)row * a.ldo] = o;
     }
   }
+  stamp(3);
+  if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); if (tid == 0) { ts[5] = ntiles; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ts[7] = xcc; } }
 }
 
 bool attention2_supported(const AttnArgs& a) {
@@ -298,8 +325,16 @@ bool attention2_supported(const AttnArgs& a) {
   return true;
 }
 
-hipError_t launch_attention2(const AttnArgs& a, hipStream_t s) {
+hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
+  static const char* ts_path = getenv("VNR_ATTN_TS");
   const int nqb = (a.Tq + 63) / 64;
+  unsigned long long* dts = nullptr;
+  const size_t nts = (size_t)nqb * a.H * a.B * 8;
+  if (ts_path) { if (hipMalloc((void**)&dts, nts * 8) != hipSuccess) return hipErrorOutOfMemory; (void)hipMemset(dts, 0, nts * 8); a.dbg_ts = dts; }
+  struct Dump { const char* p; unsigned long long* d; size_t n; hipStream_t s; const AttnArgs* a; int nqb;
+    ~Dump() { if (!p) return; (void)hipStreamSynchronize(s); std::vector<unsigned long long> h(n); (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost); (void)hipFree(d);
+      FILE* f = fopen(p, "ab"); if (f) { int hdr[8] = {a->B, a->H, a->Tq, a->Tk, a->causal, a->ali ? 1 : 0, (int)(n / 8), nqb}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); } } } dump{ts_path, dts, nts, s, &a, nqb};
   const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
   dim3 grid(nqb, a.H, a.B);
   if (a.ali) {

@@ -54,6 +54,7 @@ struct AttnArgs {
   float temperature;
   // batch strides in floats (rows * ld by default); allow K/V shared panels
   long long q_bs, k_bs, v_bs, o_bs;
+  unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [wgs][8]
 };
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);

@@ -142,6 +142,25 @@ int vnr_inference(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_leng
                   float pos_step, const float *d_eps, float *d_mel, float *d_alignments,
                   float *d_text_embd_out);
 
+/* TransformerPrior.log_probability (modules/prior.py:119-152), training=False: runs the flow backwards
+ * (coupling._backward flow.py:241-257, linear._backward :137-150, actnorm._backward :177-187).
+ * d_z [B,Tz,latent] -> d_logprobs [B]. */
+int vnr_prior_log_probability(vnr_handle h, const float *d_z, const float *d_text_embd,
+                              const int32_t *d_z_lengths, const int32_t *d_text_lengths, int B, int Tz,
+                              int Tt, float *d_logprobs);
+/* VAENAR.call (models/models.py:105-197) forward with training=False, n_sample = 1, reduce_loss=False:
+ * encoder -> length predictor -> posterior -> reparameterize (d_eps [B,Tz,latent] or NULL = zeros) ->
+ * posterior log-prob -> decoder -> masked L2 of outputs and initial outputs -> prior.log_probability.
+ * Tz = ceil(Tm / rf); d_reduced_lengths = ceil(mel_lengths / rf).
+ * Outputs: d_outs [B,Tm,output_dim] (cropped, models.py:183); per-utterance d_l2, d_kl, d_length_l2 [B]
+ * (the reduce_loss=True scalars are their means, models.py:84,92,101); d_alignments as vnr_decoder_fwd or NULL;
+ * d_aux NULL or [3*B] = predicted lengths | posterior log-probs | prior log-probs. */
+int vnr_elbo_fwd(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
+                 const float *d_mel_targets, const int32_t *d_mel_lengths,
+                 const int32_t *d_reduced_lengths, int B, int Tt, int Tm, int reduction_factor,
+                 float pos_step, const float *d_eps, float *d_outs, float *d_l2, float *d_kl,
+                 float *d_length_l2, float *d_alignments, float *d_aux);
+
 /* ---- single operators (kernel-level parity tests and micro-benchmarks) ---------------------- */
 /* tf.keras.layers.Dense on [M,K] (+ optional second input panel = tf.concat on the last axis,
  * attention.py:410-412,440-449): C = epilogue(A1.W[0:K1] + A2.W[K1:K] + bias).

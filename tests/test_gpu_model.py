@@ -154,3 +154,49 @@ def test_posterior(setup):
     rmu, rlv = oracle.posterior(mels.astype(np.float64), mem.astype(np.float64), b["text_lengths"], reduced)
     np.testing.assert_allclose(mu.numpy(), rmu, atol=1e-4, rtol=0)
     np.testing.assert_allclose(logvar.numpy(), rlv, atol=1e-4, rtol=0)
+
+
+def test_prior_log_probability(setup):
+    """prior.log_probability (prior.py:119-152): flow backwards; also log p(sample(eps)) == sample's own log-prob."""
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    r = np.random.Generator(np.random.PCG64(11))
+    reduced = (b["mel_lengths"] + 1) // 2
+    Tz = int(reduced.max())
+    z = r.standard_normal((len(reduced), Tz, hps.Common.latent_dim)).astype(np.float32)
+    mem = r.standard_normal((len(reduced), b["ids"].shape[1], hps.Encoder.Transformer.pre_hidden)).astype(np.float32)
+    got = model.prior.log_probability(z, mem, reduced, b["text_lengths"]).numpy()
+    ref = oracle.prior_log_probability(z.astype(np.float64), mem.astype(np.float64), reduced, b["text_lengths"])
+    np.testing.assert_allclose(got, ref, rtol=3e-5, atol=2e-2)
+    zs, lp = model.prior.sample(reduced, mem, b["text_lengths"], eps=b["eps"])
+    lp2 = model.prior.log_probability(zs, mem, reduced, b["text_lengths"]).numpy()
+    np.testing.assert_allclose(lp2, lp.numpy(), rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.parametrize("rf", [2, 5])
+def test_elbo_forward(setup, rf):
+    """VAENAR.call forward (models.py:105-197, training=False = dev_step train.py:148-155)."""
+    name, hps, model, oracle = setup
+    b = _batch(hps, name)
+    r = np.random.Generator(np.random.PCG64(21))
+    B, Tm = len(b["mel_lengths"]), int(b["mel_lengths"].max())
+    Tz = (Tm + rf - 1) // rf
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, 1, Tz, hps.Common.latent_dim)).astype(np.float32)
+    outs, l2, kl, ll, ali = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf,
+                                  training=False, reduce_loss=False, eps=eps)
+    routs, rl2, rkl, rll, rali = oracle.call(b["ids"], mels, b["mel_lengths"], b["text_lengths"], rf, False, False,
+                                             eps.astype(np.float64))
+    np.testing.assert_allclose(outs.numpy(), routs, atol=MEL_TOL, rtol=0)
+    np.testing.assert_allclose(l2.numpy(), rl2, rtol=1e-4)
+    np.testing.assert_allclose(ll.numpy(), rll, rtol=1e-3, atol=1e-7)
+    aux = model.last_aux.numpy()
+    np.testing.assert_allclose(aux[1], oracle.last["post_lp"][:, 0], rtol=2e-5, atol=1e-2)
+    np.testing.assert_allclose(aux[2], oracle.last["prior_lp"], rtol=3e-5, atol=3e-2)
+    np.testing.assert_allclose(kl.numpy(), rkl, rtol=1e-3, atol=6e-2)      # difference of two O(1e3..1e4) log-probs
+    for k in rali:
+        np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+    # reduce_loss=True: batch means (models.py:84,92,101)
+    _, l2m, klm, llm, _ = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf,
+                                training=False, reduce_loss=True, eps=eps)
+    np.testing.assert_allclose([l2m, llm], [rl2.mean(), rll.mean()], rtol=1e-3)

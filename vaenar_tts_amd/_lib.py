@@ -81,6 +81,8 @@ PROTOTYPES = {
     "vnr_decoder_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "vnr_posterior_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "vnr_inference": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "vnr_prior_log_probability": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "vnr_elbo_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnr_op_dense": [_vp, C.POINTER(vnr_dense_desc)],
     "vnr_op_conv1d_bn": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],

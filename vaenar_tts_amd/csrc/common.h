@@ -71,6 +71,15 @@ hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int
 // zp <- sigmoid(ls+2)*zp + shift on one half of z; rowsum[m] = sum_c log(scale) (flow.py:223-239)
 hipError_t launch_coupling_fwd(const float* heads /*[M,2*half]: log_scale | shift*/, float* z,
                                int M, int half, int zp_off, float* row_logdet, hipStream_t s);
+hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
+                               float* row_logdet, hipStream_t s);
+hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps, int M, int C, float* z,
+                          float* row_lp, hipStream_t s);
+hipError_t launch_sqerr_rows(const float* rec, int rec_T, const float* tgt, int T, int B, int C, float* rows,
+                             hipStream_t s);
+hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, const int32_t* mel_len,
+                               const float* pred_len, const float* post_lp, const float* prior_lp, int B,
+                               float* l2, float* length_l2, float* kl, hipStream_t s);
 // out[b] = sum_{t < len[b]} rows[b*T + t]   (deterministic order)
 hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T,
                                     float scale, float* out, int accumulate, hipStream_t s);

@@ -44,6 +44,8 @@ struct ConvL {  // Conv1D + BN (utils.py:56-85), packed
 struct FlowStep {
   const float *fold_wt, *fold_b;         // ActNorm o InvertibleLinear
   double logdet_per_frame;               // sum(log_scale) + log|det W|  (flow.py:168,127-129)
+  const float *inv_wt, *inv_b;           // (InvertibleLinear o ActNorm)^-1 : eps = (z.inv(W) - b) / (exp(ls) + 1e-8)
+  double inv_logdet_per_frame;           // -sum(log_scale) + log|det inv(W)|  (flow.py:181,141-145)
   const float *pre_wt, *pre_b;           // transform pre_projection
   float pos_weight;
   const float *heads_wt, *heads_b;       // log_scale_proj | shift_proj
@@ -287,6 +289,27 @@ double slogdet_abs(std::vector<double> a, int n) {
   return acc;
 }
 
+// inverse of an n x n matrix in float64 (Gauss-Jordan with partial pivoting); false when singular
+bool invert_matrix(std::vector<double> a, int n, std::vector<double>& inv) {
+  inv.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int piv = c; double best = fabs(a[(size_t)c * n + c]);
+    for (int r = c + 1; r < n; ++r) { const double v = fabs(a[(size_t)r * n + c]); if (v > best) { best = v; piv = r; } }
+    if (best == 0.0) return false;
+    if (piv != c) for (int k = 0; k < n; ++k) { std::swap(a[(size_t)c * n + k], a[(size_t)piv * n + k]); std::swap(inv[(size_t)c * n + k], inv[(size_t)piv * n + k]); }
+    const double d = 1.0 / a[(size_t)c * n + c];
+    for (int k = 0; k < n; ++k) { a[(size_t)c * n + k] *= d; inv[(size_t)c * n + k] *= d; }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = a[(size_t)r * n + c];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; ++k) { a[(size_t)r * n + k] -= f * a[(size_t)c * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k]; }
+    }
+  }
+  return true;
+}
+
 int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
   uint32_t bits; memcpy(&bits, &step, 4);
   auto key = std::make_tuple(T, dim, bits);
@@ -523,6 +546,44 @@ int posterior_body(vnr_handle h, const float* mels, const float* kv, int kv_ld, 
   return VNR_OK;
 }
 
+// TransformerPrior.log_probability (prior.py:119-152); kv = prior cross K|V panel output.  z is consumed (overwritten).
+int prior_logprob_body(vnr_handle h, float* z, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld,
+                       int B, int Tz, int Tt, float* logprobs) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M); WS(zb, (size_t)M * C);
+  HIP_TRY(h, hipMemsetAsync(logprobs, 0, (size_t)B * 4, h->stream));
+  const float* pe = nullptr;
+  TRY(get_pe(h, Tz, D, 1.0f, &pe));
+  float* zc = z; float* zn = zb;
+  for (int s = (int)h->flow.size() - 1; s >= 0; --s) {
+    const FlowStep& f = h->flow[s];
+    const bool upper = (s % 2) == 0;
+    const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;
+    GemmArgs g;   // coupling net on the conditioning half (flow.py:245-248)
+    g.A1 = zc + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
+    g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+    float* xc = xa; float* xn = xb;
+    for (size_t b = 0; b < f.blks.size(); ++b) {
+      TRY(run_xblk(h, f.blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature, nullptr));
+      std::swap(xc, xn);
+    }
+    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b; g.C = heads; g.ldc = C; g.M = M; g.N = C;
+    TRY(run_gemm(h, g));
+    RUN_MISC(h, launch_coupling_bwd(heads, zc, M, half, zp_off, rowld, h->stream));
+    RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));    // logdet = -sum log(scale)
+    g = GemmArgs(); g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = f.inv_wt; g.ldw = C; g.bias = f.inv_b; g.C = zn; g.ldc = C; g.M = M; g.N = C;
+    TRY(run_gemm(h, g));                                     // linear.bwd then actnorm.bwd, folded
+    RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)f.inv_logdet_per_frame, B, h->stream));
+    std::swap(zc, zn);
+  }
+  WS(base, (size_t)B);
+  RUN_MISC(h, launch_gauss_logprob(zc, z_len, B, Tz, C, base, h->stream));   // -0.5 (log 2pi + eps^2), masked (prior.py:147-150)
+  RUN_MISC(h, launch_masked_row_reduce(base, nullptr, B, 1, 1.0f, logprobs, 1, h->stream));
+  return VNR_OK;
+}
+
 int check_ready(vnr_handle h) {
   if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
   if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
@@ -736,6 +797,23 @@ int vnr_finalize_weights(vnr_handle h) {
       float lssum = 0.f;   // tf.reduce_sum(log_scale) in fp32 (flow.py:168)
       for (int i = 0; i < C; ++i) lssum += lsf[i];
       f.logdet_per_frame = (double)lssum + (double)(float)slogdet_abs(Wh, C);   // cast to fp32, flow.py:127-129
+      // backward direction (prior.log_probability): eps = (z . inv(W) - b) / (exp(ls) + 1e-8)  (flow.py:137-150, 177-187)
+      std::vector<double> Winv;
+      std::vector<float> abf(C), wti((size_t)C * C), bi(C);
+      if (hipMemcpy(abf.data(), ab, (size_t)C * 4, hipMemcpyDeviceToHost) != hipSuccess) { P.rc = VNR_ERR_HIP; P.missing = "d2h actnorm bias"; }
+      if (!invert_matrix(Wh, C, Winv)) { P.rc = VNR_ERR_WEIGHT; P.missing = "singular invertible-linear weight " + p + "/1/weight"; }
+      else {
+        for (int n = 0; n < C; ++n) {
+          const double d = 1.0 / ((double)expf(lsf[n]) + 1e-8);
+          for (int k = 0; k < C; ++k) wti[(size_t)n * C + k] = (float)((double)(float)Winv[(size_t)k * C + n] * d);   // inv(W) rounded to fp32 like tf.linalg.inv
+          bi[n] = (float)(-(double)abf[n] * d);
+        }
+        float* iw = P.alloc((size_t)C * C); float* ib = P.alloc(C);
+        if (iw && ib && (hipMemcpy(iw, wti.data(), (size_t)C * C * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                         hipMemcpy(ib, bi.data(), (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess)) { P.rc = VNR_ERR_HIP; P.missing = "h2d inverse fold"; }
+        f.inv_wt = iw; f.inv_b = ib;
+        f.inv_logdet_per_frame = -(double)lssum + (double)(float)slogdet_abs(Winv, C);
+      }
     }
     f.fold_wt = fw; f.fold_b = fb;
     f.pos_weight = P.scalar(p + "/2/net/pos_weight");
@@ -863,6 +941,76 @@ int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_leng
   TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kv, kv_n, B, Tz, Tt, d_eps, z, nullptr));
   return decoder_body(h, z, kv + h->prior_kv_n, kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor,
                       nullptr, d_mel, d_alignments);
+}
+
+int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+                              const int32_t* d_text_lengths, int B, int Tz, int Tt, float* d_logprobs) {
+  TRY(check_ready(h));
+  if (!d_z || !d_text_embd || !d_z_lengths || !d_logprobs || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  WS(kv, (size_t)B * Tt * h->prior_kv_n);
+  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv));
+  WS(zc, (size_t)B * Tz * h->cfg.latent_dim);
+  HIP_TRY(h, hipMemcpyAsync(zc, d_z, (size_t)B * Tz * h->cfg.latent_dim * 4, hipMemcpyDeviceToDevice, h->stream));
+  return prior_logprob_body(h, zc, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_logprobs);
+}
+
+int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
+                 const int32_t* d_mel_lengths, const int32_t* d_reduced_lengths, int B, int Tt, int Tm, int rf,
+                 float pos_step, const float* d_eps, float* d_outs, float* d_l2, float* d_kl, float* d_length_l2,
+                 float* d_alignments, float* d_aux) {
+  TRY(check_ready(h));
+  if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
+  if (!d_ids || !d_mel_targets || !d_mel_lengths || !d_reduced_lengths || !d_outs || !d_l2 || !d_kl || !d_length_l2 ||
+      B <= 0 || Tt <= 0 || Tm <= 0 || rf < 1)
+    return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  const vnr_config& c = h->cfg;
+  const int Dm = c.enc_pre_hidden, C = c.latent_dim, od = c.output_dim;
+  const int Tz = (Tm + rf - 1) / rf;                                   // mel_targets[:, ::rf, :] (models.py:123)
+  if (c.num_mels != od) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");
+  WS(text_embd, (size_t)B * Tt * Dm);
+  TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
+  WS(pred, (size_t)B);
+  RUN_MISC(h, launch_length_predictor(text_embd, h->lp_w, h->lp_b, d_text_lengths, B, Tt, Dm, c.lenpred_activation, pred, h->stream));
+  // reduced mels: frames 0, rf, 2rf, ... (strided copy, rows of num_mels floats)
+  WS(rmel, (size_t)B * Tz * c.num_mels);
+  for (int b = 0; b < B; ++b)
+    HIP_TRY(h, hipMemcpy2DAsync(rmel + (size_t)b * Tz * c.num_mels, (size_t)c.num_mels * 4, d_mel_targets + (size_t)b * Tm * c.num_mels,
+                                (size_t)rf * c.num_mels * 4, (size_t)c.num_mels * 4, Tz, hipMemcpyDeviceToDevice, h->stream));
+  // posterior (first head is USED as logvar, second as mu: models.py:136 vs posterior.py:130)
+  const int kvn = h->post_kv_n + h->prior_kv_n + h->dec_kv_n;
+  WS(kvp, (size_t)B * Tt * h->post_kv_n);
+  TRY(run_kv(h, text_embd, B * Tt, Dm, h->post_kv_wt, h->post_kv_n, kvp));
+  WS(kv, (size_t)B * Tt * (h->prior_kv_n + h->dec_kv_n));
+  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, h->prior_kv_n + h->dec_kv_n, kv));
+  (void)kvn;
+  WS(head1, (size_t)B * Tz * C); WS(head2, (size_t)B * Tz * C);
+  TRY(posterior_body(h, rmel, kvp, h->post_kv_n, d_text_lengths, d_reduced_lengths, B, Tz, Tt, head1, head2));
+  const float* logvar = head1; const float* mu = head2;
+  WS(z, (size_t)B * Tz * C); WS(rowlp, (size_t)B * Tz); WS(post_lp, (size_t)B);
+  RUN_MISC(h, launch_reparam(mu, logvar, d_eps, B * Tz, C, z, rowlp, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rowlp, d_reduced_lengths, B, Tz, 1.0f, post_lp, 0, h->stream));
+  // decoder on the samples, cropped to the target length (models.py:179-183)
+  WS(dinit, (size_t)B * Tz * rf * od); WS(douts, (size_t)B * Tz * rf * od);
+  const int kv_ld = h->prior_kv_n + h->dec_kv_n;
+  TRY(decoder_body(h, z, kv + h->prior_kv_n, kv_ld, d_reduced_lengths, d_text_lengths, B, Tz, Tt, rf, dinit, douts, d_alignments));
+  HIP_TRY(h, hipMemcpy2DAsync(d_outs, (size_t)Tm * od * 4, douts, (size_t)Tz * rf * od * 4, (size_t)Tm * od * 4, B, hipMemcpyDeviceToDevice, h->stream));
+  WS(rows, (size_t)B * Tm); WS(sum_out, (size_t)B); WS(sum_init, (size_t)B);
+  RUN_MISC(h, launch_sqerr_rows(douts, Tz * rf, d_mel_targets, Tm, B, od, rows, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rows, d_mel_lengths, B, Tm, 1.0f, sum_out, 0, h->stream));
+  RUN_MISC(h, launch_sqerr_rows(dinit, Tz * rf, d_mel_targets, Tm, B, od, rows, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rows, d_mel_lengths, B, Tm, 1.0f, sum_init, 0, h->stream));
+  // prior log-probability of the samples (z is consumed)
+  WS(prior_lp, (size_t)B);
+  TRY(prior_logprob_body(h, z, d_reduced_lengths, d_text_lengths, kv, kv_ld, B, Tz, Tt, prior_lp));
+  RUN_MISC(h, launch_elbo_scalars(sum_out, sum_init, d_mel_lengths, pred, post_lp, prior_lp, B, d_l2, d_length_l2, d_kl, h->stream));
+  if (d_aux) {   // [pred_lengths | posterior_logprobs | prior_logprobs], B floats each (diagnostics / tests)
+    HIP_TRY(h, hipMemcpyAsync(d_aux, pred, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_aux + B, post_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_aux + 2 * (size_t)B, prior_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return VNR_OK;
 }
 
 // ---- single operators ---------------------------------------------------------------------------------------

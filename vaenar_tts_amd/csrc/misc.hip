@@ -164,6 +164,98 @@ masked_row_reduce_kernel(const float* __restrict__ rows, const int32_t* __restri
   }
 }
 
+// ---- TransformerCoupling._backward tail (flow.py:246-255): zp <- (zp - shift) / (sigmoid(ls+2) + 1e-12) ---------
+__global__ void __launch_bounds__(256)
+coupling_bwd_kernel(const float* __restrict__ heads, float* __restrict__ z, int M, int half, int ldz,
+                    int zp_off, float* __restrict__ row_logdet) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* hr = heads + (size_t)row * 2 * half;
+  float* zr = z + (size_t)row * ldz + zp_off;
+  float acc = 0.f;
+  for (int c = lane; c < half; c += 64) {
+    const float ls = hr[c], sh = hr[half + c];
+    const float scale = 1.0f / (1.0f + expf(-(ls + 2.0f)));
+    zr[c] = (zr[c] - sh) / (scale + 1e-12f);                            // _inverse_affine, flow.py:220
+    acc += logf(scale);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && row_logdet) row_logdet[row] = acc;
+}
+hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
+                               float* row_logdet, hipStream_t s) {
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
+                     2 * half, zp_off, row_logdet);
+  return hipGetLastError();
+}
+
+// ---- BasePosterior.reparameterize + log_probability rows (posterior.py:21-39, 42-72), n_sample = 1 ------------------
+// z = eps * exp(0.5 * logvar) + mu ; row_lp[m] = -0.5 * (C*log(2pi) + sum_c (logvar + eps^2)).  One wave per row.
+__global__ void __launch_bounds__(256)
+reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+               int M, int C, float* __restrict__ z, float* __restrict__ row_lp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const size_t o = (size_t)row * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float lv = logvar[o + c], e = eps ? eps[o + c] : 0.f;
+    z[o + c] = e * expf(0.5f * lv) + mu[o + c];
+    acc += lv + e * e;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) row_lp[row] = -0.5f * ((float)C * 1.8378770664093453f + acc);
+}
+hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps, int M, int C, float* z,
+                          float* row_lp, hipStream_t s) {
+  hipLaunchKernelGGL(reparam_kernel, dim3((M + 3) / 4), dim3(256), 0, s, mu, logvar, eps, M, C, z, row_lp);
+  return hipGetLastError();
+}
+
+// ---- rows of VAENAR._compute_l2_loss (models.py:78): row[b*T + t] = mean_c (rec - tgt)^2 ------------------------------
+__global__ void __launch_bounds__(256)
+sqerr_rows_kernel(const float* __restrict__ rec, int rec_T, const float* __restrict__ tgt, int T, int B, int C,
+                  float* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int b = row / T, t = row - b * T;
+  const float* r = rec + ((size_t)b * rec_T + t) * C;
+  const float* g = tgt + (size_t)row * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = r[c] - g[c]; acc += d * d; }
+  acc = wave_sum(acc);
+  if (lane == 0) rows[row] = acc / (float)C;
+}
+hipError_t launch_sqerr_rows(const float* rec, int rec_T, const float* tgt, int T, int B, int C, float* rows,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(sqerr_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, rec, rec_T, tgt, T, B, C, rows);
+  return hipGetLastError();
+}
+
+// ---- per-utterance scalars of the ELBO (models.py:89-103, 184-196) ------------------------------------------------------
+// l2[b] = (sum_out[b] + sum_init[b]) / len[b] ; length[b] = (log pred - log len)^2 ; kl[b] = post_lp - prior_lp
+__global__ void elbo_scalars_kernel(const float* sum_out, const float* sum_init, const int32_t* mel_len,
+                                    const float* pred_len, const float* post_lp, const float* prior_lp, int B,
+                                    float* l2, float* length_l2, float* kl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float n = (float)mel_len[b];
+  l2[b] = sum_out[b] / n + sum_init[b] / n;
+  const float d = logf(pred_len[b]) - logf(n);
+  length_l2[b] = d * d;
+  kl[b] = post_lp[b] - prior_lp[b];
+}
+hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, const int32_t* mel_len,
+                               const float* pred_len, const float* post_lp, const float* prior_lp, int B,
+                               float* l2, float* length_l2, float* kl, hipStream_t s) {
+  hipLaunchKernelGGL(elbo_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, s, sum_out, sum_init, mel_len,
+                     pred_len, post_lp, prior_lp, B, l2, length_l2, kl);
+  return hipGetLastError();
+}
+
 hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T, float scale,
                                     float* out, int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(masked_row_reduce_kernel, dim3(B), dim3(64), 0, s, rows, len, T, scale, out,

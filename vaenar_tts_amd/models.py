@@ -114,8 +114,50 @@ class VAENAR:
         return mel, alignments
 
     def __call__(self, inputs, mel_targets, mel_lengths, text_lengths=None, reduction_factor=2,
-                 training=None, reduce_loss=None):
-        raise NotImplementedError("VAENAR.call (ELBO forward/backward, models.py:105-197) is not built yet")
+                 training=None, reduce_loss=None, eps=None, return_alignments=True):
+        """VAENAR.call (models.py:105-197), forward only (training=False: the dev_step of train.py:148-155).
+        Returns (decoded_outs [B,Tm,out_dim], l2_loss, kl_divergence, length_loss, dec_alignments); with
+        reduce_loss the three losses are means over the batch (models.py:84,92,101), otherwise [B] vectors.
+        ``eps`` [B,1,Tz,C] or [B,Tz,C] replaces tf.random.normal of posterior.reparameterize
+        (posterior.py:35); default: drawn from self.prior.rng.  The backward pass / optimizer is not built."""
+        if training:
+            raise NotImplementedError("VAENAR.call(training=True): dropout, BN batch statistics and the backward "
+                                      "pass are not built yet (DESIGN.md)")
+        assert self.n_sample == 1
+        eng = self.engine
+        rf = int(reduction_factor)
+        ids = eng.asarray(inputs, np.int32)
+        B, Tt = ids.shape
+        mel = eng.asarray(mel_targets, np.float32)
+        Tm = mel.shape[1]
+        ml_h = mel_lengths.numpy() if hasattr(mel_lengths, "numpy") and not isinstance(mel_lengths, np.ndarray) \
+            else np.asarray(mel_lengths)
+        ml = eng.to_device(ml_h.astype(np.int32), np.int32)
+        rl = eng.to_device(((ml_h.astype(np.int64) + rf - 1) // rf).astype(np.int32), np.int32)     # models.py:125
+        tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
+        Tz = (Tm + rf - 1) // rf
+        C = self.hps.Common.latent_dim
+        if eps is None:
+            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+        pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:128
+        dec = self.decoder
+        outs = eng.empty((B, Tm, dec.out_dim))
+        l2, kl, ll = eng.empty((B,)), eng.empty((B,)), eng.empty((B,))
+        ali = eng.empty((dec.nblk, B, dec.heads, Tz, Tt)) if return_alignments else None
+        aux = eng.empty((3, B))
+        check(eng.lib.vnr_elbo_fwd(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+                                   eps_d.ptr, outs.ptr, l2.ptr, kl.ptr, ll.ptr, None if ali is None else ali.ptr,
+                                   aux.ptr), eng.handle)
+        self.last_aux = aux           # predicted lengths | posterior log-probs | prior log-probs
+        alignments = {}
+        if ali is not None:
+            n = B * dec.heads * Tz * Tt
+            for i, nm in enumerate(dec.block_names):
+                alignments[nm] = ali.view(i * n, (B, dec.heads, Tz, Tt))
+        if reduce_loss:
+            l2, kl, ll = (np.float32(t.numpy().mean(dtype=np.float32)) for t in (l2, kl, ll))
+        return outs, l2, kl, ll, alignments
 
     call = __call__
 

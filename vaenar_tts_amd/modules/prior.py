@@ -40,4 +40,15 @@ class TransformerPrior(EngineModule):
         return z, logp
 
     def log_probability(self, z, condition_inputs, z_lengths=None, condition_lengths=None, training=None):
-        raise NotImplementedError("prior.log_probability (training path, prior.py:119-152) is not built yet")
+        """prior.py:119-152: log p(z | text) by running the flow backwards; [B] (device)."""
+        self._no_training(training)
+        e = self.engine
+        zd = self._f32(z)
+        cond = self._f32(condition_inputs)
+        B, Tz, _ = zd.shape
+        Tt = cond.shape[1]
+        zl = self._i32(z_lengths, B, Tz)
+        tl = self._i32(condition_lengths, B, Tt)
+        out = e.empty((B,))
+        check(e.lib.vnr_prior_log_probability(e.handle, zd.ptr, cond.ptr, zl.ptr, tl.ptr, B, Tz, Tt, out.ptr), e.handle)
+        return out

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the committed golden fixtures under tests/golden/ (test infrastructure).
 
-    python oracle/make_golden.py            # oracle fixtures (float64 oracle, stored as float32)
+    python oracle/make_golden.py            # oracle fixtures + (when /root/reference exists) refshim_* fixtures
 
 Each fixture holds inputs and expected outputs of VAENAR.inference and of inference.py's test_step
 on a small ragged batch; weights are NOT stored -- they are regenerated from (config, seed, mode) by
@@ -57,12 +57,47 @@ def build(name):
     return out
 
 
+# Fixtures produced by the REFERENCE's own Python (models.VAENAR / modules.* imported from /root/reference and
+# executed over oracle/tf_shim in float64).  They pin the composition (call order, concat order, masks, head
+# swap ...) of the path; TensorFlow's kernel numerics stay unpinned.
+REF_CASES = {
+    "refshim_tiny": (tiny_hps, dict(B=3, T_text=11, T_mel=40, ragged=True, temperature=1.0, text_step=3, mel_step=7), 7),
+    "refshim_lj": (lambda: LJHPS, dict(B=2, T_text=19, T_mel=50, ragged=True, temperature=1.0, text_step=6, mel_step=13), 11),
+}
+
+
+def build_ref(name):
+    from oracle.run_reference_on_shim import reference_call, reference_inference
+    mk, kw, seed = REF_CASES[name]
+    hps = mk()
+    w = init_weights(hps, seed=seed, mode="synthetic")
+    b = make_batch(vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, seed=seed, **kw)
+    mel, ali, _, _ = reference_inference(hps, w, b["ids"], b["mel_lengths"], b["text_lengths"], b["eps"])
+    r = np.random.Generator(np.random.PCG64(seed + 1))
+    Tm = int(b["mel_lengths"].max())
+    mels = r.standard_normal((len(b["mel_lengths"]), Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps4 = r.standard_normal((len(b["mel_lengths"]), 1, (Tm + 1) // 2, hps.Common.latent_dim)).astype(np.float32)
+    outs, l2, kl, ll, cali = reference_call(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"],
+                                            eps4.reshape(eps4.shape[0], 1, eps4.shape[2], eps4.shape[3]))
+    out = dict(seed=np.int64(seed), ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], eps=b["eps"],
+               mel=np.asarray(mel, np.float32), call_mels=mels, call_eps=eps4, call_outs=np.asarray(outs, np.float32),
+               call_l2=np.asarray(l2, np.float64), call_kl=np.asarray(kl, np.float64), call_length=np.asarray(ll, np.float64))
+    for k, v in ali.items():
+        out["ali_" + k] = np.asarray(v, np.float32)
+    out["weights_sha256"] = np.frombuffer(weights_digest(w).encode(), dtype=np.uint8)
+    return out
+
+
 def main():
     d = os.path.join(ROOT, "tests", "golden")
     os.makedirs(d, exist_ok=True)
     for name in CASES:
         np.savez_compressed(os.path.join(d, name + ".npz"), **build(name))
         print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB")
+    if os.path.isdir("/root/reference"):
+        for name in REF_CASES:
+            np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref(name))
+            print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python over the tf shim)")
 
 
 if __name__ == "__main__":

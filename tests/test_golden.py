@@ -69,3 +69,75 @@ def test_hip_path_reproduces_golden(name):
         assert np.abs(outs.numpy() - g["ts_mel"]).max() < 2e-4
     finally:
         model.engine.close()
+
+
+# ---- fixtures produced by the reference's own Python over oracle/tf_shim (composition pin) ---------------------------
+from oracle.make_golden import REF_CASES
+
+
+def _ref_weights(name, g):
+    mk, _, seed = REF_CASES[name]
+    hps = mk()
+    w = init_weights(hps, seed=seed, mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode()
+    return hps, w
+
+
+@pytest.mark.parametrize("name", sorted(REF_CASES))
+def test_oracle_matches_reference_python(name):
+    """models.VAENAR.inference / .call of the reference (run over the tf shim, float64) vs the oracle."""
+    from oracle.vaenar_numpy import Oracle
+    g = _load(name)
+    hps, w = _ref_weights(name, g)
+    o = Oracle(hps, w, np.float64)
+    mel, ali = o.inference(g["ids"], g["mel_lengths"], g["text_lengths"], 2, g["eps"])
+    # the oracle stages the positional encoding in float32 like TF; the shim run is float64 -> ~1e-6 apart
+    np.testing.assert_allclose(mel, g["mel"], atol=5e-6)
+    for k, v in ali.items():
+        np.testing.assert_allclose(v, g["ali_" + k], atol=1e-6)
+    outs, l2, kl, ll, _ = o.call(g["ids"], g["call_mels"], g["mel_lengths"], g["text_lengths"], 2, False, False,
+                                 g["call_eps"].astype(np.float64))
+    np.testing.assert_allclose(outs, g["call_outs"], atol=5e-6)
+    np.testing.assert_allclose(l2, g["call_l2"], rtol=1e-5)
+    np.testing.assert_allclose(ll, g["call_length"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(kl, g["call_kl"], rtol=1e-5, atol=2e-2)   # float32-cast slogdet in the oracle (flow.py:127)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference checkout only exists in the build container")
+def test_reference_python_live_against_oracle():
+    """Re-runs the reference's modules live (this container only) on a fresh seed."""
+    from oracle.run_reference_on_shim import reference_inference
+    from oracle.vaenar_numpy import Oracle
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.synthetic import make_batch
+    hps = tiny_hps()
+    w = init_weights(hps, seed=99, mode="synthetic")
+    b = make_batch(2, 9, 26, latent_dim=hps.Common.latent_dim, ragged=True, temperature=1.0, seed=99, text_step=4, mel_step=9)
+    mel, ali, _, _ = reference_inference(hps, w, b["ids"], b["mel_lengths"], b["text_lengths"], b["eps"])
+    rm, ra = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+    np.testing.assert_allclose(mel, rm, atol=5e-6)
+    for k in ra:
+        np.testing.assert_allclose(ali[k], ra[k], atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(REF_CASES))
+def test_hip_path_matches_reference_python(name):
+    """The HIP path against vectors produced by the reference's own Python (inference mels + ELBO terms)."""
+    from vaenar_tts_amd.models import VAENAR
+    g = _load(name)
+    hps, w = _ref_weights(name, g)
+    model = VAENAR(hps, weights=w)
+    try:
+        mel, ali = model.inference(g["ids"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, eps=g["eps"])
+        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-4
+        for k in ali:
+            np.testing.assert_allclose(ali[k].numpy(), g["ali_" + k], atol=1e-5)
+        outs, l2, kl, ll, _ = model(g["ids"], g["call_mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2,
+                                    training=False, reduce_loss=False, eps=g["call_eps"])
+        assert np.abs(outs.numpy() - g["call_outs"]).max() < 2e-4
+        np.testing.assert_allclose(l2.numpy(), g["call_l2"], rtol=1e-4)
+        np.testing.assert_allclose(ll.numpy(), g["call_length"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(kl.numpy(), g["call_kl"], rtol=1e-3, atol=6e-2)
+    finally:
+        model.engine.close()

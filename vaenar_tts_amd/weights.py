@@ -189,7 +189,7 @@ def init_weights(hps, seed=1234, mode="synthetic", include_posterior=True, dtype
             a = rng.uniform(0.5, 1.5, shape) if syn else np.ones(shape)
         else:
             raise KeyError(path)
-        w[path] = np.ascontiguousarray(a, dtype=dtype)
+        w[path] = np.ascontiguousarray(a, dtype=dtype).reshape(shape)      # (ascontiguousarray promotes 0-d to 1-d)
     return w
 
 

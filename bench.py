@@ -111,12 +111,19 @@ def main():
                                                 "layer_norm", "misc")}
         eng.profile(False)
         eng.profile_reset()
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                traffic = json.load(fh)        # PMC-derived bytes per launch, collected by separate rocprofv3 passes
+        except Exception:
+            pass
         g = prof["gemm"]
         gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         out["roofline"] = {
-            "kernel": "gemm_kernel / gemm_ln_kernel (fp32 MFMA 32x32x2)", "bound": "mfma",
-            "achieved": gemm_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": gemm_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "kernel": "gemm2_kernel family (fp32 MFMA 32x32x2, LDS-DMA ring; Dense/concat/conv/LN epilogues)",
+            "bound": "mfma", "achieved": gemm_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": gemm_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("gemm_bytes_per_launch"),
+            "traffic_source": traffic.get("source"),
             "launches_per_step": g["launches"] // max(1, args.profile_steps),
             "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
             "flops_per_step": g["flops"] / max(1, args.profile_steps),
@@ -125,9 +132,9 @@ def main():
         if a["launches"]:
             gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             out["roofline_cross_attention"] = {
-                "kernel": "attn_kernel<128,true> (decoder cross-attention core, alignments stored)",
+                "kernel": "attn2_kernel<true> (decoder cross-attention core, alignments stored)",
                 "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                "frac": gbps / PEAK_HBM_GBPS, "traffic": None,
+                "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic.get("cross_attention_ali_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],
                 "avg_launch_us": 1e3 * a["ms"] / a["launches"],
             }

@@ -55,13 +55,29 @@ attn2_kernel(const AttnArgs a, int nqb) {
   float* scratch = reinterpret_cast<float*>(smem);
   float* xarea = reinterpret_cast<float*>(smem + 2 * SLOT);
 
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int qb = a.causal ? (nqb - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // heaviest causal blocks first
+  // XCD-aware work map (speed only): workgroup id w runs on XCD w % 8 and each XCD has a private L2, so all
+  // query blocks of one (batch, head) pair -- which re-read the same K/V -- are given ids with equal w % 8.
+  // pairs are dealt round-robin to the 8 XCDs; within an XCD the order is query-block-major so that the
+  // heaviest causal blocks of every pair still start first.  Falls back to the plain order when the pair count
+  // is not a multiple of 8.
+  const int npairs = a.B * a.H;
+  int wg = blockIdx.x;
+  int pair, qidx;
+  if ((npairs & 7) == 0) {
+    const int xcd = wg & 7, j = wg >> 3, ppx = npairs >> 3;   // ppx pairs per XCD
+    qidx = j / ppx;
+    pair = (j - qidx * ppx) * 8 + xcd;
+  } else {
+    qidx = wg / npairs;
+    pair = wg - qidx * npairs;
+  }
+  const int b = pair / a.H, hd = pair - b * a.H;
+  const int qb = a.causal ? (nqb - 1 - qidx) : qidx;             // heaviest causal blocks first
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qt = wave & 1, kh = wave >> 1;
   const int half = lane >> 5, l31 = lane & 31;
-  unsigned long long* ts = a.dbg_ts ? a.dbg_ts + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
+  unsigned long long* ts = a.dbg_ts ? a.dbg_ts + (size_t)blockIdx.x * 8 : nullptr;
   auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   const int Q0 = qb * 64, q0 = Q0 + qt * 32;
@@ -336,7 +352,7 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
     ~Dump() { if (!p) return; (void)hipStreamSynchronize(s); std::vector<unsigned long long> h(n); (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost); (void)hipFree(d);
       FILE* f = fopen(p, "ab"); if (f) { int hdr[8] = {a->B, a->H, a->Tq, a->Tk, a->causal, a->ali ? 1 : 0, (int)(n / 8), nqb}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); } } } dump{ts_path, dts, nts, s, &a, nqb};
   const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
-  dim3 grid(nqb, a.H, a.B);
+  dim3 grid(nqb * a.H * a.B);
   if (a.ali) {
     auto k = attn2_kernel<true>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -71,6 +71,7 @@ hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int
 // zp <- sigmoid(ls+2)*zp + shift on one half of z; rowsum[m] = sum_c log(scale) (flow.py:223-239)
 hipError_t launch_coupling_fwd(const float* heads /*[M,2*half]: log_scale | shift*/, float* z,
                                int M, int half, int zp_off, float* row_logdet, hipStream_t s);
+hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s);
 hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s);
 hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps, int M, int C, float* z,

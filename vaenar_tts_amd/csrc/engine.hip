@@ -392,11 +392,13 @@ int encoder_body(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, i
   const int M = B * T, Dm = c.enc_pre_hidden, A = c.enc_attention_dim, F = c.enc_ffn_hidden;
   WS(xa, (size_t)M * Dm); WS(xb, (size_t)M * Dm);
   float* cur = xa; float* nxt = xb;
-  // Embedding gather fused into the first conv's A loader (encoder.py:81 + utils.py:33-38)
+  // Embedding (encoder.py:81): a 4 MB row gather, then the conv stack (utils.py:33-38) on the DMA GEMM kernel
+  if (c.enc_embd_dim > Dm) return fail(h, VNR_ERR_ARG, "embd_dim larger than pre_hidden is not supported");
+  RUN_MISC(h, launch_gather_rows(h->emb, ids, M, c.enc_embd_dim, nxt, h->stream));
+  std::swap(cur, nxt);
   for (size_t i = 0; i < h->enc_convs.size(); ++i) {
-    TRY(run_conv(h, h->enc_convs[i], i == 0 ? h->emb : cur, i == 0 ? ids : nullptr, B, T,
-                 c.enc_pre_activation, c.enc_bn_before_act, i == 0 ? cur : nxt));
-    if (i > 0) std::swap(cur, nxt);
+    TRY(run_conv(h, h->enc_convs[i], cur, nullptr, B, T, c.enc_pre_activation, c.enc_bn_before_act, nxt));
+    std::swap(cur, nxt);
   }
   const float* pe = nullptr;
   TRY(get_pe(h, T, Dm, pos_step, &pe));

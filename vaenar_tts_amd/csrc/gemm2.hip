@@ -498,14 +498,9 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     if (g.N <= 128) return st == 3 ? launch2<32, 128, 1, 2, 3, true>(g, s) : launch2<32, 128, 1, 2, 4, true>(g, s);
     return st == 3 ? launch2<32, 256, 1, 4, 3, true>(g, s) : launch2<32, 256, 1, 4, 4, true>(g, s);
   }
-  struct Cand { int bm, bn, blocks; };
-  const Cand cands[3] = {{128, 128, 4}, {64, 128, 2}, {64, 64, 1}};
-  int best = 0; long best_cost = -1;
-  for (int i = 0; i < 3; ++i) {
-    const long tiles = (long)((g.M + cands[i].bm - 1) / cands[i].bm) * ((g.N + cands[i].bn - 1) / cands[i].bn);
-    const long cost = ((tiles + 255) / 256) * cands[i].blocks;
-    if (best_cost < 0 || cost < best_cost) { best = i; best_cost = cost; }
-  }
+  // 64x64 tiles (3 workgroups per CU) measured fastest or tied on every S1 shape (profiles/r01_*); the larger
+  // tiles stay selectable for experiments (VNR_GEMM_TILE = 0: 128x128, 1: 64x128).
+  int best = 2;
   if (force_tile >= 0) best = force_tile;
   switch (best) {
     case 0: return launch2<128, 128, 2, 2, 3, false>(g, s);

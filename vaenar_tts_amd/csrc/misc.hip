@@ -256,6 +256,23 @@ hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, cons
   return hipGetLastError();
 }
 
+// ---- tf.keras.layers.Embedding (encoder.py:81): out[r, :] = table[ids[r], :]; one wave per row, float4 lanes ------
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, int rows, int dim,
+                   float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* src = table + (size_t)ids[row] * dim;
+  float* dst = out + (size_t)row * dim;
+  for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+}
+hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s) {
+  if (dim & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, rows, dim, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T, float scale,
                                     float* out, int accumulate, hipStream_t s) {
   hipLaunchKernelGGL(masked_row_reduce_kernel, dim3(B), dim3(64), 0, s, rows, len, T, scale, out,

@@ -202,6 +202,12 @@ int vnr_op_layer_norm(vnr_handle h, const float *d_x, const float *d_gamma, cons
 /* PositionalEncoding.positional_encoding (modules/utils.py:333-355): d_out [T,dim]. */
 int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *d_out);
 
+/* Engine options.  "split_fp16" (default 1): Dense/Conv GEMMs outside the text encoder evaluate every fp32
+ * product as hi*hi + lo*hi + hi*lo on the fp16 matrix pipe (fp32 accumulate; 22 significant bits per operand,
+ * measured mel error vs the float64 oracle ~1e-5); 0 = exact fp32 MFMA everywhere.  The encoder -> length
+ * predictor chain is always exact fp32.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel. */
+int vnr_set_option(vnr_handle h, const char *name, int value);
+
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream and
  * accumulated per kernel class ("gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm",

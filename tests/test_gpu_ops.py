@@ -188,3 +188,28 @@ def test_positional_encoding(eng, T, dim, step):
     _lib.check(eng.lib.vnr_op_positional_encoding(eng.handle, T, dim, float(np.float32(step)), out.ptr), eng.handle)
     ref = O.positional_encoding(T, dim, np.float32(step))
     np.testing.assert_allclose(out.numpy(), ref, atol=4e-5, rtol=0)
+
+
+@pytest.mark.parametrize("m,k1,k2,n,ln", [(200, 512, 0, 256, 0), (6400, 256, 0, 1024, 0), (333, 256, 256, 256, 1),
+                                          (129, 1024, 0, 160, 0), (400, 96, 128, 96, 1), (64, 100, 0, 513, 0)])
+def test_dense_split_fp16(eng, m, k1, k2, n, ln):
+    """The split-fp16 GEMM path (hi*hi + lo*hi + hi*lo on the fp16 matrix pipe, fp32 accumulate) must stay in the
+    fp32 round-off class: checked against float64 with the same tolerance as the exact fp32-MFMA kernel."""
+    r = rng(m + n + k1)
+    a1 = r.standard_normal((m, k1)) * r.choice([1e-3, 1.0, 30.0], size=(m, 1))      # mixed row magnitudes
+    a2 = r.standard_normal((m, k2)) if k2 else None
+    w, b = r.standard_normal((k1 + k2, n)) / np.sqrt(k1 + k2), r.standard_normal(n)
+    res = r.standard_normal((m, n)) if ln else None
+    g, be = 1 + 0.1 * r.standard_normal(n), 0.1 * r.standard_normal(n)
+    f = lambda x: np.asarray(x, np.float32).astype(np.float64)
+    eng.set_option("op_dense_split", 1)
+    try:
+        got = dense_gpu(eng, a1, w, a2=a2, bias=b, residual=res, ln=(g, be) if ln else None)
+    finally:
+        eng.set_option("op_dense_split", 0)
+    x = f(a1) if a2 is None else np.concatenate([f(a1), f(a2)], -1)
+    ref = O.dense(x, f(w), f(b))
+    if ln:
+        ref = O.layer_norm(f(res) + ref, f(g), f(be))
+    scale = np.abs(x).max(1, keepdims=True) if not ln else 1.0
+    np.testing.assert_array_less(np.abs(got - ref) / np.maximum(scale, 1.0), 3e-5)

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
+    "vnr_set_option": [_vp, C.c_char_p, _i],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
     "vnr_profile_get": [_vp, C.c_char_p, _pd, _pi64, _pd, _pd],
@@ -271,6 +272,9 @@ class Engine:
 
     def finalize(self):
         check(self.lib.vnr_finalize_weights(self.handle), self.handle)
+
+    def set_option(self, name, value):
+        check(self.lib.vnr_set_option(self.handle, name.encode(), int(value)), self.handle)
 
     # -- instrumentation ----------------------------------------------------------
     def profile(self, on):

@@ -26,6 +26,8 @@ struct GemmArgs {
   const float* A1 = nullptr; int lda1 = 0; int K1 = 0;
   const float* A2 = nullptr; int lda2 = 0;
   const float* Wt = nullptr; int ldw = 0;
+  const void* Wsplit = nullptr;     // optional pre-split fp16 image of Wt (split-fp16 MFMA path), see gemm2.hip
+  float acc_scale = 1.f;            // 2^-s when the split image was pre-scaled by 2^s
   const float* bias = nullptr;
   int act = ACT_IDENTITY;
   const float* bn_scale = nullptr; const float* bn_shift = nullptr;
@@ -71,6 +73,9 @@ hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int
 // zp <- sigmoid(ls+2)*zp + shift on one half of z; rowsum[m] = sum_c log(scale) (flow.py:223-239)
 hipError_t launch_coupling_fwd(const float* heads /*[M,2*half]: log_scale | shift*/, float* z,
                                int M, int half, int zp_off, float* row_logdet, hipStream_t s);
+// Wt [N][K] fp32 -> [N][ceil(K/32)][hi x32 | lo x32] fp16 of (w * scale), zero padded
+hipError_t launch_split_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s);
+hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s);   // *out = max(*out, bits(max|x|))
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s);
 hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s);

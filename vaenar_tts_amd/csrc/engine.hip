@@ -88,6 +88,15 @@ struct vnr_context {
   float post_pos_weight = 1.f;
   std::vector<XBlk> post_blks;
 
+  // split-fp16 weight images (gemm2.hip SPLIT path): one per packed fp32 panel, keyed by the panel's base pointer
+  struct SplitPanel { int N, K; void* img; float acc_scale; };
+  std::map<const float*, SplitPanel> split_panels;
+  std::vector<void*> split_allocs;
+  bool split_enabled = true;     // engine option "split_fp16"
+  bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
+  bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
+  std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
+
   // workspace arena (chunks; bump allocation, reset at every top-level call)
   struct Chunk { char* p; size_t cap, off; };
   std::vector<Chunk> chunks;
@@ -152,7 +161,22 @@ struct ProfScope {
   ~ProfScope() { if (on) { hipEventRecord(rec.e1, h->stream); h->prof.push_back(rec); } }
 };
 
-int run_gemm(vnr_handle h, const GemmArgs& g) {
+int run_gemm(vnr_handle h, const GemmArgs& g_in) {
+  GemmArgs g = g_in;
+  if (h->split_enabled && h->split_scope && !g.gather_ids && g.M >= 64) {
+    // the fp32 panel that contains g.Wt (sub-panels start on a row boundary and keep the row length K)
+    auto it = h->split_panels.upper_bound(g.Wt);
+    if (it != h->split_panels.begin()) {
+      --it;
+      const auto& sp = it->second;
+      const ptrdiff_t off = g.Wt - it->first;
+      if (off >= 0 && off < (ptrdiff_t)sp.N * sp.K && off % sp.K == 0 && g.ldw == sp.K && g.K == sp.K &&
+          off / sp.K + g.N <= sp.N) {
+        g.Wsplit = (const char*)sp.img + (size_t)(off / sp.K) * ((sp.K + 31) / 32) * 128;
+        g.acc_scale = sp.acc_scale;
+      }
+    }
+  }
   ProfScope ps(h, CLS_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e) +
@@ -216,10 +240,12 @@ struct Packer {
     if (!src || !panel || rc != VNR_OK) return;
     if (launch_transpose(src, K, N, panel + (size_t)n_off * K, K, h->stream) != hipSuccess) { rc = VNR_ERR_HIP; missing = "transpose launch"; }
   }
+  void reg(const float* base, int N, int K) { if (base) h->panel_registry.push_back({base, {N, K}}); }
   const float* wt(const std::string& path, int K, int N) {
     const float* src = raw(path, {K, N});
     float* p = alloc((size_t)K * N);
     transpose_into(src, K, N, p, 0);
+    reg(p, N, K);
     return p;
   }
   void copy_into(const float* src, float* dst, size_t n) {
@@ -235,6 +261,7 @@ void pack_xblk(Packer& P, const std::string& p, int D, int mem, int F, float* kv
   P.transpose_into(P.raw(p + "/self_attention/key_layer/kernel", {D, D}), D, D, qkv, D);
   P.transpose_into(P.raw(p + "/self_attention/value_layer/kernel", {D, D}), D, D, qkv, 2 * D);
   o.qkv_wt = qkv;
+  P.reg(qkv, 3 * D, D);
   o.proj1_wt = P.wt(p + "/att_proj1/kernel", 2 * D, D);
   o.proj1_b = P.raw(p + "/att_proj1/bias", {D});
   o.ln1_g = P.raw(p + "/layer_norm1/gamma", {D});
@@ -260,6 +287,7 @@ void pack_conv(Packer& P, const std::string& p, int k, int cin, int cout, ConvL&
   const float* src = P.raw(p + "/conv1d/kernel", {k, cin, cout});
   float* wt = P.alloc((size_t)k * cin * cout);
   P.transpose_into(src, k * cin, cout, wt, 0);      // [k*cin, cout] -> [cout][k*cin]
+  P.reg(wt, cout, k * cin);
   o.wt = wt;
   o.bias = P.raw(p + "/conv1d/bias", {cout});
   float* sc = P.alloc(cout); float* sh = P.alloc(cout);
@@ -387,7 +415,17 @@ int run_kv(vnr_handle h, const float* text_embd, int rows, int mem, const float*
   return run_gemm(h, g);
 }
 
+int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out);
+// The encoder feeds the length predictor, whose float sum is truncated to an integer frame count (inference.py:135):
+// the whole chain stays on the exact fp32 MFMA path.
 int encoder_body(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out) {
+  const bool saved = h->split_scope;
+  h->split_scope = false;
+  const int rc = encoder_body_impl(h, ids, lens, B, T, pos_step, out);
+  h->split_scope = saved;
+  return rc;
+}
+int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out) {
   const vnr_config& c = h->cfg;
   const int M = B * T, Dm = c.enc_pre_hidden, A = c.enc_attention_dim, F = c.enc_ffn_hidden;
   WS(xa, (size_t)M * Dm); WS(xb, (size_t)M * Dm);
@@ -590,6 +628,7 @@ int check_ready(vnr_handle h) {
   if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
   if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
   HIP_TRY(h, hipSetDevice(h->device));
+  h->split_scope = true;          // module bodies other than the encoder may use the split-fp16 GEMM path
   return VNR_OK;
 }
 
@@ -743,6 +782,8 @@ int vnr_finalize_weights(vnr_handle h) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   for (auto p : h->packed_allocs) hipFree(p);
   h->packed_allocs.clear();
+  for (auto p : h->split_allocs) hipFree(p);
+  h->split_allocs.clear(); h->split_panels.clear(); h->panel_registry.clear();
   h->enc_convs.clear(); h->post_convs.clear(); h->enc_blks.clear(); h->flow.clear(); h->dec_blks.clear(); h->post_blks.clear();
   const vnr_config& c = h->cfg;
   Packer P{h};
@@ -780,6 +821,7 @@ int vnr_finalize_weights(vnr_handle h) {
   h->prior_kv_n = c.prior_n_blk * c.prior_n_transformer_blk * 2 * Dp;
   h->dec_kv_n = c.dec_nblk * 2 * Dd;
   float* kv_panel = P.alloc((size_t)(h->prior_kv_n + h->dec_kv_n) * Dm);
+  P.reg(kv_panel, h->prior_kv_n + h->dec_kv_n, Dm);
   h->prior_kv_wt = kv_panel;
   h->dec_kv_wt = kv_panel ? kv_panel + (size_t)h->prior_kv_n * Dm : nullptr;
   std::vector<double> Wh((size_t)C * C);
@@ -814,10 +856,12 @@ int vnr_finalize_weights(vnr_handle h) {
         if (iw && ib && (hipMemcpy(iw, wti.data(), (size_t)C * C * 4, hipMemcpyHostToDevice) != hipSuccess ||
                          hipMemcpy(ib, bi.data(), (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess)) { P.rc = VNR_ERR_HIP; P.missing = "h2d inverse fold"; }
         f.inv_wt = iw; f.inv_b = ib;
+        P.reg(iw, C, C);
         f.inv_logdet_per_frame = -(double)lssum + (double)(float)slogdet_abs(Winv, C);
       }
     }
     f.fold_wt = fw; f.fold_b = fb;
+    P.reg(fw, C, C);
     f.pos_weight = P.scalar(p + "/2/net/pos_weight");
     f.pre_wt = P.wt(p + "/2/net/pre_projection/kernel", half, Dp);
     f.pre_b = P.raw(p + "/2/net/pre_projection/bias", {Dp});
@@ -827,6 +871,7 @@ int vnr_finalize_weights(vnr_handle h) {
     P.copy_into(P.raw(p + "/2/net/log_scale_proj/bias", {half}), hb, half);
     P.copy_into(P.raw(p + "/2/net/shift_proj/bias", {half}), hb ? hb + half : nullptr, half);
     f.heads_wt = hw; f.heads_b = hb;
+    P.reg(hw, C, Dp);
     for (int b = 0; b < c.prior_n_transformer_blk; ++b) {
       XBlk k;
       pack_xblk(P, p + "/2/net/attentions/" + std::to_string(b), Dp, Dm, c.prior_ffn_hidden, kv_panel,
@@ -863,6 +908,7 @@ int vnr_finalize_weights(vnr_handle h) {
     h->post_kv_n = c.post_nblk * 2 * Dq;
     float* pkv = P.alloc((size_t)h->post_kv_n * Dm);
     h->post_kv_wt = pkv;
+    P.reg(pkv, h->post_kv_n, Dm);
     for (int b = 0; b < c.post_nblk; ++b) {
       XBlk k; pack_xblk(P, "posterior/attentions/" + std::to_string(b), Dq, Dm, c.post_ffn_hidden, pkv, b * 2 * Dq, k);
       h->post_blks.push_back(k);
@@ -872,6 +918,33 @@ int vnr_finalize_weights(vnr_handle h) {
   }
   if (P.rc != VNR_OK) return fail(h, P.rc, P.missing);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // ---- split-fp16 images: w * 2^s = hi + lo (fp16 pair), s per panel so that max|w| * 2^s <= 2^14 ----------------------
+  {
+    unsigned* dmax = nullptr;
+    HIP_TRY(h, hipMalloc((void**)&dmax, h->panel_registry.size() * sizeof(unsigned) + 4));
+    HIP_TRY(h, hipMemsetAsync(dmax, 0, h->panel_registry.size() * sizeof(unsigned) + 4, h->stream));
+    for (size_t i = 0; i < h->panel_registry.size(); ++i) {
+      auto& e = h->panel_registry[i];
+      HIP_TRY(h, launch_absmax(e.first, (size_t)e.second.first * e.second.second, dmax + i, h->stream));
+    }
+    std::vector<unsigned> hmax(h->panel_registry.size() + 1);
+    HIP_TRY(h, hipMemcpyAsync(hmax.data(), dmax, h->panel_registry.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(dmax));
+    for (size_t i = 0; i < h->panel_registry.size(); ++i) {
+      auto& e = h->panel_registry[i];
+      const int N = e.second.first, K = e.second.second;
+      float mx; memcpy(&mx, &hmax[i], 4);
+      int sexp = 8;
+      if (mx > 0.f && std::isfinite(mx)) { sexp = (int)floor(log2(16384.0 / (double)mx)); if (sexp > 24) sexp = 24; if (sexp < -24) sexp = -24; }
+      void* img = nullptr;
+      HIP_TRY(h, hipMalloc(&img, (size_t)N * ((K + 31) / 32) * 128));
+      h->split_allocs.push_back(img);
+      HIP_TRY(h, launch_split_weights(e.first, N, K, (float)ldexp(1.0, sexp), img, h->stream));
+      h->split_panels[e.first] = {N, K, img, (float)ldexp(1.0, -sexp)};
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   h->finalized = true;
   return VNR_OK;
 }
@@ -1028,6 +1101,12 @@ int vnr_op_dense(vnr_handle h, const vnr_dense_desc* d) {
   g.A1 = d->d_a1; g.lda1 = d->lda1; g.K1 = d->k1; g.A2 = d->k2 > 0 ? d->d_a2 : nullptr; g.lda2 = d->lda2; g.K = K;
   g.Wt = wt; g.ldw = K; g.bias = d->d_bias; g.act = d->activation; g.residual = d->d_residual; g.ldr = d->ldr;
   g.pe = d->d_pe; g.pe_T = d->pe_T > 0 ? d->pe_T : 1; g.pe_w = d->pe_weight; g.C = d->d_c; g.ldc = d->ldc; g.M = d->m; g.N = d->n;
+  h->split_scope = false;                  // the operator entry point picks the path explicitly:
+  if (h->op_dense_split) {                  // option "op_dense_split": exercise the split-fp16 kernel on a temporary image
+    WS(img, (size_t)d->n * ((K + 31) / 32) * 32);
+    RUN_MISC(h, launch_split_weights(wt, d->n, K, 256.f, img, h->stream));
+    g.Wsplit = img; g.acc_scale = 1.f / 256.f;
+  }
   if (d->d_ln_gamma && d->d_ln_beta) {
     if (d->n <= 256 && !d->d_pe) { g.ln_gamma = d->d_ln_gamma; g.ln_beta = d->d_ln_beta; return run_gemm(h, g); }
     if (d->ldc != d->n) return fail(h, VNR_ERR_ARG, "LayerNorm epilogue needs a dense output (ldc == n)");
@@ -1076,6 +1155,13 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* 
   HIP_TRY(h, hipSetDevice(h->device));
   RUN_MISC(h, launch_positional_encoding(T, dim, step, d_out, h->stream));
   return VNR_OK;
+}
+
+int vnr_set_option(vnr_handle h, const char* name, int value) {
+  if (!h || !name) return fail(h, VNR_ERR_ARG, "null argument");
+  if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
+  return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }
 
 // ---- instrumentation -------------------------------------------------------------------------------------------

@@ -35,10 +35,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits carried by two fp16 values
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, bool SPLIT>
 __global__ void __launch_bounds__(WM* WN * 64)
 gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;
@@ -76,8 +83,13 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   const unsigned delta2 = g.A2 ? (unsigned)((const char*)g.A2 - abase) : 0u;
   const size_t a_end = (delta1 + a1_span > delta2 + a2_span) ? delta1 + a1_span : delta2 + a2_span;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, (unsigned)a_end, 0x00020000);
-  const unsigned b_bytes = (unsigned)(((size_t)(g.N - 1) * g.ldw + g.K) * 4);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.Wt, 0, b_bytes, 0x00020000);
+  // SPLIT: the weight panel is the pre-split fp16 image [N][ceil(K/32)][hi x32 | lo x32] (128 bytes per k-tile,
+  // zero padded), i.e. the same bytes-per-row geometry as fp32 with K rounded up to 32.
+  const int b_row_bytes = SPLIT ? ((g.K + 31) >> 5) * 128 : g.ldw * 4;
+  const unsigned b_bytes = SPLIT ? (unsigned)((size_t)g.N * b_row_bytes)
+                                 : (unsigned)(((size_t)(g.N - 1) * g.ldw + g.K) * 4);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(SPLIT ? (void*)g.Wsplit : (void*)g.Wt, 0, b_bytes, 0x00020000);
 
   // ---- per-lane DMA source descriptions ------------------------------------------------------------------
   // instruction x of this wave covers stage rows 8*(wave + NW*x) .. +7; lane -> row (lane>>3), chunk (lane&7)
@@ -114,7 +126,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int n = n0 + r;
     b_c4[x] = 4 * c;
-    b_off[x] = (n < g.N) ? (unsigned)(((size_t)n * g.ldw + 4 * c) * 4) : kOobOffset;
+    b_off[x] = (n < g.N) ? (unsigned)((size_t)n * b_row_bytes + 16 * c) : kOobOffset;
   }
 
   // DMA instruction d (0 <= d < LPW) of k-tile `kt` into ring slot `slot`; d < AQ are A rows, the rest B rows.
@@ -144,7 +156,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     } else {
       const int x = d - AQ;
       unsigned off = b_off[x];
-      if (k0 + b_c4[x] >= g.K) off = kOobOffset;
+      if (!SPLIT && k0 + b_c4[x] >= g.K) off = kOobOffset;   // (the split image is zero padded to whole k-tiles)
+      if (SPLIT && k0 >= g.K) off = kOobOffset;
       lds_ptr_t dst = (lds_ptr_t)(sbase + BM * 128 + (wave + NW * x) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, off, k0 * 4, 0, 0);
     }
@@ -203,72 +216,150 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   const int nk = (g.K + 31) >> 5;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
-  f32x4 fa[2][MI], fb[2][NI];
-  auto frag = [&](const char* As, const char* Bs, int c8, int set) {
+  if constexpr (SPLIT) {
+    // ---- split-fp16 pipeline: every fp32 product a*w is evaluated as hi_a*hi_w + lo_a*hi_w + hi_a*lo_w on the
+    // fp16 matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulate); the dropped lo*lo term is 2^-22 relative.
+    // A k-tile (32 k) = two k16 steps; lane-half g owns k = 16t + 8g .. +7 of step t:
+    //   A (fp32 in LDS): 16-byte chunks 4t+2g, 4t+2g+1 -> split in registers
+    //   B (pre-split)  : hi chunk 2t+g, lo chunk 4+2t+g
+    int rdA[2][2], rdB[2][2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + i * 4096 + rd_off[c8]);
+    for (int t = 0; t < 2; ++t) {
+      rdA[t][0] = l31 * 128 + (((4 * t + 2 * half) ^ swz) << 4);
+      rdA[t][1] = l31 * 128 + (((4 * t + 2 * half + 1) ^ swz) << 4);
+      rdB[t][0] = l31 * 128 + (((2 * t + half) ^ swz) << 4);
+      rdB[t][1] = l31 * 128 + (((4 + 2 * t + half) ^ swz) << 4);
+    }
+    f16x8 ahi[2][MI], alo[2][MI], bhi[2][NI], blo[2][NI];
+    auto fragS = [&](const char* As, const char* Bs, int t, int set) {
+      f32x4 x0[MI], x1[MI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + rd_off[c8]);
-  };
-  auto mfma_group = [&](int set, int kt_dma, int ns, bool with_dma) {
-    int d = 0;
+      for (int i = 0; i < MI; ++i) {
+        x0[i] = *reinterpret_cast<const f32x4*>(As + i * 4096 + rdA[t][0]);
+        x1[i] = *reinterpret_cast<const f32x4*>(As + i * 4096 + rdA[t][1]);
+      }
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < NI; ++j) {
+        bhi[set][j] = *reinterpret_cast<const f16x8*>(Bs + j * 4096 + rdB[t][0]);
+        blo[set][j] = *reinterpret_cast<const f16x8*>(Bs + j * 4096 + rdB[t][1]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 h, l;
+          split_f16(x0[i][e], h, l); ahi[set][i][e] = h; alo[set][i][e] = l;
+          split_f16(x1[i][e], h, l); ahi[set][i][4 + e] = h; alo[set][i][4 + e] = l;
+        }
+    };
+    auto mfmaS = [&](int set, int kt_dma, int ns, bool with_dma) {
+      int d = 0;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][s], fa[set][i][s], acc[i][j], 0, 0, 0);   // D^T: lane <-> row m
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], ahi[set][i], acc[i][j], 0, 0, 0);   // D^T
+          if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], alo[set][i], acc[i][j], 0, 0, 0);
+          if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[set][j], ahi[set][i], acc[i][j], 0, 0, 0);
           if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
         }
-    if (with_dma)
+      if (with_dma)
 #pragma unroll
-      for (; d < LPW; ++d) issue_one(kt_dma, ns, d);       // more DMA instructions than MFMAs in one group
-  };
-  stamp(1);
-  wait_vmcnt<(NSTAGE - 2) * LPW>();                   // tile 0 landed
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  {
-    const char* As = smem + wm * TM * 128;
-    const char* Bs = smem + BM * 128 + wn * TN * 128;
-    frag(As, Bs, 0, 0);
-    frag(As, Bs, 1, 1);
-  }
-  int slot = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
-    const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
-    int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;   // slot of tile kt-1 == slot of tile kt+NSTAGE-1
-    int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;             // slot of tile kt+1
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, kt + NSTAGE - 1, ns, true);          // G0 + DMA of tile kt+NSTAGE-1
-    frag(As, Bs, 2, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(1, 0, 0, false);                        // G1
-    frag(As, Bs, 3, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, 0, 0, false);                        // G2
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");   // tile kt+1 landed; my reads of tile kt done
+        for (; d < LPW; ++d) issue_one(kt_dma, ns, d);
+    };
+    stamp(1);
+    wait_vmcnt<(NSTAGE - 2) * LPW>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    fragS(smem + wm * TM * 128, smem + BM * 128 + wn * TN * 128, 0, 0);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
+      const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
+      int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;
+      int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;
+      __builtin_amdgcn_sched_barrier(0);
+      fragS(As, Bs, 1, 1);                               // second k16 step of this tile
+      mfmaS(0, kt + NSTAGE - 1, ns, true);               // first step + DMA of tile kt+NSTAGE-1
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      mfmaS(1, 0, 0, false);
+      fragS(smem + nx * STAGE_BYTES + wm * TM * 128, smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128, 0, 0);
+      slot = nx;
+    }
+  } else {
+  f32x4 fa[2][MI], fb[2][NI];
+    auto frag = [&](const char* As, const char* Bs, int c8, int set) {
+  #pragma unroll
+      for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(As + i * 4096 + rd_off[c8]);
+  #pragma unroll
+      for (int j = 0; j < NI; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Bs + j * 4096 + rd_off[c8]);
+    };
+    auto mfma_group = [&](int set, int kt_dma, int ns, bool with_dma) {
+      int d = 0;
+  #pragma unroll
+      for (int s = 0; s < 4; ++s)
+  #pragma unroll
+        for (int i = 0; i < MI; ++i)
+  #pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j][s], fa[set][i][s], acc[i][j], 0, 0, 0);   // D^T: lane <-> row m
+            if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
+          }
+      if (with_dma)
+  #pragma unroll
+        for (; d < LPW; ++d) issue_one(kt_dma, ns, d);       // more DMA instructions than MFMAs in one group
+    };
+    stamp(1);
+    wait_vmcnt<(NSTAGE - 2) * LPW>();                   // tile 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
-      const char* An = smem + nx * STAGE_BYTES + wm * TM * 128;
-      const char* Bn = smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128;
-      frag(An, Bn, 0, 0);                              // first group of tile kt+1 (set 0 is free after G2)
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group(1, 0, 0, false);                      // G3
-      frag(An, Bn, 1, 1);
+      const char* As = smem + wm * TM * 128;
+      const char* Bs = smem + BM * 128 + wn * TN * 128;
+      frag(As, Bs, 0, 0);
+      frag(As, Bs, 1, 1);
     }
-    slot = nx;
-  }
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
+      const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
+      int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;   // slot of tile kt-1 == slot of tile kt+NSTAGE-1
+      int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;             // slot of tile kt+1
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(0, kt + NSTAGE - 1, ns, true);          // G0 + DMA of tile kt+NSTAGE-1
+      frag(As, Bs, 2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(1, 0, 0, false);                        // G1
+      frag(As, Bs, 3, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(0, 0, 0, false);                        // G2
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");   // tile kt+1 landed; my reads of tile kt done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      {
+        const char* An = smem + nx * STAGE_BYTES + wm * TM * 128;
+        const char* Bn = smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128;
+        frag(An, Bn, 0, 0);                              // first group of tile kt+1 (set 0 is free after G2)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, 0, 0, false);                      // G3
+        frag(An, Bn, 1, 1);
+      }
+      slot = nx;
+    }
+}
   wait_vmcnt<0>();                                    // drain the dummy tail tiles before LDS is reused / exit
 
   // Result layout (operands swapped, D^T): lane (l31, half) owns output ROW m = .. + l31 and, per 32x32 block,
   // the 4-column groups n = .. + 8*q + 4*half + {0,1,2,3}, q = 0..3 (register 4q + e): 16-byte stores, and a
   // row's LayerNorm statistics are an in-lane sum plus one cross-half shuffle.
   stamp(3);
+  const float ascale = SPLIT ? g.acc_scale : 1.0f;
   if (!LN) {
     if (vec_ok) {
 #pragma unroll
@@ -298,7 +389,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             const int col = n0 + wn * TN + j * 32 + 8 * q + 4 * half;
             if (!rok || col >= g.N) continue;
             const float4 bi = p_bias[j][q], sc = p_sc[j][q], sh = p_sh[j][q];
-            float v[4] = {acc[i][j][4 * q] + bi.x, acc[i][j][4 * q + 1] + bi.y, acc[i][j][4 * q + 2] + bi.z, acc[i][j][4 * q + 3] + bi.w};
+            float v[4] = {acc[i][j][4 * q] * ascale + bi.x, acc[i][j][4 * q + 1] * ascale + bi.y, acc[i][j][4 * q + 2] * ascale + bi.z, acc[i][j][4 * q + 3] * ascale + bi.w};
             if (g.bn_scale && g.bn_first) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act2(v[e], g.act);
@@ -322,7 +413,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             for (int e = 0; e < 4; ++e) {
               const int c = n0 + wn * TN + j * 32 + 8 * q + 4 * half + e;
               if (c >= g.N) continue;
-              float t = acc[i][j][4 * q + e] + (g.bias ? g.bias[c] : 0.f);
+              float t = acc[i][j][4 * q + e] * ascale + (g.bias ? g.bias[c] : 0.f);
               if (g.bn_scale && g.bn_first) t = t * g.bn_scale[c] + g.bn_shift[c];
               t = act2(t, g.act);
               if (g.bn_scale && !g.bn_first) t = t * g.bn_scale[c] + g.bn_shift[c];
@@ -358,10 +449,10 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
           const int col = wn * TN + j * 32 + 8 * q + 4 * half;
           const bool ok = rok && col < g.N;
           const float4 bi = p_bias[j][q], r4 = res[j][q];
-          v[j][4 * q + 0] = ok ? act2(acc[0][j][4 * q + 0] + bi.x, g.act) + r4.x : 0.f;
-          v[j][4 * q + 1] = ok ? act2(acc[0][j][4 * q + 1] + bi.y, g.act) + r4.y : 0.f;
-          v[j][4 * q + 2] = ok ? act2(acc[0][j][4 * q + 2] + bi.z, g.act) + r4.z : 0.f;
-          v[j][4 * q + 3] = ok ? act2(acc[0][j][4 * q + 3] + bi.w, g.act) + r4.w : 0.f;
+          v[j][4 * q + 0] = ok ? act2(acc[0][j][4 * q + 0] * ascale + bi.x, g.act) + r4.x : 0.f;
+          v[j][4 * q + 1] = ok ? act2(acc[0][j][4 * q + 1] * ascale + bi.y, g.act) + r4.y : 0.f;
+          v[j][4 * q + 2] = ok ? act2(acc[0][j][4 * q + 2] * ascale + bi.z, g.act) + r4.z : 0.f;
+          v[j][4 * q + 3] = ok ? act2(acc[0][j][4 * q + 3] * ascale + bi.w, g.act) + r4.w : 0.f;
           s1 += (v[j][4 * q] + v[j][4 * q + 1]) + (v[j][4 * q + 2] + v[j][4 * q + 3]);
         }
     } else {
@@ -374,7 +465,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             const int col = wn * TN + j * 32 + 8 * q + 4 * half + e;
             float t = 0.f;
             if (rok && col < g.N) {
-              t = act2(acc[0][j][4 * q + e] + (g.bias ? g.bias[col] : 0.f), g.act);
+              t = act2(acc[0][j][4 * q + e] * ascale + (g.bias ? g.bias[col] : 0.f), g.act);
               if (g.residual) t += g.residual[(size_t)row * g.ldr + col];
             }
             v[j][4 * q + e] = t;
@@ -432,7 +523,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, bool SPLIT = false>
 static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = LN ? 1 : (g.N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
@@ -446,10 +537,10 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
     const int mode = g.taps > 0 ? 1 : 0;
-    if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false>;
+    if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
-    else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN>;
+    else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
     (void)hipStreamSynchronize(s);
@@ -462,11 +553,11 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   }
   if (g.taps > 0) {
     if (LN) return hipErrorInvalidValue;
-    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false>;
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
   } else {
-    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN>;
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
   }
@@ -494,6 +585,10 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   static const int force_tile = getenv("VNR_GEMM_TILE") ? atoi(getenv("VNR_GEMM_TILE")) : -1;
   const GemmArgs& g = g_in;
   static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
+  if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
+    if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 4, true, true>(g, s) : launch2<32, 256, 1, 4, 4, true, true>(g, s);
+    return launch2<64, 64, 2, 2, 3, false, true>(g, s);
+  }
   if (g.ln_gamma) {
     if (g.N <= 128) return st == 3 ? launch2<32, 128, 1, 2, 3, true>(g, s) : launch2<32, 128, 1, 2, 4, true>(g, s);
     return st == 3 ? launch2<32, 256, 1, 4, 3, true>(g, s) : launch2<32, 256, 1, 4, 4, true>(g, s);

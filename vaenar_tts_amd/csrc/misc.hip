@@ -256,6 +256,39 @@ hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, cons
   return hipGetLastError();
 }
 
+// ---- max |x| of a buffer (bits of the non-negative float compare like unsigned ints) ---------------------------------
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
+  return hipGetLastError();
+}
+
+// ---- weight image of the split-fp16 GEMM path: w*scale = hi + lo (two fp16), k-tiles of 32 ------------------------------
+__global__ void split_weights_kernel(const float* __restrict__ Wt, int N, int K, float scale, _Float16* __restrict__ out) {
+  const int KT = (K + 31) >> 5;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * KT * 32) return;
+  const int p = idx & 31; const size_t nk = idx >> 5; const int kt = nk % KT; const size_t n = nk / KT;
+  const int k = kt * 32 + p;
+  const float w = k < K ? Wt[n * K + k] * scale : 0.f;
+  const _Float16 hi = (_Float16)w;
+  const _Float16 lo = (_Float16)(w - (float)hi);
+  out[nk * 64 + p] = hi;
+  out[nk * 64 + 32 + p] = lo;
+}
+hipError_t launch_split_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s) {
+  const size_t n = (size_t)N * ((K + 31) >> 5) * 32;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
+  return hipGetLastError();
+}
+
 // ---- tf.keras.layers.Embedding (encoder.py:81): out[r, :] = table[ids[r], :]; one wave per row, float4 lanes ------
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, int rows, int dim,

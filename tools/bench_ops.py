@@ -38,8 +38,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--split", type=int, default=0, help="use the split-fp16 GEMM kernel")
     args = ap.parse_args()
     eng = _lib.Engine(tiny_hps(), 0)
+    eng.set_option('op_dense_split', args.split)
     r = np.random.Generator(np.random.PCG64(0))
     if args.what in ("gemm", "all"):
         print("%-20s %6s %5s %5s %9s %9s %7s" % ("gemm", "M", "K", "N", "avg_us", "TFLOP/s", "frac"))

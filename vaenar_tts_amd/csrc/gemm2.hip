@@ -587,6 +587,11 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
   if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
     if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 4, true, true>(g, s) : launch2<32, 256, 1, 4, 4, true, true>(g, s);
+    static const int stile = getenv("VNR_SPLIT_TILE") ? atoi(getenv("VNR_SPLIT_TILE")) : -1;   // measurement knob
+    int t = stile;
+    if (t < 0) t = 2;
+    if (t == 0) return launch2<128, 128, 2, 2, 3, false, true>(g, s);
+    if (t == 1) return launch2<64, 128, 2, 2, 3, false, true>(g, s);
     return launch2<64, 64, 2, 2, 3, false, true>(g, s);
   }
   if (g.ln_gamma) {

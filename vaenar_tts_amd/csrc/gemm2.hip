@@ -216,6 +216,27 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   const int nk = (g.K + 31) >> 5;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  // LayerNorm row panels: the residual tile [32][N] is fetched NOW by LDS-DMA into a staging region behind the
+  // ring (16-byte chunks XOR-swizzled by row so the row-per-lane ds_read_b128 of the epilogue is conflict-free);
+  // it lands under the main loop.  The same region later holds the normalised rows, which leave as whole
+  // contiguous rows (1 KiB per wave instruction) instead of 64 partial cache lines per instruction.
+  constexpr int RES_INSTR = LN ? (32 * BN / 4 / 64) / NW : 0;      // residual DMA instructions per wave (BN-wide rows)
+  const bool staged = LN && vec_ok && (g.N & 63) == 0;
+  float* Rst = reinterpret_cast<float*>(smem + NSTAGE * STAGE_BYTES);
+  if (LN && staged && g.residual) {
+    const int cpr = g.N >> 2;                                     // 16-byte chunks per row
+    const unsigned r_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldr + g.N) * 4);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)g.residual, 0, r_bytes, 0x00020000);
+#pragma unroll
+    for (int x = 0; x < RES_INSTR; ++x) {
+      const int gidx = (wave + NW * x) * 64 + lane;                // linear chunk index inside the [32][N] tile
+      const int r = gidx / cpr, pc = gidx - r * cpr;
+      const int c = pc ^ (r & 15);
+      const unsigned off = (r < 32 && m0 + r < g.M) ? (unsigned)(((size_t)(m0 + r) * g.ldr + 4 * c) * 4) : kOobOffset;
+      if ((wave + NW * x) * 64 < 32 * cpr)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_ptr_t)((char*)Rst + (wave + NW * x) * 1024), 16, off, 0, 0, 0);
+    }
+  }
   if constexpr (SPLIT) {
     // ---- split-fp16 pipeline: every fp32 product a*w is evaluated as hi_a*hi_w + lo_a*hi_w + hi_a*lo_w on the
     // fp16 matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulate); the dropped lo*lo term is 2^-22 relative.
@@ -270,7 +291,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         for (; d < LPW; ++d) issue_one(kt_dma, ns, d);
     };
     stamp(1);
-    wait_vmcnt<(NSTAGE - 2) * LPW>();
+    wait_vmcnt<(NSTAGE - 2) * LPW>();                  // (with a staged residual in flight this also drains tile 1: conservative)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     fragS(smem + wm * TM * 128, smem + BM * 128 + wn * TN * 128, 0, 0);
@@ -428,6 +449,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     static_assert(!LN || (WM == 1 && MI == 1), "LayerNorm epilogue: one 32-row panel per workgroup");
     __syncthreads();                                  // all waves are done with the ring -> reuse it
     float* red = reinterpret_cast<float*>(smem);      // [2][32][NW]
+    const int cpr = g.N >> 2;
     const int row = m0 + l31;
     const bool rok = row < g.M;
     float v[NI][16];
@@ -439,8 +461,12 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = wn * TN + j * 32 + 8 * q + 4 * half;
-          res[j][q] = (rok && g.residual && col < g.N) ? *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (staged)      // swizzled LDS copy (DMA'd at kernel start; zeros for rows >= M)
+            res[j][q] = (g.residual && col < g.N) ? *reinterpret_cast<const float4*>(Rst + (size_t)l31 * g.N + 4 * ((col >> 2) ^ (l31 & 15)))
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+          else
+            res[j][q] = (rok && g.residual && col < g.N) ? *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
       for (int j = 0; j < NI; ++j)
@@ -497,7 +523,30 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) var += red[32 * NW + l31 * NW + w];
     const float rstd = 1.0f / sqrtf(var * (1.f / (float)g.N) + kLnEps);
-    if (rok) {
+    if (staged) {
+      // normalised rows go back to the staging tile (same swizzle), then leave as whole rows
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn * TN + j * 32 + 8 * q + 4 * half;
+          if (col >= g.N) continue;
+          const float4 ga = p_sc[j][q], be = p_sh[j][q];
+          *reinterpret_cast<float4*>(Rst + (size_t)l31 * g.N + 4 * ((col >> 2) ^ (l31 & 15))) =
+              make_float4((v[j][4 * q + 0] - mean) * rstd * ga.x + be.x, (v[j][4 * q + 1] - mean) * rstd * ga.y + be.y,
+                          (v[j][4 * q + 2] - mean) * rstd * ga.z + be.z, (v[j][4 * q + 3] - mean) * rstd * ga.w + be.w);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int x = 0; x < RES_INSTR; ++x) {
+        const int gidx = (wave + NW * x) * 64 + lane;
+        const int r = gidx / cpr, c = gidx - r * cpr;               // logical chunk c of row r
+        if (r < 32 && m0 + r < g.M) {
+          const float4 o4 = *reinterpret_cast<const float4*>(Rst + (size_t)r * g.N + 4 * (c ^ (r & 15)));
+          *reinterpret_cast<float4*>(g.C + (size_t)(m0 + r) * g.ldc + 4 * c) = o4;
+        }
+      }
+    } else if (rok) {
 #pragma unroll
       for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -526,7 +575,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, bool SPLIT = false>
 static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = LN ? 1 : (g.N + BN - 1) / BN;
-  const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * 128 + (LN ? (size_t)32 * BN * 4 : 0);
   const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
   static const char* ts_path = getenv("VNR_GEMM_TS");
   if (ts_path) {   // measurement only: synchronous launch + dump of the per-workgroup stamps
@@ -586,7 +635,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   const GemmArgs& g = g_in;
   static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
   if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
-    if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 4, true, true>(g, s) : launch2<32, 256, 1, 4, 4, true, true>(g, s);
+    if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 3, true, true>(g, s) : launch2<32, 256, 1, 4, 3, true, true>(g, s);
     static const int stile = getenv("VNR_SPLIT_TILE") ? atoi(getenv("VNR_SPLIT_TILE")) : -1;   // measurement knob
     int t = stile;
     if (t < 0) t = 2;
@@ -595,8 +644,9 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     return launch2<64, 64, 2, 2, 3, false, true>(g, s);
   }
   if (g.ln_gamma) {
-    if (g.N <= 128) return st == 3 ? launch2<32, 128, 1, 2, 3, true>(g, s) : launch2<32, 128, 1, 2, 4, true>(g, s);
-    return st == 3 ? launch2<32, 256, 1, 4, 3, true>(g, s) : launch2<32, 256, 1, 4, 4, true>(g, s);
+    (void)st;
+    if (g.N <= 128) return launch2<32, 128, 1, 2, 3, true>(g, s);
+    return launch2<32, 256, 1, 4, 3, true>(g, s);
   }
   // 64x64 tiles (3 workgroups per CU) measured fastest or tied on every S1 shape (profiles/r01_*); the larger
   // tiles stay selectable for experiments (VNR_GEMM_TILE = 0: 128x128, 1: 64x128).

@@ -204,8 +204,9 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *
 
 /* Engine options.  "split_fp16" (default 1): Dense/Conv GEMMs outside the text encoder evaluate every fp32
  * product as hi*hi + lo*hi + hi*lo on the fp16 matrix pipe (fp32 accumulate; 22 significant bits per operand,
- * measured mel error vs the float64 oracle ~1e-5); 0 = exact fp32 MFMA everywhere.  The encoder -> length
- * predictor chain is always exact fp32.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel. */
+ * measured mel error vs the float64 oracle ~3e-6, same as exact fp32 MFMA); 0 = exact fp32 MFMA everywhere.
+ * "split_encoder" (default 1): the text encoder (which feeds the integer frame-count predictor) uses the split path as
+ * well; 0 keeps that chain on exact fp32 MFMA.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 
 /* ---- instrumentation ------------------------------------------------------------------------ */

@@ -93,6 +93,7 @@ struct vnr_context {
   std::map<const float*, SplitPanel> split_panels;
   std::vector<void*> split_allocs;
   bool split_enabled = true;     // engine option "split_fp16"
+  bool split_encoder = true;     // engine option "split_encoder": the text encoder uses the split path too (measured as accurate as exact fp32: profiles/r01_split_accuracy.txt)
   bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
@@ -416,11 +417,12 @@ int run_kv(vnr_handle h, const float* text_embd, int rows, int mem, const float*
 }
 
 int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out);
-// The encoder feeds the length predictor, whose float sum is truncated to an integer frame count (inference.py:135):
-// the whole chain stays on the exact fp32 MFMA path.
+// The encoder feeds the length predictor, whose float sum is truncated to an integer frame count (inference.py:135).
+// Option "split_encoder" = 0 keeps this chain on the exact fp32 MFMA path; the split path measured equally accurate
+// (profiles/r01_split_accuracy.txt) and is the default.
 int encoder_body(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out) {
   const bool saved = h->split_scope;
-  h->split_scope = false;
+  h->split_scope = h->split_encoder;
   const int rc = encoder_body_impl(h, ids, lens, B, T, pos_step, out);
   h->split_scope = saved;
   return rc;
@@ -1160,6 +1162,7 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* 
 int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!h || !name) return fail(h, VNR_ERR_ARG, "null argument");
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }

@@ -41,6 +41,21 @@ __device__ __forceinline__ float fast_exp(float x) {
   const float r = __builtin_amdgcn_exp2f(t);
   return (x < -87.0f) ? ((x < -104.0f) ? 0.0f : expf(x)) : __builtin_fmaf(r, e * LN2, r);
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 h = (_Float16)x0[e]; hi[e] = h; lo[e] = (_Float16)(x0[e] - (float)h);
+    h = (_Float16)x1[e]; hi[4 + e] = h; lo[4 + e] = (_Float16)(x1[e] - (float)h);
+  }
+}
+// 3-term split product on the f16 matrix pipe: (ah + al) * (bh + bl) ~= ah*bh + al*bh + ah*bl  (fp32 accumulate)
+__device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  return c;
+}
 }  // namespace
 
 template <bool ALI>
@@ -117,16 +132,20 @@ attn2_kernel(const AttnArgs a, int nqb) {
   issue_tile(0, 0);
   if (ntiles_all > 1) issue_tile(1, 1);
 
-  // ---- Q fragment: lane (i,h) keeps Q[q0+i][8c+4h .. +3], c = 0..7 (issued first; in flight with the first tiles) --------
-  f32x4 qf[8];
+  // ---- Q fragment for the f16 matrix pipe: lane (i, g = half) keeps d = 16t + 8g .. +7, t = 0..3, as hi/lo fp16 pairs.
+  // Every product of QK^T and PV is evaluated as a 3-term hi/lo split (fp32 accumulate): fp32-class accuracy at the
+  // f16 MFMA rate; softmax statistics stay in fp32 registers.
+  f16x8 qhi[4], qlo[4];
   {
     const int iq = q0 + l31;
     const bool qok = iq < a.Tq;
-    const float* qp = a.Q + (size_t)b * a.q_bs + (size_t)(qok ? iq : 0) * a.ldq + hd * 64 + half * 4;
+    const float* qp = a.Q + (size_t)b * a.q_bs + (size_t)(qok ? iq : 0) * a.ldq + hd * 64 + half * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      if (qok) qf[c] = *reinterpret_cast<const f32x4*>(qp + c * 8);
-      else { qf[c][0] = 0.f; qf[c][1] = 0.f; qf[c][2] = 0.f; qf[c][3] = 0.f; }
+    for (int t = 0; t < 4; ++t) {
+      f32x4 x0, x1;
+      if (qok) { x0 = *reinterpret_cast<const f32x4*>(qp + t * 16); x1 = *reinterpret_cast<const f32x4*>(qp + t * 16 + 4); }
+      else { x0[0] = x0[1] = x0[2] = x0[3] = 0.f; x1 = x0; }
+      split8(x0, x1, qhi[t], qlo[t]);
     }
   }
   const int qlen = a.q_len ? a.q_len[b] : a.Tq;
@@ -144,20 +163,25 @@ attn2_kernel(const AttnArgs a, int nqb) {
   const bool use_tau = tau != 1.0f;
   const int iq = q0 + l31;
   const bool qvalid = iq < qlen;
-  // K operand read offsets (bytes) inside a tile: row 32*kh + l31, logical chunk 2c + half
-  int k_rd[8];
+  // K operand read offsets (bytes) inside a tile: row 32*kh + l31, logical 16-byte chunks 4t + 2*half (+1)
+  int k_rd[4][2];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) k_rd[c] = (32 * kh + l31) * 256 + (((2 * c + half) ^ (l31 & 15)) << 4);
+  for (int t = 0; t < 4; ++t) {
+    k_rd[t][0] = (32 * kh + l31) * 256 + (((4 * t + 2 * half) ^ (l31 & 15)) << 4);
+    k_rd[t][1] = (32 * kh + l31) * 256 + (((4 * t + 2 * half + 1) ^ (l31 & 15)) << 4);
+  }
 
   // S^T block of this wave for tile kt: keys kt*64 + 32*kh + frow(r, half), query l31
   auto qk_block = [&](const char* Ks, int kt, f32x16& st) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + k_rd[c]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[c][s], st, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + k_rd[t][0]);
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + k_rd[t][1]);
+      f16x8 khi, klo;
+      split8(k0, k1, khi, klo);
+      st = mfma3(khi, klo, qhi[t], qlo[t], st);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -175,13 +199,25 @@ attn2_kernel(const AttnArgs a, int nqb) {
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+  // O += P.V on the f16 pipe.  k-slot (step t', lane-half g, e) carries key frow(8t'+e, g): P's registers 8t'..8t'+7 are
+  // the A operand as they are; the B operand gathers the matching V rows (two runs of 4 consecutive rows).
   auto pv_block = [&](const char* Vs, const f32x16& p) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* vrow = reinterpret_cast<const float*>(Vs) + (32 * kh + frow(r, half)) * 64 + l31;
-      const float v0 = vrow[0], v1 = vrow[32];
-      O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v0, O[0], 0, 0, 0);
-      O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v1, O[1], 0, 0, 0);
+    for (int tp = 0; tp < 2; ++tp) {
+      f32x4 p0, p1, va0, va1, vb0, vb1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p0[e] = p[8 * tp + e]; p1[e] = p[8 * tp + 4 + e];
+        const float* r0 = reinterpret_cast<const float*>(Vs) + (32 * kh + frow(8 * tp + e, half)) * 64 + l31;
+        const float* r1 = reinterpret_cast<const float*>(Vs) + (32 * kh + frow(8 * tp + 4 + e, half)) * 64 + l31;
+        va0[e] = r0[0]; va1[e] = r1[0]; vb0[e] = r0[32]; vb1[e] = r1[32];
+      }
+      f16x8 phi, plo, vhi, vlo;
+      split8(p0, p1, phi, plo);
+      split8(va0, va1, vhi, vlo);
+      O[0] = mfma3(phi, plo, vhi, vlo, O[0]);
+      split8(vb0, vb1, vhi, vlo);
+      O[1] = mfma3(phi, plo, vhi, vlo, O[1]);
     }
   };
 

@@ -16,6 +16,7 @@ the north star), a `cpu_baseline` (the NumPy oracle, fp32, timed on this box's h
 import argparse
 import json
 import os
+import os
 import sys
 import time
 
@@ -25,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-S1 = dict(B=16, T_text=128, T_mel=800, rf=2)
+S1 = dict(B=int(os.environ.get("VNR_BENCH_B", "16")), T_text=128, T_mel=800, rf=2)   # (VNR_BENCH_B: tuning experiments only)
 ALG_GFLOP_S1 = 343.2           # algorithmic FLOPs of one S1 inference batch
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (no sparsity)

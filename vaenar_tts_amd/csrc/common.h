@@ -59,6 +59,33 @@ struct AttnArgs {
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [wgs][8]
 };
 
+// ---- row-panel chain kernel (gemm3.hip) ---------------------------------------------------------------------------
+constexpr int kMaxChainStages = 20;
+struct ChainStage {
+  const void* w;            // operand-major split image, positioned at this stage's first 32-column block
+  int kt_total;             // k-tiles per column block (block stride = kt_total * 4096 bytes)
+  int kt0, nk;              // first k-tile and number of k-tiles consumed by this stage
+  int n;                    // output columns (<= 256)
+  int a0, a1, asw;          // activation panel a0 for k-tiles [0, asw), a1 for [asw, nk) (re-based to its tile 0)
+  const float* bias;        // [n] or null
+  int act;
+  int res;                  // residual panel index or -1
+  const float* gamma; const float* beta;   // LayerNorm or null
+  int acc_mode;             // 0: plain stage; 1/2/3: FFN second layer over hidden chunks (start / continue / finish+epilogue)
+  float* out; int ldo;      // HBM output [M, n] or null
+  int dst;                  // destination panel or -1
+  float scale;              // 2^-s of the pre-scaled weight image
+};
+struct ChainArgs {
+  const float* in0; int ld0;   // panel 0 <- in0[M, D]
+  const float* in1; int ld1;   // panel 1 <- in1[M, D] (or null)
+  int M, D, nstages;
+  const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded
+  unsigned long long* dbg_ts;   // measurement only: [wgs][64] s_memtime stamps (start, panels, then loop/epilogue per stage)
+  ChainStage st[kMaxChainStages];
+};
+hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);
+
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
 bool gemm2_supported(const GemmArgs& g);          // LDS-DMA ring kernel (gemm2.hip) can take it
 hipError_t launch_gemm2(const GemmArgs& g, hipStream_t s);
@@ -76,6 +103,8 @@ hipError_t launch_coupling_fwd(const float* heads /*[M,2*half]: log_scale | shif
 // Wt [N][K] fp32 -> [N][ceil(K/32)][hi x32 | lo x32] fp16 of (w * scale), zero padded
 hipError_t launch_split_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s);
 hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s);   // *out = max(*out, bits(max|x|))
+// Wt [N][K] fp32 -> operand-major split image [ceil(N/32)][ceil(K/32)][2 steps][hi|lo][64 lanes][8 fp16] (gemm3.hip)
+hipError_t launch_opmajor_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s);
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s);
 hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s);

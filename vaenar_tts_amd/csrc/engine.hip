@@ -89,10 +89,12 @@ struct vnr_context {
   std::vector<XBlk> post_blks;
 
   // split-fp16 weight images (gemm2.hip SPLIT path): one per packed fp32 panel, keyed by the panel's base pointer
-  struct SplitPanel { int N, K; void* img; float acc_scale; };
+  struct SplitPanel { int N, K; void* img; float acc_scale; void* opm; };   // opm: operand-major image (gemm3.hip)
   std::map<const float*, SplitPanel> split_panels;
+  std::map<std::vector<const void*>, float*> chain_prm;   // packed epilogue parameters of a chain program, keyed by its parameter pointers
   std::vector<void*> split_allocs;
   bool split_enabled = true;     // engine option "split_fp16"
+  bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool split_encoder = true;     // engine option "split_encoder": the text encoder uses the split path too (measured as accurate as exact fp32: profiles/r01_split_accuracy.txt)
   bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
@@ -184,6 +186,60 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
                                    " (M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) + " K=" + std::to_string(g.K) + ")");
   return VNR_OK;
 }
+// split image of the fp32 panel rows starting at Wt (row length K): pointer to its first row, k-tiles per row, 2^-s
+struct SplitRef { const void* img = nullptr; int kt_total = 0; float scale = 1.f; const char* opm = nullptr; };
+bool split_lookup(vnr_handle h, const float* Wt, int K, int N, SplitRef& out) {
+  auto it = h->split_panels.upper_bound(Wt);
+  if (it == h->split_panels.begin()) return false;
+  --it;
+  const auto& sp = it->second;
+  const ptrdiff_t off = Wt - it->first;
+  if (off < 0 || off >= (ptrdiff_t)sp.N * sp.K || off % sp.K != 0 || K != sp.K || off / sp.K + N > sp.N) return false;
+  out.kt_total = (sp.K + 31) / 32;
+  out.img = (const char*)sp.img + (size_t)(off / sp.K) * out.kt_total * 128;
+  out.scale = sp.acc_scale;
+  out.opm = ((off / sp.K) % 32 == 0) ? (const char*)sp.opm + (size_t)(off / sp.K / 32) * out.kt_total * 4096 : nullptr;
+  return true;
+}
+struct Tail { const float* wt; int n; const float* bias; float* out; int ldo; };   // extra Dense(D -> n) on the block output
+
+// The chain kernel reads the epilogue parameters (bias | gamma | beta, 256 floats each, per stage) of its whole program
+// as ONE contiguous block: it is assembled once per distinct program (device-to-device copies, stream ordered) and cached.
+int chain_params(vnr_handle h, ChainArgs& g) {
+  std::vector<const void*> key;
+  key.reserve(4 * g.nstages);
+  for (int i = 0; i < g.nstages; ++i) {
+    key.push_back(g.st[i].bias); key.push_back(g.st[i].gamma); key.push_back(g.st[i].beta);
+    key.push_back((const void*)(uintptr_t)(unsigned)(g.st[i].n * 4 + g.st[i].acc_mode));
+  }
+  auto it = h->chain_prm.find(key);
+  if (it == h->chain_prm.end()) {
+    float* d = nullptr;
+    const size_t bytes = (size_t)g.nstages * 768 * sizeof(float);
+    HIP_TRY(h, hipMalloc((void**)&d, bytes));
+    h->split_allocs.push_back(d);
+    HIP_TRY(h, hipMemsetAsync(d, 0, bytes, h->stream));
+    for (int i = 0; i < g.nstages; ++i) {
+      const ChainStage& st = g.st[i];
+      if (st.acc_mode == 1 || st.acc_mode == 2) continue;
+      const float* src[3] = {st.bias, st.gamma, st.beta};
+      for (int a = 0; a < 3; ++a)
+        if (src[a]) HIP_TRY(h, hipMemcpyAsync(d + (size_t)i * 768 + a * 256, src[a], (size_t)st.n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    it = h->chain_prm.emplace(std::move(key), d).first;
+  }
+  g.prm = it->second;
+  return VNR_OK;
+}
+
+int run_chain(vnr_handle h, ChainArgs& g, double flops) {
+  TRY(chain_params(h, g));
+  ProfScope ps(h, CLS_GEMM, flops, 0.0);
+  hipError_t e = launch_panel_chain(g, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("panel chain launch: ") + hipGetErrorString(e));
+  return VNR_OK;
+}
+
 int run_attention(vnr_handle h, const AttnArgs& a, bool cross) {
   const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
                     (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
@@ -355,34 +411,103 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
 // ---- module bodies ----------------------------------------------------------------------------------
 // CrossAttentionBLK.call (attention.py:436-452).  x [M,D] -> out [M,D]; kv = cross K|V panel output
 // [B*Tt, kv_ld] of the memory; ali (optional) [B,H,Tq,Tt].
+// qkv_buf [M,3D]: the fused self-attention Q|K|V of x; when qkv_ready it was already produced by the previous
+// block's chain tail.  tails: extra Dense(D -> n) layers applied to the block OUTPUT inside the same launch (the next
+// block's Q|K|V, the flow heads, the decoder out-projection, the posterior heads).
 int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const float* kv, int kv_ld,
              const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau,
-             float* ali) {
+             float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails) {
   const int M = B * Tq, D = k.D, F = k.F;
-  WS(qkv, (size_t)M * 3 * D); WS(sa, (size_t)M * D); WS(y, (size_t)M * D); WS(q, (size_t)M * D);
-  WS(ca, (size_t)M * D); WS(o, (size_t)M * D); WS(hid, (size_t)M * F);
+  WS(sa, (size_t)M * D); WS(y, (size_t)M * D); WS(q, (size_t)M * D); WS(ca, (size_t)M * D);
   GemmArgs g;
   // self attention: fused Q|K|V projection (no bias, attention.py:154-159)
-  g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.qkv_wt; g.ldw = D; g.C = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D;
-  TRY(run_gemm(h, g));
+  if (!qkv_ready) {
+    g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.qkv_wt; g.ldw = D; g.C = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D;
+    TRY(run_gemm(h, g));
+  }
   AttnArgs a;
   a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.ldk = 3 * D; a.V = qkv + 2 * D; a.ldv = 3 * D;
   a.q_len = q_len; a.k_len = q_len; a.ctx = sa; a.ldo = D; a.ali = nullptr; a.B = B; a.H = heads; a.Tq = Tq; a.Tk = Tq;
   a.causal = 1; a.temperature = tau;
   a.q_bs = (long long)Tq * 3 * D; a.k_bs = a.q_bs; a.v_bs = a.q_bs; a.o_bs = (long long)Tq * D;
   TRY(run_attention(h, a, false));
-  // LN1(att_proj1(concat(x, sa)) + x)
-  g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.A2 = sa; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj1_wt; g.ldw = 2 * D;
-  g.bias = k.proj1_b; g.residual = x; g.ldr = D; g.ln_gamma = k.ln1_g; g.ln_beta = k.ln1_b; g.C = y; g.ldc = D; g.M = M; g.N = D;
-  if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, y, k.ln1_g, k.ln1_b, M, D, y)); }
-  else TRY(run_gemm(h, g));
+
+  // ---- fused row-panel chains (gemm3.hip) when the split images exist and the widths fit one 256-column panel --------
+  SplitRef r_p1, r_q, r_p2, r_f1, r_f2;
+  bool chain = h->split_enabled && h->split_scope && h->chain_enabled && D <= 256 && !(D & 31) && !(F & 31) &&
+               split_lookup(h, k.proj1_wt, 2 * D, D, r_p1) && split_lookup(h, k.q_wt, D, D, r_q) &&
+               split_lookup(h, k.proj2_wt, 2 * D, D, r_p2) && split_lookup(h, k.ffn1_wt, D, F, r_f1) &&
+               split_lookup(h, k.ffn2_wt, F, D, r_f2) && r_p1.opm && r_q.opm && r_p2.opm && r_f1.opm && r_f2.opm;
+  std::vector<SplitRef> r_t(tails.size());
+  int tail_stages = 0;
+  for (size_t i = 0; chain && i < tails.size(); ++i) {
+    chain = split_lookup(h, tails[i].wt, D, tails[i].n, r_t[i]) && r_t[i].opm && !(tails[i].n & 3) && !(tails[i].ldo & 3);
+    tail_stages += (tails[i].n + 255) / 256;
+  }
+  const int PT = D / 32, nchunks = (F + 255) / 256;
+  if (chain && 1 + 2 * nchunks + tail_stages > kMaxChainStages) chain = false;
+
+  if (chain) {
+    // chain B: y = LN1(att_proj1(concat(x, sa)) + x) ; q = y . Wq
+    ChainArgs c; memset(&c, 0, sizeof(c));
+    c.in0 = x; c.ld0 = D; c.in1 = sa; c.ld1 = D; c.M = M; c.D = D; c.nstages = 2;
+    ChainStage& s0 = c.st[0];
+    s0.w = r_p1.opm; s0.kt_total = r_p1.kt_total; s0.kt0 = 0; s0.nk = 2 * PT; s0.n = D; s0.a0 = 0; s0.a1 = 1; s0.asw = PT; s0.bias = k.proj1_b;
+    s0.act = ACT_IDENTITY; s0.res = 0; s0.gamma = k.ln1_g; s0.beta = k.ln1_b; s0.acc_mode = 0; s0.out = y; s0.ldo = D; s0.dst = 0; s0.scale = r_p1.scale;
+    ChainStage& s1 = c.st[1];
+    s1.w = r_q.opm; s1.kt_total = r_q.kt_total; s1.kt0 = 0; s1.nk = PT; s1.n = D; s1.a0 = 0; s1.a1 = 0; s1.asw = PT; s1.bias = nullptr; s1.act = ACT_IDENTITY;
+    s1.res = -1; s1.gamma = nullptr; s1.beta = nullptr; s1.acc_mode = 0; s1.out = q; s1.ldo = D; s1.dst = -1; s1.scale = r_q.scale;
+    TRY(run_chain(h, c, 2.0 * M * D * (2.0 * D + D)));
+  } else {
+    g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.A2 = sa; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj1_wt; g.ldw = 2 * D;
+    g.bias = k.proj1_b; g.residual = x; g.ldr = D; g.ln_gamma = k.ln1_g; g.ln_beta = k.ln1_b; g.C = y; g.ldc = D; g.M = M; g.N = D;
+    if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, y, k.ln1_g, k.ln1_b, M, D, y)); }
+    else TRY(run_gemm(h, g));
+    g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.q_wt; g.ldw = D; g.C = q; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+  }
   // cross attention
-  g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.q_wt; g.ldw = D; g.C = q; g.ldc = D; g.M = M; g.N = D;
-  TRY(run_gemm(h, g));
   a.Q = q; a.ldq = D; a.K = kv + k.kv_col; a.ldk = kv_ld; a.V = kv + k.kv_col + D; a.ldv = kv_ld;
   a.q_len = q_len; a.k_len = m_len; a.ctx = ca; a.ldo = D; a.ali = ali; a.Tq = Tq; a.Tk = Tt; a.causal = 0;
   a.q_bs = (long long)Tq * D; a.k_bs = (long long)Tt * kv_ld; a.v_bs = a.k_bs; a.o_bs = (long long)Tq * D;
   TRY(run_attention(h, a, true));
+
+  if (chain) {
+    // chain C: o = LN2(att_proj2(concat(y, ca)) + y) ; out = LN(dense2(relu(dense1(o))) + o) ; tails on out
+    ChainArgs c; memset(&c, 0, sizeof(c));
+    c.in0 = y; c.ld0 = D; c.in1 = ca; c.ld1 = D; c.M = M; c.D = D;
+    int n = 0;
+    ChainStage* s = &c.st[n++];
+    s->w = r_p2.opm; s->kt_total = r_p2.kt_total; s->kt0 = 0; s->nk = 2 * PT; s->n = D; s->a0 = 0; s->a1 = 1; s->asw = PT; s->bias = k.proj2_b; s->act = ACT_IDENTITY;
+    s->res = 0; s->gamma = k.ln2_g; s->beta = k.ln2_b; s->acc_mode = 0; s->out = nullptr; s->ldo = 0; s->dst = 0; s->scale = r_p2.scale;
+    for (int ch = 0; ch < nchunks; ++ch) {                 // hidden columns [256*ch, 256*ch + w)
+      const int c0 = ch * 256, w = (F - c0 < 256) ? F - c0 : 256;
+      s = &c.st[n++];                                      // h_ch = relu(o . W1[:, chunk] + b1[chunk])  -> panel 1
+      s->w = r_f1.opm + (size_t)(c0 / 32) * r_f1.kt_total * 4096; s->kt_total = r_f1.kt_total; s->kt0 = 0; s->nk = PT; s->n = w;
+      s->a0 = 0; s->a1 = 0; s->asw = PT; s->bias = k.ffn1_b + c0; s->act = ACT_RELU; s->res = -1; s->gamma = nullptr; s->beta = nullptr; s->acc_mode = 0;
+      s->out = nullptr; s->ldo = 0; s->dst = 1; s->scale = r_f1.scale;
+      s = &c.st[n++];                                      // acc += h_ch . W2[chunk, :]
+      const bool last = ch == nchunks - 1;
+      s->w = r_f2.opm; s->kt_total = r_f2.kt_total; s->kt0 = c0 / 32; s->nk = w / 32; s->n = D; s->a0 = 1; s->a1 = 1; s->asw = w / 32;
+      s->bias = last ? k.ffn2_b : nullptr; s->act = ACT_IDENTITY; s->res = last ? 0 : -1; s->gamma = last ? k.ffn_g : nullptr; s->beta = last ? k.ffn_b : nullptr;
+      s->acc_mode = nchunks == 1 ? 0 : (ch == 0 ? 1 : (last ? 3 : 2));
+      s->out = last ? out : nullptr; s->ldo = D; s->dst = last ? 0 : -1; s->scale = r_f2.scale;
+    }
+    double fl = 2.0 * M * D * (2.0 * D) + 4.0 * M * (double)D * F;
+    for (size_t i = 0; i < tails.size(); ++i)
+      for (int c0 = 0; c0 < tails[i].n; c0 += 256) {
+        const int w = (tails[i].n - c0 < 256) ? tails[i].n - c0 : 256;
+        s = &c.st[n++];
+        s->w = r_t[i].opm + (size_t)(c0 / 32) * r_t[i].kt_total * 4096; s->kt_total = r_t[i].kt_total; s->kt0 = 0; s->nk = PT; s->n = w;
+        s->a0 = 0; s->a1 = 0; s->asw = PT; s->bias = tails[i].bias ? tails[i].bias + c0 : nullptr; s->act = ACT_IDENTITY; s->res = -1; s->gamma = nullptr; s->beta = nullptr;
+        s->acc_mode = 0; s->out = tails[i].out + c0; s->ldo = tails[i].ldo; s->dst = -1; s->scale = r_t[i].scale;
+        fl += 2.0 * M * D * (double)w;
+      }
+    c.nstages = n;
+    TRY(run_chain(h, c, fl));
+    return VNR_OK;
+  }
+  WS(o, (size_t)M * D); WS(hid, (size_t)M * F);
   // LN2(att_proj2(concat(y, ca)) + y)
   g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.A2 = ca; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj2_wt; g.ldw = 2 * D;
   g.bias = k.proj2_b; g.residual = y; g.ldr = D; g.ln_gamma = k.ln2_g; g.ln_beta = k.ln2_b; g.C = o; g.ldc = D; g.M = M; g.N = D;
@@ -396,6 +521,35 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   g.ln_gamma = k.ffn_g; g.ln_beta = k.ffn_b; g.C = out; g.ldc = D; g.M = M; g.N = D;
   if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, out, k.ffn_g, k.ffn_b, M, D, out)); }
   else TRY(run_gemm(h, g));
+  for (const Tail& t : tails) {      // unfused tails
+    g = GemmArgs(); g.A1 = out; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = t.wt; g.ldw = D; g.bias = t.bias; g.C = t.out; g.ldc = t.ldo; g.M = M; g.N = t.n;
+    TRY(run_gemm(h, g));
+  }
+  return VNR_OK;
+}
+
+// a stack of CrossAttentionBLKs (transform.py:53-56, decoder.py:188-192, posterior.py:124-127): block i's chain produces block
+// i+1's Q|K|V; `tails` are applied to the last block's output.  Returns the buffer holding the stack output.
+int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb, const float* kv, int kv_ld,
+               const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau, float* ali_base,
+               size_t ali_stride, const std::vector<Tail>& tails, float** result) {
+  const int M = B * Tq;
+  float* xc = xa; float* xn = xb;
+  if (blks.empty()) { *result = xc; return VNR_OK; }
+  const int D = blks[0].D;
+  WS(qkv0, (size_t)M * 3 * D); WS(qkv1, (size_t)M * 3 * D);
+  float* qc = qkv0; float* qn = qkv1;
+  bool ready = false;
+  for (size_t b = 0; b < blks.size(); ++b) {
+    std::vector<Tail> t;
+    if (b + 1 < blks.size()) t.push_back({blks[b + 1].qkv_wt, 3 * D, nullptr, qn, 3 * D});
+    else t = tails;
+    TRY(run_xblk(h, blks[b], xc, xn, kv, kv_ld, q_len, m_len, B, Tq, Tt, heads, tau,
+                 ali_base ? ali_base + b * ali_stride : nullptr, qc, ready, t));
+    ready = b + 1 < blks.size();      // (also true on the unfused path: the tails loop computed it)
+    std::swap(xc, xn); std::swap(qc, qn);
+  }
+  *result = xc;
   return VNR_OK;
 }
 
@@ -503,15 +657,14 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
     g = GemmArgs(); g.A1 = dst + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
     g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
     TRY(run_gemm(h, g));
-    float* xc = xa; float* xn = xb;
-    for (size_t b = 0; b < f.blks.size(); ++b) {
-      TRY(run_xblk(h, f.blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads,
-                   c.prior_temperature, nullptr));
-      std::swap(xc, xn);
+    float* xc = nullptr;        // the log_scale | shift heads ride on the last block's chain (tail)
+    TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc));
+    if (f.blks.empty()) {
+      g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
+      g.C = heads; g.ldc = C; g.M = M; g.N = C;
+      TRY(run_gemm(h, g));
     }
-    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
-    g.C = heads; g.ldc = C; g.M = M; g.N = C;
-    TRY(run_gemm(h, g));
     RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, logprobs ? rowld : nullptr, h->stream));
     if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));
     zc = dst;
@@ -531,20 +684,19 @@ int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const
   GemmArgs g;
   g.A1 = z; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = h->dec_pre_wt; g.ldw = C; g.bias = h->dec_pre_b; g.C = xa; g.ldc = D; g.M = M; g.N = D;
   TRY(run_gemm(h, g));
-  float* xc = xa; float* xn = xb;
   const size_t ali_sz = (size_t)B * c.dec_attention_heads * Tz * Tt;
-  for (size_t b = 0; b < h->dec_blks.size(); ++b) {
-    TRY(run_xblk(h, h->dec_blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.dec_attention_heads,
-                 c.dec_attention_temperature, alignments ? alignments + b * ali_sz : nullptr));
-    std::swap(xc, xn);
-  }
   // out_projection[:, :, :rf*out_dim] -> reshape [B, Tz*rf, out_dim] (decoder.py:193-195): only the live
-  // columns are computed; the [M, rf*od] result IS the reshaped tensor.
+  // columns are computed; the [M, rf*od] result IS the reshaped tensor.  It rides on the last block's chain.
   float* init = initial;
   if (!init) { WS(tmp, (size_t)M * rf * od); init = tmp; }
-  g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->dec_out_wt; g.ldw = D; g.bias = h->dec_out_b;
-  g.C = init; g.ldc = rf * od; g.M = M; g.N = rf * od;
-  TRY(run_gemm(h, g));
+  float* xc = nullptr;
+  TRY(run_xstack(h, h->dec_blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.dec_attention_heads, c.dec_attention_temperature,
+                 alignments, ali_sz, {Tail{h->dec_out_wt, rf * od, h->dec_out_b, init, rf * od}}, &xc));
+  if (h->dec_blks.empty()) {
+    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->dec_out_wt; g.ldw = D; g.bias = h->dec_out_b;
+    g.C = init; g.ldc = rf * od; g.M = M; g.N = rf * od;
+    TRY(run_gemm(h, g));
+  }
   const int Tm = Tz * rf, Mm = B * Tm, Fp = c.dec_post_conv_filters;
   WS(pa, (size_t)Mm * Fp); WS(pb, (size_t)Mm * Fp);
   const float* cur = init; float* nxt = pa;
@@ -574,17 +726,16 @@ int posterior_body(vnr_handle h, const float* mels, const float* kv, int kv_ld, 
   g = GemmArgs(); g.A1 = xa; g.lda1 = P; g.K1 = P; g.K = P; g.Wt = h->post_d2_wt; g.ldw = P; g.bias = h->post_d2_b; g.act = c.post_pre_activation;
   g.pe = pe; g.pe_T = Tz; g.pe_w = h->post_pos_weight; g.C = xb; g.ldc = P; g.M = M; g.N = P;
   TRY(run_gemm(h, g));               // + pos_weight * PE (posterior.py:120-121)
-  float* xc = xb; float* xn = xa;
-  for (size_t b = 0; b < h->post_blks.size(); ++b) {
-    TRY(run_xblk(h, h->post_blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.post_attention_heads,
-                 c.post_temperature, nullptr));
-    std::swap(xc, xn);
-  }
   const int D = c.post_attention_dim;
-  g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->post_mu_wt; g.ldw = D; g.bias = h->post_mu_b; g.C = mu; g.ldc = C; g.M = M; g.N = C;
-  TRY(run_gemm(h, g));
-  g.Wt = h->post_lv_wt; g.bias = h->post_lv_b; g.C = logvar;
-  TRY(run_gemm(h, g));
+  float* xc = nullptr;
+  TRY(run_xstack(h, h->post_blks, xb, xa, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.post_attention_heads, c.post_temperature,
+                 nullptr, 0, {Tail{h->post_mu_wt, C, h->post_mu_b, mu, C}, Tail{h->post_lv_wt, C, h->post_lv_b, logvar, C}}, &xc));
+  if (h->post_blks.empty()) {
+    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->post_mu_wt; g.ldw = D; g.bias = h->post_mu_b; g.C = mu; g.ldc = C; g.M = M; g.N = C;
+    TRY(run_gemm(h, g));
+    g.Wt = h->post_lv_wt; g.bias = h->post_lv_b; g.C = logvar;
+    TRY(run_gemm(h, g));
+  }
   return VNR_OK;
 }
 
@@ -606,13 +757,13 @@ int prior_logprob_body(vnr_handle h, float* z, const int32_t* z_len, const int32
     g.A1 = zc + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
     g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
     TRY(run_gemm(h, g));
-    float* xc = xa; float* xn = xb;
-    for (size_t b = 0; b < f.blks.size(); ++b) {
-      TRY(run_xblk(h, f.blks[b], xc, xn, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature, nullptr));
-      std::swap(xc, xn);
+    float* xc = nullptr;
+    TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc));
+    if (f.blks.empty()) {
+      g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b; g.C = heads; g.ldc = C; g.M = M; g.N = C;
+      TRY(run_gemm(h, g));
     }
-    g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b; g.C = heads; g.ldc = C; g.M = M; g.N = C;
-    TRY(run_gemm(h, g));
     RUN_MISC(h, launch_coupling_bwd(heads, zc, M, half, zp_off, rowld, h->stream));
     RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));    // logdet = -sum log(scale)
     g = GemmArgs(); g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = f.inv_wt; g.ldw = C; g.bias = f.inv_b; g.C = zn; g.ldc = C; g.M = M; g.N = C;
@@ -785,7 +936,7 @@ int vnr_finalize_weights(vnr_handle h) {
   for (auto p : h->packed_allocs) hipFree(p);
   h->packed_allocs.clear();
   for (auto p : h->split_allocs) hipFree(p);
-  h->split_allocs.clear(); h->split_panels.clear(); h->panel_registry.clear();
+  h->split_allocs.clear(); h->split_panels.clear(); h->panel_registry.clear(); h->chain_prm.clear();
   h->enc_convs.clear(); h->post_convs.clear(); h->enc_blks.clear(); h->flow.clear(); h->dec_blks.clear(); h->post_blks.clear();
   const vnr_config& c = h->cfg;
   Packer P{h};
@@ -943,7 +1094,11 @@ int vnr_finalize_weights(vnr_handle h) {
       HIP_TRY(h, hipMalloc(&img, (size_t)N * ((K + 31) / 32) * 128));
       h->split_allocs.push_back(img);
       HIP_TRY(h, launch_split_weights(e.first, N, K, (float)ldexp(1.0, sexp), img, h->stream));
-      h->split_panels[e.first] = {N, K, img, (float)ldexp(1.0, -sexp)};
+      void* opm = nullptr;
+      HIP_TRY(h, hipMalloc(&opm, (size_t)((N + 31) / 32) * ((K + 31) / 32) * 4096));
+      h->split_allocs.push_back(opm);
+      HIP_TRY(h, launch_opmajor_weights(e.first, N, K, (float)ldexp(1.0, sexp), opm, h->stream));
+      h->split_panels[e.first] = {N, K, img, (float)ldexp(1.0, -sexp), opm};
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
@@ -1162,6 +1317,7 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* 
 int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!h || !name) return fail(h, VNR_ERR_ARG, "null argument");
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);

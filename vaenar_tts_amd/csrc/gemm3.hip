@@ -1,0 +1,326 @@
+// Row-panel chain kernel (gfx950, split-fp16 MFMA): a workgroup owns 32 activation rows and runs a short PROGRAM of
+// dense stages on them without leaving the CU.  Replaces chains of the reference's per-row ops inside
+// CrossAttentionBLK (modules/attention.py:440-452) and FFN (modules/utils.py:48-53):
+//     LN(att_proj(concat(x, ctx)) + x)  ->  query projection                                   (2 stages)
+//     LN(att_proj(concat(y, ctx)) + y)  ->  FFN dense1+relu -> dense2 + residual -> LN  ->  next Q|K|V / flow heads
+// Only weights are streamed (each wave owns 32 output columns and prefetches exactly its own weight operands into
+// registers, 4 k-tiles deep, from an operand-major image: no LDS, no workgroup barrier inside a stage); activations stay
+// in two LDS panels [32][<=256] kept in the
+// split form the f16 matrix pipe consumes (per 32-k tile: 32 x fp16 hi | 32 x fp16 lo), so every product is the
+// 3-term hi/lo split with fp32 accumulation (fp32-class accuracy, see gemm2.hip).  FFN hidden activations never
+// touch HBM: the hidden layer is produced and consumed in chunks of <= 256 columns.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace vnr {
+
+namespace {
+constexpr unsigned kOob3 = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds3_t;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PANEL_BYTES = 32 * 1024;          // 32 rows x 8 k-tiles x 128 B
+constexpr int P_OFF = 2048;                     // [0, 2 KB): LayerNorm exchange scratch [2][32][8]
+constexpr int PRM_OFF = P_OFF + 2 * PANEL_BYTES;     // epilogue parameters [kMaxChainStages][3][256] fp32
+constexpr int CHAIN_LDS = PRM_OFF + kMaxChainStages * 768 * 4;
+constexpr int PF = 4;                           // weight k-tiles kept in flight per wave (register prefetch depth)
+
+__device__ __forceinline__ float act3(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+// workgroup barrier that orders LDS traffic only: global stores stay in flight (a __syncthreads() would drain vmcnt
+// and expose the full store latency at every stage boundary)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// byte offset of 16-byte chunk `c` (0..7) of k-tile `kt` in row `r` of a panel (chunk index XOR-swizzled by row)
+__device__ __forceinline__ int panel_off(int r, int kt, int c) { return r * 1024 + ((((kt << 3) + c) ^ (r & 15)) << 4); }
+}  // namespace
+
+__global__ void __launch_bounds__(512)
+panel_chain_kernel(const ChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * 32;
+  auto panel_ptr = [&](int i) -> char* { return smem + P_OFF + i * PANEL_BYTES; };
+  float* scratch = reinterpret_cast<float*>(smem);
+  float* prm = reinterpret_cast<float*>(smem + PRM_OFF);       // [stage][bias | gamma | beta][256]
+  unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 64 : nullptr;
+  auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
+  auto wstamp = [&](int si, int i) { if (ts && si == 1 && lane == 0) ts[32 + wave * 4 + i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // ---- the weight stream --------------------------------------------------------------------------------------------
+  // Every stage's weights sit in an operand-major image: block (column block, k-tile) = 4 x 1 KiB pieces, piece
+  // i = 2*t + part (t = k16 step, part 0 = hi / 1 = lo); lane l reads bytes [16 l, 16 l + 16) of a piece, i.e. exactly
+  // its MFMA operand slot, so every wave instruction is one fully coalesced 1 KiB read straight into registers.
+  // The k-tiles of ALL stages form one flat sequence per wave; PF tiles are always in flight and slot u is refilled
+  // right after the MFMAs that consumed it -- across stage boundaries too.  Every refill is issued unconditionally
+  // (tiles a wave does not need, the padding of a stage to a multiple of PF, and the tail after the last stage use an
+  // out-of-range buffer offset: no memory traffic, zeros returned), so the number of loads between a refill and its use
+  // is a compile-time constant and the compiler's s_waitcnt is vmcnt(4*(PF-1)), never a full drain.
+  h16x8 wreg[PF][4];
+  int fs = 0, fk = 0, fnk = 0, fpad = 0;
+  unsigned fvoff = kOob3;
+  __amdgpu_buffer_rsrc_t frs;
+  auto open_stage = [&](int s_) {
+    const ChainStage& st = g.st[s_];
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(st.w), 0, 0x40000000, 0x00020000);
+    fnk = st.nk;
+    fpad = (st.nk + PF - 1) / PF * PF;
+    fvoff = (32 * wave < st.n) ? (unsigned)((wave * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
+  };
+  auto fetch = [&](int u) {
+    const unsigned vo = (fk < fnk) ? fvoff : kOob3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      wreg[u][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, fk * 4096 + i * 1024, 0));
+    if (++fk == fpad) {
+      fk = 0;
+      if (fs + 1 < g.nstages) { ++fs; open_stage(fs); } else { fnk = 0; }      // past the end: dummy (out-of-range) refills
+    }
+  };
+  open_stage(0);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) fetch(u);
+
+  // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (one contiguous block, no registers; read back with
+  //      ds_read at the epilogues, so no vector-memory wait is ever needed there)
+  {
+    const int chunks = g.nstages * 768 / 4;                          // 16-byte chunks; 64 per wave instruction
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)chunks * 16u, 0x00020000);
+    for (int c0 = wave * 64; c0 < chunks; c0 += 512)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + c0 * 16), 16, (unsigned)(c0 + lane) * 16u, 0, 0, 0);
+  }
+  // ---- input panels (fp32 rows in HBM -> split fp16 panel): all reads issued first, rows beyond M read as zeros --------
+  {
+    const int q4 = g.D >> 2;                                       // float4 per row (<= 64)
+    float4 x[2][4];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const float* src = pi == 0 ? g.in0 : g.in1;
+      const int ld = pi == 0 ? g.ld0 : g.ld1;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int e = tid + 512 * it, r = e / q4, j = e - r * q4;
+        x[pi][it] = (src && r < 32 && m0 + r < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + 4 * j)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      if (!(pi == 0 ? g.in0 : g.in1)) continue;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int e = tid + 512 * it, r = e / q4, j = e - r * q4;
+        if (r >= 32) continue;
+        const int kt = j >> 3, p = (j & 7) * 4;                    // position inside the 32-k tile
+        h16x4 hi, lo;
+        const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const _Float16 h = (_Float16)xv[q]; hi[q] = h; lo[q] = (_Float16)(xv[q] - (float)h); }
+        *reinterpret_cast<h16x4*>(panel_ptr(pi) + panel_off(r, kt, p >> 3) + (p & 4) * 2) = hi;
+        *reinterpret_cast<h16x4*>(panel_ptr(pi) + panel_off(r, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // parameter DMA landed (the head weight tiles too: issued first)
+  lds_barrier();
+  stamp(1);
+
+  f32x16 accF;                                          // persistent accumulator of the FFN second layer
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accF[r] = 0.f;
+
+#pragma unroll 1
+  for (int si = 0; si < g.nstages; ++si) {
+    const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
+    const bool wave_on = 32 * wave < st.n;               // this wave owns output columns 32w .. 32w+31
+    const char* const Ap0 = panel_ptr(st.a0);
+    const char* const Ap1 = panel_ptr(st.a1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    wstamp(si, 0);
+    const int npad = (st.nk + PF - 1) / PF * PF;
+#pragma unroll 1
+    for (int kb = 0; kb < npad; kb += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int kt = kb + u;
+        if (wave_on && kt < st.nk) {
+          const char* Ap = (kt < st.asw) ? Ap0 : Ap1;
+          const int akt = (kt < st.asw) ? kt : kt - st.asw;
+          h16x8 ah[2], al[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            ah[t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 2 * t + half));
+            al[t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 4 + 2 * t + half));
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {                                   // D^T: lane <-> activation row
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], ah[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], al[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], ah[t], acc, 0, 0, 0);
+          }
+        }
+        fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)
+      }
+    }
+    stamp(2 + 2 * si);
+    wstamp(si, 1);
+    // ---- FFN second layer: accumulate over hidden chunks (modes 1,2: no epilogue yet) ----------------------------------
+    if (st.acc_mode == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accF[r] = acc[r];
+    } else if (st.acc_mode >= 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accF[r] += acc[r];
+    }
+    if (st.acc_mode == 1 || st.acc_mode == 2) { lds_barrier(); stamp(3 + 2 * si); continue; }   // the hidden panel may be rewritten next
+    if (st.acc_mode == 3) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = accF[r];
+    }
+
+    // ---- epilogue: v = act(acc*scale + bias) (+ residual panel) ; optional LayerNorm over the row ------------------------
+    // lane (row l31, half) holds columns n = 32*wave + 8q + 4*half + e  (register 4q + e)
+    float v[16];
+    const int row = m0 + l31;
+    const float* sp = prm + si * 768;
+    bool cok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * wave + 8 * q + 4 * half;
+      cok[q] = wave_on && col < st.n;                                   // (n is a multiple of 4)
+      const float4 bi = *reinterpret_cast<const float4*>(sp + col);
+      v[4 * q + 0] = acc[4 * q + 0] * st.scale + bi.x;
+      v[4 * q + 1] = acc[4 * q + 1] * st.scale + bi.y;
+      v[4 * q + 2] = acc[4 * q + 2] * st.scale + bi.z;
+      v[4 * q + 3] = acc[4 * q + 3] * st.scale + bi.w;
+    }
+    if (st.act == ACT_RELU) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+    } else if (st.act == ACT_TANH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+    }
+    if (st.res >= 0) {                                                  // residual = hi + lo of the panel entry (22 bits)
+      const char* Rp = panel_ptr(st.res);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * wave + 8 * q + 4 * half, kt = col >> 5, p = col & 31;
+        const h16x4 rh = *reinterpret_cast<const h16x4*>(Rp + panel_off(l31, kt, p >> 3) + (p & 4) * 2);
+        const h16x4 rl = *reinterpret_cast<const h16x4*>(Rp + panel_off(l31, kt, 4 + (p >> 3)) + (p & 4) * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)rh[e] + (float)rl[e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!cok[q]) v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0.f;
+    if (st.gamma) {                                                      // LayerNormalization (eps 1e-3), two-pass statistics
+      float s1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s1 += v[r];
+      s1 += __shfl_xor(s1, 32, 64);
+      if (half == 0) scratch[l31 * 8 + wave] = s1;
+      lds_barrier();
+      float mean = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) mean += scratch[l31 * 8 + w];
+      mean *= 1.f / (float)st.n;
+      float s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = cok[q] ? v[4 * q + e] - mean : 0.f;
+          s2 += d * d;
+        }
+      s2 += __shfl_xor(s2, 32, 64);
+      if (half == 0) scratch[256 + l31 * 8 + wave] = s2;
+      lds_barrier();
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) var += scratch[256 + l31 * 8 + w];
+      const float rstd = 1.0f / sqrtf(var * (1.f / (float)st.n) + kLnEps);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * wave + 8 * q + 4 * half;
+        const float4 ga = *reinterpret_cast<const float4*>(sp + 256 + col), be = *reinterpret_cast<const float4*>(sp + 512 + col);
+        v[4 * q + 0] = (v[4 * q + 0] - mean) * rstd * ga.x + be.x;
+        v[4 * q + 1] = (v[4 * q + 1] - mean) * rstd * ga.y + be.y;
+        v[4 * q + 2] = (v[4 * q + 2] - mean) * rstd * ga.z + be.z;
+        v[4 * q + 3] = (v[4 * q + 3] - mean) * rstd * ga.w + be.w;
+      }
+    } else if (st.dst >= 0 && (st.dst == st.a0 || (st.asw < st.nk && st.dst == st.a1))) {
+      lds_barrier();                                                  // in-place stage: every wave is done reading the source panel
+    }
+    wstamp(si, 2);
+    // ---- outputs: HBM (fp32, 16-byte row pieces) and/or destination panel (split fp16) -----------------------------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = 32 * wave + 8 * q + 4 * half;
+      if (!cok[q]) continue;
+      if (st.out && row < g.M)
+        *reinterpret_cast<float4*>(st.out + (size_t)row * st.ldo + col) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      if (st.dst >= 0) {
+        h16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[4 * q + e]; hi[e] = h; lo[e] = (_Float16)(v[4 * q + e] - (float)h); }
+        const int kt = col >> 5, p = col & 31;
+        *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(l31, kt, p >> 3) + (p & 4) * 2) = hi;
+        *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(l31, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
+      }
+    }
+    lds_barrier();                                                    // panels are complete / free before the next stage
+    stamp(3 + 2 * si);
+    wstamp(si, 3);
+  }
+}
+
+hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
+  if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
+  for (int i = 0; i < g.nstages; ++i) {
+    const ChainStage& st = g.st[i];
+    if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
+    if (st.out && (st.ldo & 3)) return hipErrorInvalidValue;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)panel_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS);
+    attr_set = true;
+  }
+  static const char* ts_path = getenv("VNR_CHAIN_TS");
+  if (ts_path) {
+    ChainArgs gg = g;
+    const size_t n = (size_t)((g.M + 31) / 32) * 64;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemset(d, 0, n * 8);
+    gg.dbg_ts = d;
+    hipLaunchKernelGGL(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, gg);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hbuf(n);
+    (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FILE* f = fopen(ts_path, "ab");
+    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 64)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, g);
+  return hipGetLastError();
+}
+
+}  // namespace vnr

@@ -289,6 +289,30 @@ hipError_t launch_split_weights(const float* Wt, int N, int K, float scale, void
   return hipGetLastError();
 }
 
+// ---- operand-major split image for the row-panel chain kernel (gemm3.hip) ------------------------------------------------------
+// out[((nb*KT + kt)*4 + 2*t + part)*512 + lane*8 + e] = part(w[32 nb + (lane&31)][32 kt + 16 t + 8 (lane>>5) + e] * scale)
+__global__ void opmajor_weights_kernel(const float* __restrict__ Wt, int N, int K, float scale, _Float16* __restrict__ out) {
+  const int KT = (K + 31) >> 5, NB = (N + 31) >> 5;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (nb, kt, t, lane)
+  if (idx >= (size_t)NB * KT * 2 * 64) return;
+  const int lane = idx & 63, t = (idx >> 6) & 1;
+  const size_t blk = idx >> 7; const int kt = blk % KT; const size_t nb = blk / KT;
+  const int n = (int)nb * 32 + (lane & 31), k0 = kt * 32 + 16 * t + 8 * (lane >> 5);
+  _Float16* hi = out + ((blk * 4 + 2 * t) * 512) + lane * 8;
+  _Float16* lo = hi + 512;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float w = (n < N && k0 + e < K) ? Wt[(size_t)n * K + k0 + e] * scale : 0.f;
+    const _Float16 h = (_Float16)w;
+    hi[e] = h; lo[e] = (_Float16)(w - (float)h);
+  }
+}
+hipError_t launch_opmajor_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s) {
+  const size_t n = (size_t)((N + 31) / 32) * ((K + 31) / 32) * 128;
+  hipLaunchKernelGGL(opmajor_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
+  return hipGetLastError();
+}
+
 // ---- tf.keras.layers.Embedding (encoder.py:81): out[r, :] = table[ids[r], :]; one wave per row, float4 lanes ------
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, int rows, int dim,

@@ -32,14 +32,16 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ int frow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 // exp(x) for x <= 0 on the hardware exp2 unit (v_exp_f32, ~1 ulp): t = x*log2(e) is rounded, the rounding error
 // and the low part of log2(e) are folded back to first order: exp(x) = 2^t * (1 + ln2 * e).  Relative error
-// ~2e-7 for |x| < 100; exp(-inf) = 0, large negative arguments flush to 0 like expf.
+// ~2e-7 for |x| < 87; below -87 (result < 1.7e-38, i.e. denormal against a softmax denominator >= 1) the result
+// is flushed to 0 -- branch free: the softmax calls this 32 times per lane and a divergent fallback costs more
+// than the exponentials.
 __device__ __forceinline__ float fast_exp(float x) {
   const float L2E = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
   const float t = x * L2E;
   float e = __builtin_fmaf(x, L2E, -t);
   e = __builtin_fmaf(x, L2E_LO, e);
   const float r = __builtin_amdgcn_exp2f(t);
-  return (x < -87.0f) ? ((x < -104.0f) ? 0.0f : expf(x)) : __builtin_fmaf(r, e * LN2, r);
+  return (x < -87.0f) ? 0.0f : __builtin_fmaf(r, e * LN2, r);
 }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
@@ -183,15 +185,23 @@ attn2_kernel(const AttnArgs a, int nqb) {
       split8(k0, k1, khi, klo);
       st = mfma3(khi, klo, qhi[t], qlo[t], st);
     }
+    const int j0 = kt * KT + 32 * kh;                 // first key of this wave's block
+    // wave-uniform fast path: every (query, key) of the block is valid and unmasked -> scale only
+    const bool plain = (!a.causal || j0 + 31 <= q0) && !use_tau && j0 + 32 <= klen && j0 + 32 <= a.Tk && q0 + 32 <= qlen;
+    if (plain) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = kt * KT + 32 * kh + frow(r, half);
-      float s = st[r] * 0.125f;                       // / sqrt(64), exact
-      if (use_tau) s = s / tau;
-      const bool ok = qvalid && (j < klen) && (!a.causal || j <= iq);
-      s = ok ? s : kMaskFill;                         // attention.py:240
-      if (j >= a.Tk) s = -INFINITY;                   // key does not exist
-      st[r] = s;
+      for (int r = 0; r < 16; ++r) st[r] *= 0.125f;   // / sqrt(64), exact
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + frow(r, half);
+        float s = st[r] * 0.125f;
+        if (use_tau) s = s / tau;
+        const bool ok = qvalid && (j < klen) && (!a.causal || j <= iq);
+        s = ok ? s : kMaskFill;                       // attention.py:240
+        if (j >= a.Tk) s = -INFINITY;                 // key does not exist
+        st[r] = s;
+      }
     }
   };
   f32x16 O[2];
@@ -298,8 +308,11 @@ attn2_kernel(const AttnArgs a, int nqb) {
     if (half == 0) xch[128 + wave * 32 + l31] = ps;
     __syncthreads();
     l_run = ps + xch[128 + (wave ^ 2) * 32 + l31];
+    {
+      const float linv = 1.0f / l_run;                // softmax, attention.py:242 (one true division per row, then products)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st0[r] = st0[r] / l_run; st1[r] = st1[r] / l_run; }   // softmax, attention.py:242
+      for (int r = 0; r < 16; ++r) { st0[r] *= linv; st1[r] *= linv; }
+    }
     if (wave_active) {
       // alignment rows: transpose each 32x32 block through LDS, store 128-byte row pieces with 16-byte lanes
       float* Pw = scratch + wave * 1024;              // [32 queries][32 keys], XOR-swizzled columns
@@ -318,7 +331,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
           const int qrow = q0 + rr, key = t * KT + 32 * kh + 4 * kc;
           if (qrow < a.Tq) {
             float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
-            if (key + 3 < a.Tk && !(a.Tk & 3)) *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            if (key + 3 < a.Tk && !(a.Tk & 3)) { f32x4 o4 = {v4[0], v4[1], v4[2], v4[3]}; __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(dst)); }
             else
 #pragma unroll
               for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
@@ -363,7 +376,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
       const float fa = __shfl(sa * linv, src, 64), fb = __shfl(sb * linv, src, 64);
       const float o = O[nb][r] * fa + mg[pw * 1024 + r * 64 + lane] * fb;
       const int row = q0 + src;
-      if (row < a.Tq) ob[(size_t)row * a.ldo] = o;
+      if (row < a.Tq) __builtin_nontemporal_store(o, ob + (size_t)row * a.ldo);   // nt: streams out during the kernel (see common.h)
     }
   }
   stamp(3);

@@ -61,6 +61,15 @@ struct AttnArgs {
 
 // ---- row-panel chain kernel (gemm3.hip) ---------------------------------------------------------------------------
 constexpr int kMaxChainStages = 20;
+// Plain 16-byte output store.  (Non-temporal stores were measured: they help for the attention outputs -- the
+// end-of-kernel L2 write-back shrinks -- but cost 10 % of the step on GEMM / chain outputs, whose consumers then
+// miss the cache.)
+#if defined(__HIPCC__)
+__device__ __forceinline__ void out_store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+#endif
+
 struct ChainStage {
   const void* w;            // operand-major split image, positioned at this stage's first 32-column block
   int kt_total;             // k-tiles per column block (block stride = kt_total * 4096 bytes)

@@ -417,7 +417,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             if (g.bn_scale && !g.bn_first) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
             const float4 pe4 = pev[j][q], r4 = res[j][q];
             v[0] += g.pe_w * pe4.x + r4.x; v[1] += g.pe_w * pe4.y + r4.y; v[2] += g.pe_w * pe4.z + r4.z; v[3] += g.pe_w * pe4.w + r4.w;
-            *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            out_store4(g.C + (size_t)row * g.ldc + col, v[0], v[1], v[2], v[3]);
           }
       }
     } else {   // generic (unaligned N / strides): scalar path
@@ -543,7 +543,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         const int r = gidx / cpr, c = gidx - r * cpr;               // logical chunk c of row r
         if (r < 32 && m0 + r < g.M) {
           const float4 o4 = *reinterpret_cast<const float4*>(Rst + (size_t)r * g.N + 4 * (c ^ (r & 15)));
-          *reinterpret_cast<float4*>(g.C + (size_t)(m0 + r) * g.ldc + 4 * c) = o4;
+          out_store4(g.C + (size_t)(m0 + r) * g.ldc + 4 * c, o4.x, o4.y, o4.z, o4.w);
         }
       }
     } else if (rok) {
@@ -555,9 +555,9 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
           if (col >= g.N) continue;
           if (vec_ok) {
             const float4 ga = p_sc[j][q], be = p_sh[j][q];
-            *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + col) =
-                make_float4((v[j][4 * q + 0] - mean) * rstd * ga.x + be.x, (v[j][4 * q + 1] - mean) * rstd * ga.y + be.y,
-                            (v[j][4 * q + 2] - mean) * rstd * ga.z + be.z, (v[j][4 * q + 3] - mean) * rstd * ga.w + be.w);
+            out_store4(g.C + (size_t)row * g.ldc + col,
+                      (v[j][4 * q + 0] - mean) * rstd * ga.x + be.x, (v[j][4 * q + 1] - mean) * rstd * ga.y + be.y,
+                      (v[j][4 * q + 2] - mean) * rstd * ga.z + be.z, (v[j][4 * q + 3] - mean) * rstd * ga.w + be.w);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)

@@ -274,7 +274,7 @@ panel_chain_kernel(const ChainArgs g) {
       const int col = 32 * wave + 8 * q + 4 * half;
       if (!cok[q]) continue;
       if (st.out && row < g.M)
-        *reinterpret_cast<float4*>(st.out + (size_t)row * st.ldo + col) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        out_store4(st.out + (size_t)row * st.ldo + col, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       if (st.dst >= 0) {
         h16x4 hi, lo;
 #pragma unroll

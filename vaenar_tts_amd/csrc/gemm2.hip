@@ -52,7 +52,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int AQ = BM / 8 / NW, BQ = BN / 8 / NW, LPW = AQ + BQ;   // DMA instructions per wave per stage
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "stage rows must split evenly over the waves");
-  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -637,11 +637,15 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
     if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 3, true, true>(g, s) : launch2<32, 256, 1, 4, 3, true, true>(g, s);
     static const int stile = getenv("VNR_SPLIT_TILE") ? atoi(getenv("VNR_SPLIT_TILE")) : -1;   // measurement knob
-    int t = stile;
-    if (t < 0) t = 2;
-    if (t == 0) return launch2<128, 128, 2, 2, 3, false, true>(g, s);
-    if (t == 1) return launch2<64, 128, 2, 2, 3, false, true>(g, s);
-    return launch2<64, 64, 2, 2, 3, false, true>(g, s);
+    static const int sstages = getenv("VNR_SPLIT_STAGES") ? atoi(getenv("VNR_SPLIT_STAGES")) : -1;   // measurement knob
+    int t = stile, ns = sstages;
+    // 64x64 tiles (3 workgroups per CU) are fastest or tied on every S1 shape except the long-K PostNet convolutions
+    // (M = 12800, K = 5*256): there the 64x128 tile halves the activation re-reads (53 -> 40 us per layer, tools/sweep_split_tiles.sh)
+    if (t < 0) t = (g.taps > 0 && g.M >= 8192 && g.N >= 128) ? 1 : 2;
+    if (ns < 0) ns = 3;
+    if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, true>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, true>(g, s) : launch2<128, 128, 2, 2, 3, false, true>(g, s);
+    if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, true>(g, s) : launch2<64, 128, 2, 2, 3, false, true>(g, s);
+    return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, true>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, true>(g, s) : launch2<64, 64, 2, 2, 3, false, true>(g, s);
   }
   if (g.ln_gamma) {
     (void)st;

@@ -152,25 +152,32 @@ panel_chain_kernel(const ChainArgs g) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     wstamp(si, 0);
     const int npad = (st.nk + PF - 1) / PF * PF;
+    // activation operands are read ONE k-tile ahead (registers a[cur] / a[nxt]) so the LDS latency of tile kt+1 hides
+    // under the six MFMAs of tile kt; reads past the stage's last tile are clamped (harmless re-read)
+    h16x8 afr[2][4];
+    auto read_a = [&](int kt, int set) {
+      const int kc = kt < st.nk ? kt : st.nk - 1;
+      const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
+      const int akt = (kc < st.asw) ? kc : kc - st.asw;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        afr[set][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 2 * t + half));
+        afr[set][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 4 + 2 * t + half));
+      }
+    };
+    read_a(0, 0);
 #pragma unroll 1
     for (int kb = 0; kb < npad; kb += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int kt = kb + u;
+        read_a(kt + 1, (u + 1) & 1);
         if (wave_on && kt < st.nk) {
-          const char* Ap = (kt < st.asw) ? Ap0 : Ap1;
-          const int akt = (kt < st.asw) ? kt : kt - st.asw;
-          h16x8 ah[2], al[2];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            ah[t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 2 * t + half));
-            al[t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 4 + 2 * t + half));
-          }
 #pragma unroll
           for (int t = 0; t < 2; ++t) {                                   // D^T: lane <-> activation row
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], ah[t], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], al[t], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], ah[t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][2 * t], acc, 0, 0, 0);
           }
         }
         fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)

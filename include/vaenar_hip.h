@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VNR_ABI_VERSION 1
+#define VNR_ABI_VERSION 2
 
 typedef struct vnr_context *vnr_handle;
 
@@ -71,6 +71,9 @@ typedef struct vnr_config {
   float   post_temperature;
   /* LengthPredictor.Dense (hparams.py:346-348) */
   int32_t lenpred_activation;
+  /* Dropout rates, active only with option "training" (hparams.py:299-300,321,326-327): encoder prenet convs,
+   * encoder positional dropout, PostNet convs, posterior PreNet, posterior positional dropout */
+  float   enc_pre_drop_rate, enc_pos_drop_rate, dec_post_drop_rate, post_pre_drop_rate, post_pos_drop_rate;
 } vnr_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
@@ -148,7 +151,9 @@ int vnr_inference(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_leng
 int vnr_prior_log_probability(vnr_handle h, const float *d_z, const float *d_text_embd,
                               const int32_t *d_z_lengths, const int32_t *d_text_lengths, int B, int Tz,
                               int Tt, float *d_logprobs);
-/* VAENAR.call (models/models.py:105-197) forward with training=False, n_sample = 1, reduce_loss=False:
+/* VAENAR.call (models/models.py:105-197) forward, n_sample = 1, reduce_loss=False.  With option "training" = 1 it is
+ * the training-mode forward of train.py:130-134: Dropout active (counter-based masks keyed by option "dropout_seed"),
+ * BatchNormalization on batch statistics with the moving statistics updated in the weight store.  Default (training=0):
  * encoder -> length predictor -> posterior -> reparameterize (d_eps [B,Tz,latent] or NULL = zeros) ->
  * posterior log-prob -> decoder -> masked L2 of outputs and initial outputs -> prior.log_probability.
  * Tz = ceil(Tm / rf); d_reduced_lengths = ceil(mel_lengths / rf).
@@ -208,6 +213,20 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *
  * "split_encoder" (default 1): the text encoder (which feeds the integer frame-count predictor) uses the split path as
  * well; 0 keeps that chain on exact fp32 MFMA.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
+/* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
+ * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,
+ * utils.py:15,17,84, posterior.py:122) draw counter-based masks; BatchNormalization (utils.py:79-83) normalises with the
+ * batch mean / population variance over all B*T rows and updates moving_mean / moving_variance (momentum 0.99). */
+
+/* VAENAR.init (models/models.py:212-226) <- train.py:176-179 init_step: text encoder (training=True) ->
+ * TransformerPrior.init (prior.py:171-186: every ActNormFlow sets log_scale / bias from the statistics of its input,
+ * flow.py:189-196) -> decoder at max_reduction_factor.  d_reduced_lengths = ceil(mel_lengths / max_rf), Tz = their
+ * padded maximum, d_eps [B,Tz,latent] the initial noise (NULL = zeros), d_mel NULL or [B, Tz*max_rf, output_dim].
+ * The ActNorm variables and BN moving statistics in the weight store are updated and all packed panels rebuilt. */
+int vnr_init(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
+             const int32_t *d_reduced_lengths, int B, int Tt, int Tz, float pos_step,
+             const float *d_eps, float *d_mel);
+
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream and

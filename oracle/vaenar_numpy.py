@@ -112,6 +112,43 @@ def batch_norm_train(x, gamma, beta, eps=BN_EPS):
     return (x - mean) / np.sqrt(var + eps) * gamma + beta, mean, var
 
 
+# ---- counter-based dropout masks (training-mode parity) --------------------------------------------
+# The reference draws its masks from TensorFlow's stateful RNG (tf.keras.layers.Dropout), which cannot be reproduced.
+# The engine uses a counter-based hash instead (vaenar_tts_amd/csrc/misc.hip: rowop_kernel / mix32, engine.hip:
+# site_key); the statements below are bit-identical to it so training-mode parity runs with dropout ON.
+DROPOUT_SITES = {"text_encoder/pe_dropout": 8, "posterior/prenet/dropout1": 16, "posterior/prenet/dropout2": 17,
+                 "posterior/pe_dropout": 18}
+for _i in range(8):
+    DROPOUT_SITES["text_encoder/prenet/conv_stack/%d/dropout" % _i] = _i
+    DROPOUT_SITES["decoder/postnet/conv_stack/%d/dropout" % _i] = 32 + _i
+
+
+def _mix32(k):
+    """murmur3 finaliser on uint32 arrays (wrap-around arithmetic)."""
+    k = np.asarray(k, np.uint32).copy()
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint32(16); k *= np.uint32(0x85EBCA6B)
+        k ^= k >> np.uint32(13); k *= np.uint32(0xC2B2AE35)
+        k ^= k >> np.uint32(16)
+    return k
+
+
+def dropout_site_key(seed, site):
+    with np.errstate(over="ignore"):
+        return _mix32(np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(site + 1) * np.uint32(0x9E3779B9)))
+
+
+def dropout_keep(shape, rate, seed, site):
+    """Boolean keep-mask of one Dropout call: element i (row-major) is kept iff
+    mix32(i * 0x9E3779B1 + key(seed, site)) >= rate * 2^32."""
+    n = int(np.prod(shape))
+    rate32 = np.float32(rate)
+    thresh = np.uint32(min(np.float32(rate32 * np.float32(4294967296.0)), np.float32(4294967040.0)))
+    with np.errstate(over="ignore"):
+        k = _mix32(np.arange(n, dtype=np.uint32) * np.uint32(0x9E3779B1) + dropout_site_key(seed, site))
+    return (k >= thresh).reshape(shape)
+
+
 def softmax_last(x):
     """tf.math.softmax: exp(x-max)/sum."""
     m = x.max(-1, keepdims=True)
@@ -134,6 +171,8 @@ class Oracle:
         self.dtype = dtype
         self.w = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}
         self.dropout_masks = None      # {site: keep_mask*scale} injected for training parity
+        self.dropout_seed = None       # or: counter-based masks, bit-identical to the engine's (dropout_keep)
+        self.update_moving_stats = False   # BatchNormalization(training=True) also assigns moving_mean / moving_variance
         self.last = {}                 # intermediates of the last call (for tests)
 
     # -- helpers ---------------------------------------------------------------
@@ -147,7 +186,27 @@ class Oracle:
         """Dropout with injectable mask (training only); identity otherwise."""
         if training and self.dropout_masks is not None and site in self.dropout_masks:
             return x * self.dropout_masks[site].astype(self.dtype)
+        if training and self.dropout_seed is not None:
+            rate = self._drop_rate(site)
+            if rate > 0:
+                keep = dropout_keep(x.shape, rate, self.dropout_seed, DROPOUT_SITES[site])
+                scale = np.float32(1.0) / (np.float32(1.0) - np.float32(rate))      # tf.keras Dropout: x / (1 - rate)
+                return np.where(keep, x * self.dtype(scale), self.dtype(0))
         return x
+
+    def _drop_rate(self, site):
+        h = self.hps
+        if site.startswith("text_encoder/prenet"):
+            return h.Encoder.Transformer.pre_drop_rate
+        if site == "text_encoder/pe_dropout":
+            return h.Encoder.Transformer.pos_drop_rate
+        if site.startswith("decoder/postnet"):
+            return h.Decoder.Transformer.post_drop_rate
+        if site.startswith("posterior/prenet"):
+            return h.Posterior.Transformer.pre_drop_rate
+        if site == "posterior/pe_dropout":
+            return h.Posterior.Transformer.pos_drop_rate
+        raise KeyError(site)
 
     # -- attention.py ----------------------------------------------------------
     def mha(self, p, inputs, memory, memory_lengths, query_lengths, causality, num_head,
@@ -215,6 +274,10 @@ class Oracle:
                 out, mean, var = batch_norm_train(t, g, b)
                 self.last[f"{p}/bn/batch_mean"] = mean
                 self.last[f"{p}/bn/batch_var"] = var
+                if self.update_moving_stats:      # Keras momentum 0.99 (population variance, non-fused rank-3 path)
+                    mom = self.dtype(np.float32(0.99)); om = self.dtype(np.float32(1.0) - np.float32(0.99))
+                    self.w[f"{p}/bn/moving_mean"] = self._g(f"{p}/bn/moving_mean") * mom + mean * om
+                    self.w[f"{p}/bn/moving_variance"] = self._g(f"{p}/bn/moving_variance") * mom + var * om
                 return out
             return batch_norm_infer(t, g, b, self._g(f"{p}/bn/moving_mean"),
                                     self._g(f"{p}/bn/moving_variance"))

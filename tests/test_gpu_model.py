@@ -200,3 +200,86 @@ def test_elbo_forward(setup, rf):
     _, l2m, klm, llm, _ = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf,
                                 training=False, reduce_loss=True, eps=eps)
     np.testing.assert_allclose([l2m, llm], [rl2.mean(), rll.mean()], rtol=1e-3)
+
+
+# ---- training-mode forward and data-dependent init (A17 training=True forward, A23) -------------
+BN_PATHS = ["text_encoder/prenet/conv_stack/%d/bn/%s", "decoder/postnet/conv_stack/%d/bn/%s"]
+
+
+def _fresh(name):
+    """Training-mode calls mutate the weight store (BN moving statistics, ActNorm variables): private copies."""
+    hps = tiny_hps() if name == "tiny" else LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    model = VAENAR(hps, weights=w)
+    oracle = Oracle(hps, {k: v.copy() for k, v in w.items()}, np.float64)
+    oracle.update_moving_stats = True
+    return hps, model, oracle
+
+
+@pytest.mark.parametrize("name", ["tiny", "lj"])
+def test_elbo_forward_training_mode(name):
+    """VAENAR.call(training=True) forward (train.py:130-134): Dropout ON (counter-based masks reproduced bit for bit by
+    the oracle), BatchNormalization on batch statistics, moving statistics updated."""
+    hps, model, oracle = _fresh(name)
+    try:
+        b = _batch(hps, name)
+        rf, seed = 2, 77
+        r = np.random.Generator(np.random.PCG64(22))
+        B, Tm = len(b["mel_lengths"]), int(b["mel_lengths"].max())
+        Tz = (Tm + rf - 1) // rf
+        mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+        eps = r.standard_normal((B, 1, Tz, hps.Common.latent_dim)).astype(np.float32)
+        outs, l2, kl, ll, _ = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf,
+                                    training=True, reduce_loss=False, eps=eps, dropout_seed=seed)
+        oracle.dropout_seed = seed
+        routs, rl2, rkl, rll, _ = oracle.call(b["ids"], mels, b["mel_lengths"], b["text_lengths"], rf, True, False,
+                                              eps.astype(np.float64))
+        np.testing.assert_allclose(outs.numpy(), routs, atol=MEL_TOL, rtol=0)
+        np.testing.assert_allclose(l2.numpy(), rl2, rtol=1e-4)
+        np.testing.assert_allclose(ll.numpy(), rll, rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(kl.numpy(), rkl, rtol=1e-3, atol=6e-2)
+        # dropout was really active: the eval-mode forward of the same inputs differs
+        eouts, *_ = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf, training=False,
+                          reduce_loss=False, eps=eps)
+        # (the eval forward above already runs on the UPDATED moving statistics: compare them with the oracle's)
+        n_enc, n_post = hps.Encoder.Transformer.n_conv, hps.Decoder.Transformer.post_n_conv
+        paths = [BN_PATHS[0] % (i, s) for i in range(n_enc) for s in ("moving_mean", "moving_variance")] + \
+                [BN_PATHS[1] % (i, s) for i in range(n_post) for s in ("moving_mean", "moving_variance")]
+        got = model.get_weights(paths)
+        for p in paths:
+            np.testing.assert_allclose(got[p], oracle.w[p], rtol=2e-5, atol=2e-6, err_msg=p)
+        assert np.abs(eouts.numpy() - outs.numpy()).max() > 1e-3
+        oracle.dropout_seed = None
+        reouts, *_ = oracle.call(b["ids"], mels, b["mel_lengths"], b["text_lengths"], rf, False, False, eps.astype(np.float64))
+        np.testing.assert_allclose(eouts.numpy(), reouts, atol=MEL_TOL, rtol=0)
+    finally:
+        model.engine.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "lj"])
+def test_model_init_actnorm(name):
+    """VAENAR.init (models.py:212-226): data-dependent ActNorm init (flow.py:189-196) at max_reduction_factor."""
+    hps, model, oracle = _fresh(name)
+    try:
+        b = _batch(hps, name)
+        rf, seed = hps.Common.max_reduction_factor, 5
+        red = (b["mel_lengths"].astype(np.int64) + rf - 1) // rf
+        Tz, C = int(red.max()), hps.Common.latent_dim
+        r = np.random.Generator(np.random.PCG64(23))
+        eps = r.standard_normal((len(red), Tz, C)).astype(np.float32)
+        mel = model.init(b["ids"], b["mel_lengths"], b["text_lengths"], eps=eps, dropout_seed=seed)
+        oracle.dropout_seed = seed
+        rmel = oracle.init(b["ids"], b["mel_lengths"], b["text_lengths"], eps.astype(np.float64))
+        np.testing.assert_allclose(mel.numpy(), rmel, atol=MEL_TOL, rtol=0)
+        paths = ["prior/glow/%d/0/%s" % (s, v) for s in range(hps.Prior.Transformer.n_blk) for v in ("log_scale", "bias")]
+        got = model.get_weights(paths)
+        for p in paths:
+            np.testing.assert_allclose(got[p], oracle.w[p], rtol=1e-4, atol=2e-5, err_msg=p)
+        # the re-packed engine now samples with the initialised flow: inference parity against the updated oracle
+        oracle.dropout_seed = None
+        bi = _batch(hps, name)
+        gmel, _ = model.inference(bi["ids"], bi["mel_lengths"], bi["text_lengths"], eps=bi["eps"])
+        omel, _ = oracle.inference(bi["ids"], bi["mel_lengths"], bi["text_lengths"], 2, bi["eps"].astype(np.float64))
+        np.testing.assert_allclose(gmel.numpy(), omel, atol=MEL_TOL, rtol=0)
+    finally:
+        model.engine.close()

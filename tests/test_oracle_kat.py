@@ -229,3 +229,17 @@ def test_oracle_fp32_mode_tracks_fp64():
     m64, _ = Oracle(LJHPS, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
     m32, _ = Oracle(LJHPS, w, np.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
     assert m32.dtype == np.float32 and np.abs(m32 - m64).max() < 1e-4
+
+
+def test_dropout_hash_known_answers():
+    """The counter-based dropout mask shared by the engine (misc.hip: mix32 / rowop_kernel, engine.hip: site_key) and
+    the oracle: fixed points of the hash, keep fraction, determinism and independence across sites."""
+    from oracle.vaenar_numpy import DROPOUT_SITES, dropout_keep, dropout_site_key, _mix32
+    assert int(_mix32(np.uint32(0))) == 0 and int(_mix32(np.uint32(1))) == 0x514E28B7      # murmur3 fmix32 vectors
+    assert int(dropout_site_key(1234, 8)) == 3684969370
+    k1 = dropout_keep((1000, 100), 0.1, 1234, DROPOUT_SITES["text_encoder/pe_dropout"])
+    k2 = dropout_keep((1000, 100), 0.1, 1234, DROPOUT_SITES["text_encoder/pe_dropout"])
+    k3 = dropout_keep((1000, 100), 0.1, 1234, DROPOUT_SITES["posterior/pe_dropout"])
+    assert (k1 == k2).all() and abs(k1.mean() - 0.9) < 5e-3 and abs((k1 == k3).mean() - 0.82) < 1e-2
+    assert dropout_keep((64,), 0.0, 1, 0).all()
+    assert abs(dropout_keep((200000,), 0.5, 7, 16).mean() - 0.5) < 5e-3

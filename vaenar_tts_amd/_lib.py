@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
 
@@ -40,6 +40,8 @@ class vnr_config(C.Structure):
         ("post_attention_dim", C.c_int32), ("post_attention_heads", C.c_int32),
         ("post_ffn_hidden", C.c_int32), ("post_temperature", C.c_float),
         ("lenpred_activation", C.c_int32),
+        ("enc_pre_drop_rate", C.c_float), ("enc_pos_drop_rate", C.c_float), ("dec_post_drop_rate", C.c_float),
+        ("post_pre_drop_rate", C.c_float), ("post_pos_drop_rate", C.c_float),
     ]
 
 
@@ -89,6 +91,7 @@ PROTOTYPES = {
     "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
     "vnr_set_option": [_vp, C.c_char_p, _i],
+    "vnr_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
     "vnr_profile_get": [_vp, C.c_char_p, _pd, _pi64, _pd, _pd],
@@ -148,6 +151,9 @@ def config_from_hps(hps):
     c.post_attention_dim, c.post_attention_heads = q.attention_dim, q.attention_heads
     c.post_ffn_hidden, c.post_temperature = q.ffn_hidden, q.temperature
     c.lenpred_activation = ACT[hps.LengthPredictor.Dense.activation]
+    c.enc_pre_drop_rate, c.enc_pos_drop_rate = e.pre_drop_rate, e.pos_drop_rate
+    c.dec_post_drop_rate = d.post_drop_rate
+    c.post_pre_drop_rate, c.post_pos_drop_rate = q.pre_drop_rate, q.pos_drop_rate
     return c
 
 

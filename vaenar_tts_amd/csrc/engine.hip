@@ -40,9 +40,14 @@ struct SBlk {   // SelfAttentionBLK (attention.py:392-415), packed
 struct ConvL {  // Conv1D + BN (utils.py:56-85), packed
   const float *wt, *bias, *bn_scale, *bn_shift;
   int cin, cout, k;
+  float *gamma, *beta, *moving_mean, *moving_var;   // the BN variables themselves (training mode: batch statistics + moving update)
+  float drop_rate; int site;                        // Dropout after BN (utils.py:84), active when training
 };
 struct FlowStep {
   const float *fold_wt, *fold_b;         // ActNorm o InvertibleLinear
+  float *an_log_scale, *an_bias;         // the ActNorm variables themselves (data-dependent init writes them, flow.py:189-196)
+  const float* lin_w;                    // InvertibleLinear weight [C][C] as stored
+  double lin_logdet;                     // log|det W| cast to fp32 (flow.py:127-129)
   double logdet_per_frame;               // sum(log_scale) + log|det W|  (flow.py:168,127-129)
   const float *inv_wt, *inv_b;           // (InvertibleLinear o ActNorm)^-1 : eps = (z.inv(W) - b) / (exp(ls) + 1e-8)
   double inv_logdet_per_frame;           // -sum(log_scale) + log|det inv(W)|  (flow.py:181,141-145)
@@ -55,6 +60,13 @@ struct FlowStep {
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
 enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_COUNT };
 const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc"};
+
+// Dropout sites (one mask stream per tf.keras.layers.Dropout instance of the path): encoder.py:70,87; utils.py:73,84
+// (prenet / postnet convolutions); utils.py:11-17 (posterior PreNet, two uses of one layer); posterior.py:99,122
+enum { SITE_ENC_CONV = 0, SITE_ENC_PE = 8, SITE_POST_PRENET1 = 16, SITE_POST_PRENET2 = 17, SITE_POST_PE = 18, SITE_POSTNET_CONV = 32 };
+inline unsigned host_mix32(unsigned k) { k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16; return k; }
+// per-site key of the counter-based mask (oracle/vaenar_numpy.py: dropout_site_key is the same statement)
+inline unsigned site_key(unsigned seed, int site) { return host_mix32(seed ^ ((unsigned)(site + 1) * 0x9E3779B9u)); }
 
 }  // namespace
 
@@ -97,6 +109,8 @@ struct vnr_context {
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool split_encoder = true;     // engine option "split_encoder": the text encoder uses the split path too (measured as accurate as exact fp32: profiles/r01_split_accuracy.txt)
   bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
+  bool training = false;         // engine option "training": Dropout active, BatchNormalization on batch statistics (+ moving update)
+  unsigned drop_seed = 0;        // engine option "dropout_seed"
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
 
@@ -352,6 +366,7 @@ void pack_conv(Packer& P, const std::string& p, int k, int cin, int cout, ConvL&
   const float* b = P.raw(p + "/bn/beta", {cout});
   const float* m = P.raw(p + "/bn/moving_mean", {cout});
   const float* v = P.raw(p + "/bn/moving_variance", {cout});
+  o.gamma = const_cast<float*>(g); o.beta = const_cast<float*>(b); o.moving_mean = const_cast<float*>(m); o.moving_var = const_cast<float*>(v);
   if (P.rc == VNR_OK && launch_bn_affine(g, b, m, v, cout, sc, sh, P.h->stream) != hipSuccess) { P.rc = VNR_ERR_HIP; P.missing = "bn_affine launch"; }
   o.bn_scale = sc; o.bn_shift = sh;
 }
@@ -560,7 +575,32 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
   g.bias = c.bias; g.act = act; g.bn_scale = c.bn_scale; g.bn_shift = c.bn_shift; g.bn_first = bn_first;
   g.C = y; g.ldc = c.cout; g.M = B * T; g.N = c.cout; g.taps = c.k; g.conv_T = T; g.conv_C = c.cin;
   g.gather_ids = gather;
-  return run_gemm(h, g);
+  if (!h->training) return run_gemm(h, g);
+  // training=True (utils.py:76-85): conv -> act -> BatchNormalization on BATCH statistics (all B*T rows, padding
+  // included; moving statistics updated, momentum 0.99) -> Dropout
+  if (bn_first) return fail(h, VNR_ERR_ARG, "training mode supports bn_before_act=False only");
+  g.bn_scale = nullptr; g.bn_shift = nullptr;
+  TRY(run_gemm(h, g));
+  const int M = B * T, C = c.cout;
+  WS(stat, (size_t)4 * C + 2 * C);                       // 2*C doubles (mean, centred squares) + scale/shift floats
+  double* mean = reinterpret_cast<double*>(stat);
+  double* sq = mean + C;
+  float* sc = stat + 4 * C; float* sh = sc + C;
+  HIP_TRY(h, hipMemsetAsync(stat, 0, (size_t)4 * C * sizeof(float), h->stream));
+  RUN_MISC(h, launch_col_sum(y, M, C, C, nullptr, mean, h->stream));
+  RUN_MISC(h, launch_scale_d(mean, C, 1.0 / (double)M, h->stream));
+  RUN_MISC(h, launch_col_sum(y, M, C, C, mean, sq, h->stream));
+  RUN_MISC(h, launch_bn_train_finish(mean, sq, M, C, c.gamma, c.beta, 0.99f, c.moving_mean, c.moving_var, sc, sh, h->stream));
+  RUN_MISC(h, launch_rowop(y, M, C, sc, sh, nullptr, 1, 0.f, c.drop_rate, site_key(h->drop_seed, c.site), y, h->stream));
+  return VNR_OK;
+}
+// the moving statistics changed (training-mode forward): refresh the folded inference affine of every BN
+int refresh_bn_affine(vnr_handle h) {
+  for (auto* v : {&h->enc_convs, &h->post_convs})
+    for (const ConvL& c : *v)
+      RUN_MISC(h, launch_bn_affine(c.gamma, c.beta, c.moving_mean, c.moving_var, c.cout, const_cast<float*>(c.bn_scale),
+                                   const_cast<float*>(c.bn_shift), h->stream));
+  return VNR_OK;
 }
 
 // cross-attention K|V of the memory for a group of blocks: one GEMM over a stacked panel
@@ -600,6 +640,8 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
   g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = h->enc_proj_wt; g.ldw = Dm; g.bias = h->enc_proj_b;
   g.pe = pe; g.pe_T = T; g.pe_w = h->enc_pos_weight; g.C = nxt; g.ldc = Dm; g.M = M; g.N = Dm;
   TRY(run_gemm(h, g));                                       // prenet.projection + pos_weight*PE (encoder.py:85-86)
+  if (h->training && c.enc_pos_drop_rate > 0.f)              // pe_dropout (encoder.py:87)
+    RUN_MISC(h, launch_rowop(nxt, M, Dm, nullptr, nullptr, nullptr, 1, 0.f, c.enc_pos_drop_rate, site_key(h->drop_seed, SITE_ENC_PE), nxt, h->stream));
   std::swap(cur, nxt);
   WS(qkv, (size_t)M * 3 * A); WS(att, (size_t)M * A); WS(y, (size_t)M * Dm); WS(hid, (size_t)M * F);
   for (size_t i = 0; i < h->enc_blks.size(); ++i) {
@@ -673,6 +715,62 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
   return VNR_OK;
 }
 
+// TransformerPrior.init (prior.py:171-186): like sample(), but every ActNorm first sets its variables from the statistics
+// of its input (ActNormFlow.init, flow.py:189-196) -- written straight into the weight store.  Runs unfolded (the folded
+// panels are rebuilt by the caller afterwards).
+int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B,
+                    int Tz, int Tt, const float* eps, float* z_out) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  WS(za, (size_t)M * C); WS(zb, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C);
+  WS(stat, (size_t)4 * C + C); WS(wt, (size_t)C * C);
+  double* mean = reinterpret_cast<double*>(stat);
+  double* sq = mean + C;
+  float* sc = stat + 4 * C;
+  if (eps) HIP_TRY(h, hipMemcpyAsync(za, eps, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  else HIP_TRY(h, hipMemsetAsync(za, 0, (size_t)M * C * 4, h->stream));
+  const float* pe = nullptr;
+  TRY(get_pe(h, Tz, D, 1.0f, &pe));
+  float* zc = za; float* zn = zb;
+  const int nsteps = (int)h->flow.size();
+  for (int s = 0; s < nsteps; ++s) {
+    const FlowStep& f = h->flow[s];
+    // ActNorm.init: per-channel mean / population std over ALL B*Tz rows (padding included), then the forward
+    HIP_TRY(h, hipMemsetAsync(stat, 0, (size_t)4 * C * sizeof(float), h->stream));
+    RUN_MISC(h, launch_col_sum(zc, M, C, C, nullptr, mean, h->stream));
+    RUN_MISC(h, launch_scale_d(mean, C, 1.0 / (double)M, h->stream));
+    RUN_MISC(h, launch_col_sum(zc, M, C, C, mean, sq, h->stream));
+    RUN_MISC(h, launch_actnorm_init_finish(mean, sq, M, C, f.an_log_scale, f.an_bias, sc, h->stream));
+    RUN_MISC(h, launch_rowop(zc, M, C, sc, f.an_bias, nullptr, 1, 0.f, 0.f, 0u, zc, h->stream));       // z * exp(ls) + b
+    // InvertibleLinear forward z . W on the exact fp32 path (flow.py:123-135)
+    RUN_MISC(h, launch_transpose(f.lin_w, C, C, wt, C, h->stream));
+    GemmArgs g;
+    g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = wt; g.ldw = C; g.C = zn; g.ldc = C; g.M = M; g.N = C;
+    const bool saved = h->split_scope; h->split_scope = false;
+    const int rc = run_gemm(h, g);
+    h->split_scope = saved;
+    TRY(rc);
+    float* dst = zn;
+    const bool upper = (s % 2) == 0;
+    const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;
+    g = GemmArgs(); g.A1 = dst + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
+    g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+    float* xc = nullptr;
+    TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc));
+    if (f.blks.empty()) {
+      g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
+      g.C = heads; g.ldc = C; g.M = M; g.N = C;
+      TRY(run_gemm(h, g));
+    }
+    RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, nullptr, h->stream));
+    std::swap(zc, zn);
+  }
+  HIP_TRY(h, hipMemcpyAsync(z_out, zc, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  return VNR_OK;
+}
+
 // TransformerDecoder.call (decoder.py:181-199); kv = decoder cross K|V panel output
 int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const int32_t* z_len,
                  const int32_t* t_len, int B, int Tz, int Tt, int rf, float* initial, float* outputs,
@@ -717,15 +815,25 @@ int posterior_body(vnr_handle h, const float* mels, const float* kv, int kv_ld, 
   const vnr_config& c = h->cfg;
   const int M = B * Tz, P = c.post_pre_hidden, C = c.latent_dim;
   WS(xa, (size_t)M * P); WS(xb, (size_t)M * P);
-  GemmArgs g;   // PreNet (utils.py:13-18), dropout inactive
+  GemmArgs g;   // PreNet (utils.py:13-18)
   g.A1 = mels; g.lda1 = c.num_mels; g.K1 = c.num_mels; g.K = c.num_mels; g.Wt = h->post_d1_wt; g.ldw = c.num_mels; g.bias = h->post_d1_b;
   g.act = c.post_pre_activation; g.C = xa; g.ldc = P; g.M = M; g.N = P;
   TRY(run_gemm(h, g));
   const float* pe = nullptr;
   TRY(get_pe(h, Tz, P, 1.0f, &pe));
   g = GemmArgs(); g.A1 = xa; g.lda1 = P; g.K1 = P; g.K = P; g.Wt = h->post_d2_wt; g.ldw = P; g.bias = h->post_d2_b; g.act = c.post_pre_activation;
-  g.pe = pe; g.pe_T = Tz; g.pe_w = h->post_pos_weight; g.C = xb; g.ldc = P; g.M = M; g.N = P;
-  TRY(run_gemm(h, g));               // + pos_weight * PE (posterior.py:120-121)
+  g.C = xb; g.ldc = P; g.M = M; g.N = P;
+  if (!h->training) {
+    g.pe = pe; g.pe_T = Tz; g.pe_w = h->post_pos_weight;
+    TRY(run_gemm(h, g));             // + pos_weight * PE (posterior.py:120-121)
+  } else {
+    // training=True: the PreNet's Dropout(0.5) is active after both layers (Keras call context, utils.py:15,17), then
+    // + pos_weight * PE and pe_dropout (posterior.py:121-122)
+    RUN_MISC(h, launch_rowop(xa, M, P, nullptr, nullptr, nullptr, 1, 0.f, c.post_pre_drop_rate, site_key(h->drop_seed, SITE_POST_PRENET1), xa, h->stream));
+    TRY(run_gemm(h, g));
+    RUN_MISC(h, launch_rowop(xb, M, P, nullptr, nullptr, nullptr, 1, 0.f, c.post_pre_drop_rate, site_key(h->drop_seed, SITE_POST_PRENET2), xb, h->stream));
+    RUN_MISC(h, launch_rowop(xb, M, P, nullptr, nullptr, pe, Tz, h->post_pos_weight, c.post_pos_drop_rate, site_key(h->drop_seed, SITE_POST_PE), xb, h->stream));
+  }
   const int D = c.post_attention_dim;
   float* xc = nullptr;
   TRY(run_xstack(h, h->post_blks, xb, xa, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.post_attention_heads, c.post_temperature,
@@ -947,6 +1055,7 @@ int vnr_finalize_weights(vnr_handle h) {
   int cin = c.enc_embd_dim;
   for (int i = 0; i < c.enc_n_conv; ++i) {
     ConvL L; pack_conv(P, "text_encoder/prenet/conv_stack/" + std::to_string(i), c.enc_conv_kernel, cin, Dm, L);
+    L.drop_rate = c.enc_pre_drop_rate; L.site = SITE_ENC_CONV + i;
     h->enc_convs.push_back(L); cin = Dm;
   }
   h->enc_proj_wt = P.wt("text_encoder/prenet/projection/kernel", Dm, Dm);
@@ -993,7 +1102,8 @@ int vnr_finalize_weights(vnr_handle h) {
       for (size_t i = 0; i < Wf.size(); ++i) Wh[i] = (double)Wf[i];
       float lssum = 0.f;   // tf.reduce_sum(log_scale) in fp32 (flow.py:168)
       for (int i = 0; i < C; ++i) lssum += lsf[i];
-      f.logdet_per_frame = (double)lssum + (double)(float)slogdet_abs(Wh, C);   // cast to fp32, flow.py:127-129
+      f.lin_logdet = (double)(float)slogdet_abs(Wh, C);
+      f.logdet_per_frame = (double)lssum + f.lin_logdet;   // cast to fp32, flow.py:127-129
       // backward direction (prior.log_probability): eps = (z . inv(W) - b) / (exp(ls) + 1e-8)  (flow.py:137-150, 177-187)
       std::vector<double> Winv;
       std::vector<float> abf(C), wti((size_t)C * C), bi(C);
@@ -1014,6 +1124,7 @@ int vnr_finalize_weights(vnr_handle h) {
       }
     }
     f.fold_wt = fw; f.fold_b = fb;
+    f.an_log_scale = const_cast<float*>(ls); f.an_bias = const_cast<float*>(ab); f.lin_w = W;
     P.reg(fw, C, C);
     f.pos_weight = P.scalar(p + "/2/net/pos_weight");
     f.pre_wt = P.wt(p + "/2/net/pre_projection/kernel", half, Dp);
@@ -1047,6 +1158,7 @@ int vnr_finalize_weights(vnr_handle h) {
   cin = od;
   for (int i = 0; i < c.dec_post_n_conv; ++i) {
     ConvL L; pack_conv(P, "decoder/postnet/conv_stack/" + std::to_string(i), c.dec_post_conv_kernel, cin, c.dec_post_conv_filters, L);
+    L.drop_rate = c.dec_post_drop_rate; L.site = SITE_POSTNET_CONV + i;
     h->post_convs.push_back(L); cin = c.dec_post_conv_filters;
   }
   h->dec_res_wt = P.wt("decoder/residual_projection/kernel", cin, od);
@@ -1111,7 +1223,8 @@ int vnr_text_encoder_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_le
   TRY(check_ready(h));
   if (!d_ids || !d_out || B <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
-  return encoder_body(h, d_ids, d_lengths, B, T, pos_step, d_out);
+  TRY(encoder_body(h, d_ids, d_lengths, B, T, pos_step, d_out));
+  return h->training ? refresh_bn_affine(h) : VNR_OK;
 }
 
 int vnr_length_predictor_fwd(vnr_handle h, const float* d_text_embd, const int32_t* d_lengths, int B, int T, float* d_out) {
@@ -1140,8 +1253,9 @@ int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, co
   ws_reset(h);
   WS(kv, (size_t)B * Tt * h->dec_kv_n);
   TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->dec_kv_wt, h->dec_kv_n, kv));
-  return decoder_body(h, d_z, kv, h->dec_kv_n, d_z_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, d_initial,
-                      d_outputs, d_alignments);
+  TRY(decoder_body(h, d_z, kv, h->dec_kv_n, d_z_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, d_initial,
+                   d_outputs, d_alignments));
+  return h->training ? refresh_bn_affine(h) : VNR_OK;
 }
 
 int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_embd, const int32_t* d_text_lengths,
@@ -1242,7 +1356,38 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
     HIP_TRY(h, hipMemcpyAsync(d_aux + B, post_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_aux + 2 * (size_t)B, prior_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
   }
+  if (h->training) TRY(refresh_bn_affine(h));     // the moving statistics moved
   return VNR_OK;
+}
+
+// VAENAR.init (models.py:212-226): encoder(training=True) -> prior.init -> decoder(training=True, rf = max).
+static int init_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths, int B,
+                     int Tt, int Tz, float pos_step, const float* d_eps, float* d_mel) {
+  const vnr_config& c = h->cfg;
+  const int Dm = c.enc_pre_hidden, C = c.latent_dim, rf = c.max_reduction_factor;
+  WS(text_embd, (size_t)B * Tt * Dm);
+  TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
+  const int kv_ld = h->prior_kv_n + h->dec_kv_n;
+  WS(kv, (size_t)B * Tt * kv_ld);
+  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, kv_ld, kv));
+  WS(z, (size_t)B * Tz * C);
+  TRY(prior_init_body(h, d_reduced_lengths, d_text_lengths, kv, kv_ld, B, Tz, Tt, d_eps, z));
+  float* mel = d_mel;
+  if (!mel) { WS(tmp, (size_t)B * Tz * rf * c.output_dim); mel = tmp; }
+  return decoder_body(h, z, kv + h->prior_kv_n, kv_ld, d_reduced_lengths, d_text_lengths, B, Tz, Tt, rf, nullptr, mel, nullptr);
+}
+int vnr_init(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths, int B,
+             int Tt, int Tz, float pos_step, const float* d_eps, float* d_mel) {
+  TRY(check_ready(h));
+  if (!d_ids || !d_reduced_lengths || B <= 0 || Tt <= 0 || Tz <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  const bool saved = h->training;
+  h->training = true;
+  const int rc = init_impl(h, d_ids, d_text_lengths, d_reduced_lengths, B, Tt, Tz, pos_step, d_eps, d_mel);
+  h->training = saved;
+  TRY(rc);
+  // ActNorm variables and BN moving statistics changed: rebuild every folded / packed panel from the weight store
+  return vnr_finalize_weights(h);
 }
 
 // ---- single operators ---------------------------------------------------------------------------------------
@@ -1320,6 +1465,8 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
+  if (!strcmp(name, "training")) { h->training = value != 0; return VNR_OK; }
+  if (!strcmp(name, "dropout_seed")) { h->drop_seed = (unsigned)value; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }
 

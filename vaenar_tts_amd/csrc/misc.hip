@@ -457,4 +457,106 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
   return hipGetLastError();
 }
 
+// ---- training-mode statistics and dropout ------------------------------------------------------------
+// Column sums of x[M][C] (row stride ld) in float64: out[c] += sum_m f(x[m][c]) with f(v) = v, or (v - mean[c])^2
+// when `mean` is given (second pass of a two-pass variance).  Used by BatchNormalization(training=True)
+// (tf.nn.moments over axes (0,1), padded frames included: utils.py:79-83) and ActNormFlow.init (flow.py:189-196).
+__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;                       // 4 row groups per block
+  double acc = 0.0;
+  if (c < C) {
+    const double mu = mean ? mean[c] : 0.0;
+    for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+      const double v = (double)x[(size_t)m * ld + c];
+      acc += mean ? (v - mu) * (v - mu) : v;
+    }
+  }
+  __shared__ double part[4][64];
+  part[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && c < C) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
+  int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out);
+  return hipGetLastError();
+}
+__global__ void scale_d_kernel(double* v, int n, double f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= f;
+}
+hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s) {
+  hipLaunchKernelGGL(scale_d_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, n, f);
+  return hipGetLastError();
+}
+// BatchNormalization(training=True) (Keras, TF 2.2, non-fused path for rank-3 inputs): normalise with the batch
+// mean / population variance, update the moving statistics with momentum 0.99.
+//   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale;  moving = moving * 0.99 + batch * 0.01
+__global__ void bn_train_finish_kernel(const double* mean, const double* sq, int M, int C, const float* gamma,
+                                       const float* beta, float momentum, float* moving_mean, float* moving_var,
+                                       float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = (float)mean[c], var = (float)(sq[c] / (double)M);
+  const float inv = gamma[c] * (1.0f / sqrtf(var + kBnEps));
+  scale[c] = inv;
+  shift[c] = beta[c] - mu * inv;
+  moving_mean[c] = moving_mean[c] * momentum + mu * (1.0f - momentum);
+  moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
+}
+hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
+                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, gamma, beta, momentum,
+                     moving_mean, moving_var, scale, shift);
+  return hipGetLastError();
+}
+// ActNormFlow.init (flow.py:189-196): log_scale = log(1 / (std + 1e-8)), bias = -mean / (std + 1e-8) from the
+// statistics of ALL rows (padding included); also emits exp(log_scale) for the forward that follows.
+__global__ void actnorm_init_finish_kernel(const double* mean, const double* sq, int M, int C, float* log_scale, float* bias,
+                                           float* scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = (float)mean[c], sd = sqrtf((float)(sq[c] / (double)M));
+  const float ls = logf(1.0f / (sd + 1e-8f));
+  log_scale[c] = ls;
+  bias[c] = -mu / (sd + 1e-8f);
+  scale[c] = expf(ls);
+}
+hipError_t launch_actnorm_init_finish(const double* mean, const double* sq, int M, int C, float* log_scale, float* bias,
+                                      float* scale, hipStream_t s) {
+  hipLaunchKernelGGL(actnorm_init_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, log_scale, bias, scale);
+  return hipGetLastError();
+}
+// Counter-based dropout mask: keep element i of site `key` iff mix32(i * 0x9E3779B1 + key) >= rate * 2^32
+// (murmur3 finaliser).  oracle/vaenar_numpy.py:dropout_keep is the bit-identical NumPy statement, so training-mode
+// parity runs with dropout ON.  tf.keras.layers.Dropout: y = x * keep / (1 - rate).
+__device__ __forceinline__ unsigned mix32(unsigned k) {
+  k ^= k >> 16; k *= 0x85EBCA6Bu; k ^= k >> 13; k *= 0xC2B2AE35u; k ^= k >> 16;
+  return k;
+}
+// y[m][c] = dropout( x[m][c] * scale[c] + shift[c] + pe_w * pe[(m % T)][c] )   (each term optional)
+__global__ void rowop_kernel(const float* x, int M, int C, const float* scale, const float* shift, const float* pe, int T,
+                             float pe_w, float rate, unsigned key, float* y) {
+  const size_t n = (size_t)M * C;
+  const unsigned thresh = rate > 0.f ? (unsigned)fminf(rate * 4294967296.0f, 4294967040.0f) : 0u;
+  const float keep_scale = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), c = (int)(i - (size_t)m * C);
+    float v = x[i];
+    if (scale) v *= scale[c];
+    if (shift) v += shift[c];
+    if (pe) v += pe_w * pe[(size_t)(m % T) * C + c];
+    if (rate > 0.f) v = (mix32((unsigned)i * 0x9E3779B1u + key) >= thresh) ? v * keep_scale : 0.f;
+    y[i] = v;
+  }
+}
+hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const float* shift, const float* pe, int T, float pe_w,
+                        float rate, unsigned key, float* y, hipStream_t s) {
+  const size_t n = (size_t)M * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(rowop_kernel, dim3(blocks), dim3(256), 0, s, x, M, C, scale, shift, pe, T > 0 ? T : 1, pe_w, rate, key, y);
+  return hipGetLastError();
+}
+
 }  // namespace vnr

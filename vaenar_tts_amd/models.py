@@ -114,17 +114,20 @@ class VAENAR:
         return mel, alignments
 
     def __call__(self, inputs, mel_targets, mel_lengths, text_lengths=None, reduction_factor=2,
-                 training=None, reduce_loss=None, eps=None, return_alignments=True):
-        """VAENAR.call (models.py:105-197), forward only (training=False: the dev_step of train.py:148-155).
+                 training=None, reduce_loss=None, eps=None, return_alignments=True, dropout_seed=0):
+        """VAENAR.call (models.py:105-197), forward.  training=False is the dev_step of train.py:148-155;
+        training=True is the forward half of train_step (train.py:130-134): Dropout active (counter-based masks
+        keyed by ``dropout_seed``; oracle/vaenar_numpy.py reproduces them bit for bit), BatchNormalization on batch
+        statistics with the moving statistics updated in the engine's weight store.
         Returns (decoded_outs [B,Tm,out_dim], l2_loss, kl_divergence, length_loss, dec_alignments); with
         reduce_loss the three losses are means over the batch (models.py:84,92,101), otherwise [B] vectors.
         ``eps`` [B,1,Tz,C] or [B,Tz,C] replaces tf.random.normal of posterior.reparameterize
         (posterior.py:35); default: drawn from self.prior.rng.  The backward pass / optimizer is not built."""
-        if training:
-            raise NotImplementedError("VAENAR.call(training=True): dropout, BN batch statistics and the backward "
-                                      "pass are not built yet (DESIGN.md)")
         assert self.n_sample == 1
         eng = self.engine
+        eng.set_option("training", 1 if training else 0)
+        if training:
+            eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
         rf = int(reduction_factor)
         ids = eng.asarray(inputs, np.int32)
         B, Tt = ids.shape
@@ -149,6 +152,7 @@ class VAENAR:
         check(eng.lib.vnr_elbo_fwd(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
                                    eps_d.ptr, outs.ptr, l2.ptr, kl.ptr, ll.ptr, None if ali is None else ali.ptr,
                                    aux.ptr), eng.handle)
+        eng.set_option("training", 0)
         self.last_aux = aux           # predicted lengths | posterior log-probs | prior log-probs
         alignments = {}
         if ali is not None:
@@ -161,5 +165,40 @@ class VAENAR:
 
     call = __call__
 
-    def init(self, text_inputs, mel_lengths, text_lengths=None):
-        raise NotImplementedError("VAENAR.init (data-dependent ActNorm init, models.py:212-226) is not built yet")
+    def init(self, text_inputs, mel_lengths, text_lengths=None, eps=None, dropout_seed=0):
+        """VAENAR.init (models.py:212-226; init_step of train.py:176-179): text encoder with training=True ->
+        TransformerPrior.init (every ActNorm takes log_scale / bias from the statistics of its input, flow.py:189-196)
+        -> decoder at max_reduction_factor.  Returns the predicted mel; the ActNorm variables and the BN moving
+        statistics in the engine's weight store are updated (read them with ``get_weights``).
+        ``eps`` [B,Tz,C] replaces tf.random.normal of prior._initial_sample (prior.py:31)."""
+        eng = self.engine
+        rf = int(self.max_reduction_factor)
+        ids = eng.asarray(text_inputs, np.int32)
+        B, Tt = ids.shape
+        ml_h = mel_lengths.numpy() if hasattr(mel_lengths, "numpy") and not isinstance(mel_lengths, np.ndarray) \
+            else np.asarray(mel_lengths)
+        red = ((ml_h.astype(np.int64) + rf - 1) // rf).astype(np.int32)          # models.py:213
+        Tz = int(red.max())
+        rl = eng.to_device(red, np.int32)
+        tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
+        C = self.hps.Common.latent_dim
+        if eps is None:
+            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+        pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:214
+        mel = eng.empty((B, Tz * rf, self.decoder.out_dim))
+        eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
+        check(eng.lib.vnr_init(eng.handle, ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, float(pos_step), eps_d.ptr, mel.ptr),
+              eng.handle)
+        self._len_cache = {}
+        return mel
+
+    def get_weights(self, paths=None):
+        """{path: ndarray} read back from the engine (after init / training-mode forwards)."""
+        from .weights import weight_spec
+        spec = weight_spec(self.hps)
+        return {k: eng_get(self.engine, k, spec[k]) for k in (paths or spec)}
+
+
+def eng_get(engine, path, shape):
+    return engine.get_weight(path, shape if len(shape) else (1,)).reshape(shape)

@@ -31,5 +31,12 @@ class EngineModule:
     def _no_training(self, training):
         if training:
             raise NotImplementedError(
-                "%s: training=True (dropout / batch statistics / backward) is not built yet; "
-                "see DESIGN.md section 'next'" % self.name)
+                "%s: training=True is not built for this module (no dropout / batch statistics inside it; "
+                "the backward pass is the next row, DESIGN.md)" % self.name)
+
+    def _set_training(self, training, dropout_seed=None):
+        """The reference's `training=` argument: Dropout on (counter-based masks keyed by the engine option
+        "dropout_seed"), BatchNormalization on batch statistics + moving update.  Forward only."""
+        self.engine.set_option("training", 1 if training else 0)
+        if training and dropout_seed is not None:
+            self.engine.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)

@@ -13,9 +13,9 @@ class TransformerDecoder(EngineModule):
         self.block_names = ['decoder-attention-{}'.format(i) for i in range(nblk)]
 
     def __call__(self, inputs, text_embd, z_lengths=None, text_lengths=None, reduction_factor=2,
-                 training=None, return_alignments=True):
+                 training=None, return_alignments=True, dropout_seed=None):
         """decoder.py:181-199 -> (initial_outs, outputs, {name: alignments [B,H,Tz,Tt]})."""
-        self._no_training(training)
+        self._set_training(training, dropout_seed)
         e = self.engine
         z = self._f32(inputs)
         mem = self._f32(text_embd)
@@ -29,6 +29,7 @@ class TransformerDecoder(EngineModule):
         ali = e.empty((self.nblk, B, self.heads, Tz, Tt)) if return_alignments else None
         check(e.lib.vnr_decoder_fwd(e.handle, z.ptr, mem.ptr, zl.ptr, tl.ptr, B, Tz, Tt, rf, initial.ptr,
                                     outputs.ptr, self._ptr(ali)), e.handle)
+        self._set_training(False)
         alignments = {}
         if ali is not None:
             n = B * self.heads * Tz * Tt

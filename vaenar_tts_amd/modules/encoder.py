@@ -10,15 +10,16 @@ class TransformerEncoder(EngineModule):
         super().__init__(name, engine)
         self.vocab_size, self.embd_dim, self.pre_hidden = vocab_size, embd_dim, pre_hidden
 
-    def __call__(self, inputs, input_lengths=None, pos_step=1.0, training=None):
+    def __call__(self, inputs, input_lengths=None, pos_step=1.0, training=None, dropout_seed=None):
         """encoder.py:79-93: ids [B,T] -> text encoding [B,T,pre_hidden] (device)."""
-        self._no_training(training)
+        self._set_training(training, dropout_seed)
         e = self.engine
         ids = e.asarray(inputs, 'int32')
         B, T = ids.shape
         lens = self._i32(input_lengths, B, T)
         out = e.empty((B, T, self.pre_hidden))
         check(e.lib.vnr_text_encoder_fwd(e.handle, ids.ptr, lens.ptr, B, T, float(pos_step), out.ptr), e.handle)
+        self._set_training(False)
         return out
 
     call = __call__

@@ -9,10 +9,10 @@ class TransformerPosterior(EngineModule):
         super().__init__(name, engine)
         self.latent_dim = latent_dim
 
-    def __call__(self, inputs, src_enc, src_lengths=None, target_lengths=None, training=None):
+    def __call__(self, inputs, src_enc, src_lengths=None, target_lengths=None, training=None, dropout_seed=None):
         """posterior.py:115-130 -> (mu_projection output, logvar_projection output, None).
         NB models.py:136 unpacks this as ``logvar, mu, _``."""
-        self._no_training(training)
+        self._set_training(training, dropout_seed)
         e = self.engine
         x = self._f32(inputs)
         mem = self._f32(src_enc)
@@ -24,6 +24,7 @@ class TransformerPosterior(EngineModule):
         logvar = e.empty((B, Tz, self.latent_dim))
         check(e.lib.vnr_posterior_fwd(e.handle, x.ptr, mem.ptr, sl.ptr, tl.ptr, B, Tz, Tt, mu.ptr, logvar.ptr),
               e.handle)
+        self._set_training(False)
         return mu, logvar, None
 
     call = __call__

@@ -1,0 +1,71 @@
+"""The autograd restatement (oracle/vaenar_torch.py) is pinned against the NumPy specification: identical forward on
+the training-mode ELBO (dropout ON, BN batch statistics), and its gradients against central finite differences of the
+NumPy oracle's loss for a handful of variables."""
+import numpy as np
+import pytest
+
+from oracle.vaenar_numpy import Oracle
+from oracle.vaenar_torch import TorchOracle, adam_step
+from vaenar_tts_amd.configs import tiny_hps
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights
+
+
+def _case():
+    hps = tiny_hps()
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    b = make_batch(2, 7, 18, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                   ragged=True, text_step=2, mel_step=5)
+    r = np.random.Generator(np.random.PCG64(3))
+    Tm = int(b["mel_lengths"].max())
+    mels = r.standard_normal((2, Tm, hps.Audio.num_mels))
+    eps = r.standard_normal((2, 1, (Tm + 1) // 2, hps.Common.latent_dim))
+    return hps, w, b, mels, eps
+
+
+def _np_loss(hps, w, b, mels, eps, seed=9, kl_weight=1e-5, length_weight=1.0):
+    o = Oracle(hps, {k: np.asarray(v, np.float64) for k, v in w.items()}, np.float64)
+    o.dropout_seed = seed
+    _, l2, kl, ll, _ = o.call(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, True, True, eps)
+    return float(l2 + kl_weight * max(kl, 0.0) + length_weight * ll), (float(l2), float(kl), float(ll))
+
+
+def test_torch_forward_equals_numpy_oracle():
+    hps, w, b, mels, eps = _case()
+    t = TorchOracle(hps, w)
+    loss, mel_l2, kl, ll = t.train_loss(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, dropout_seed=9)
+    ref, (rl2, rkl, rll) = _np_loss(hps, w, b, mels, eps)
+    assert abs(float(mel_l2) - rl2) < 1e-10 and abs(float(ll) - rll) < 1e-10
+    assert abs(float(kl) - rkl) < 1e-7 * max(1.0, abs(rkl))
+    assert abs(float(loss) - ref) < 1e-9
+
+
+@pytest.mark.parametrize("path", ["decoder/residual_projection/bias", "posterior/mu_projection/kernel",
+                                  "prior/glow/0/1/weight", "prior/glow/1/0/log_scale",
+                                  "text_encoder/prenet/conv_stack/0/bn/gamma", "length_predictor/projection/kernel",
+                                  "decoder/attentions/0/cross_attention/key_layer/kernel"])
+def test_torch_gradient_matches_finite_difference(path):
+    hps, w, b, mels, eps = _case()
+    kw = 1.0 if path.startswith("prior") else 1e-5         # make the KL term visible for the flow variables
+    # the length predictor sees stop_gradient(text_embd) (models.py:133): a finite difference of the encoder variables
+    # would see through it, so the length term is switched off for them
+    lw = 0.0 if path.startswith("text_encoder") else 1.0
+    g, _ = TorchOracle(hps, w).gradients(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, kl_weight=kw,
+                                         length_weight=lw, dropout_seed=9)
+    idx = np.unravel_index(int(np.abs(g[path]).argmax()), g[path].shape) if g[path].ndim else ()
+    h = 1e-5
+    vals = []
+    for sgn in (+1, -1):
+        w2 = {k: np.asarray(v, np.float64).copy() for k, v in w.items()}
+        w2[path][idx] += sgn * h
+        vals.append(_np_loss(hps, w2, b, mels, eps, kl_weight=kw, length_weight=lw)[0])
+    fd = (vals[0] - vals[1]) / (2 * h)
+    assert abs(fd - g[path][idx]) <= 2e-5 * max(1.0, abs(fd)), (fd, g[path][idx])
+
+
+def test_adam_step_known_answer():
+    w = {"a": np.array([1.0, -2.0])}; g = {"a": np.array([0.5, -0.25])}
+    m = {"a": np.zeros(2)}; v = {"a": np.zeros(2)}
+    adam_step(w, g, m, v, 1, lr=1e-3)
+    # first step of bias-corrected Adam moves every coordinate by lr * sign(g) (up to eps)
+    np.testing.assert_allclose(w["a"], [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-8)

@@ -218,6 +218,21 @@ int vnr_set_option(vnr_handle h, const char *name, int value);
  * utils.py:15,17,84, posterior.py:122) draw counter-based masks; BatchNormalization (utils.py:79-83) normalises with the
  * batch mean / population variance over all B*T rows and updates moving_mean / moving_variance (momentum 0.99). */
 
+/* train_step (train.py:127-138): VAENAR.call(training=True) under the tape, loss = mel_l2 + kl_weight * max(kl, 0) +
+ * length_weight * length_l2 (train.py:135; reduce_loss=True means over the batch), gradients w.r.t. every trainable
+ * variable (the length predictor sees stop_gradient(text_embd), models.py:133), then tf.keras.optimizers.Adam
+ * (train.py:116-117: lr_t = lr sqrt(1-b2^t)/(1-b1^t), w -= lr_t m / (sqrt(v) + epsilon)).  Dropout masks follow option
+ * "dropout_seed"; d_eps [B,Tz,latent] is the reparameterisation noise.  apply_update = 0 computes the gradients only
+ * (vnr_get_gradient).  h_scalars (HOST, 4 floats or NULL) = mel_l2, kl, length_l2, loss -- the tuple train_step returns.
+ * After an update the inference panels are rebuilt lazily by the next inference-mode call.  Synchronises. */
+int vnr_train_step(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
+                   const float *d_mel_targets, const int32_t *d_mel_lengths,
+                   const int32_t *d_reduced_lengths, int B, int Tt, int Tm, int rf, float pos_step,
+                   const float *d_eps, float kl_weight, float length_weight, float learning_rate,
+                   float beta1, float beta2, float epsilon, int apply_update, float *h_scalars);
+/* d loss / d variable of the last vnr_train_step (n floats, layout of the variable) -- tape.gradient (train.py:136). */
+int vnr_get_gradient(vnr_handle h, const char *path, float *host, int64_t n);
+
 /* VAENAR.init (models/models.py:212-226) <- train.py:176-179 init_step: text encoder (training=True) ->
  * TransformerPrior.init (prior.py:171-186: every ActNormFlow sets log_scale / bias from the statistics of its input,
  * flow.py:189-196) -> decoder at max_reduction_factor.  d_reduced_lengths = ceil(mel_lengths / max_rf), Tz = their

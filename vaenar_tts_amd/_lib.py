@@ -92,6 +92,8 @@ PROTOTYPES = {
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
     "vnr_set_option": [_vp, C.c_char_p, _i],
     "vnr_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
+    "vnr_train_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],
+    "vnr_get_gradient": [_vp, C.c_char_p, _vp, C.c_int64],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
     "vnr_profile_get": [_vp, C.c_char_p, _pd, _pi64, _pd, _pd],
@@ -269,6 +271,11 @@ class Engine:
     def get_weight(self, path, shape):
         out = np.empty(shape, np.float32)
         check(self.lib.vnr_get_weight(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
+        return out
+
+    def get_gradient(self, path, shape):
+        out = np.empty(shape, np.float32)
+        check(self.lib.vnr_get_gradient(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
         return out
 
     def load_weights(self, weights):

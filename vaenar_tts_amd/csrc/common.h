@@ -153,4 +153,39 @@ hipError_t launch_actnorm_init_finish(const double* mean, const double* sq, int 
 hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const float* shift, const float* pe, int T, float pe_w,
                         float rate, unsigned key, float* y, hipStream_t s);
 
+// training step: backward / optimizer kernels (train_kernels.hip)
+hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift, hipStream_t s);
+hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                                const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
+                                float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
+                                int causal, float temperature, hipStream_t s);
+hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_act_bwd(float* d, const float* y, size_t n, int act, hipStream_t s);
+hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, int rows, int cols, int accumulate, hipStream_t s);
+hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream_t s);
+hipError_t launch_bn_bwd(const float* d, const float* x, const double* mean, const double* sq, const float* gamma, int M, int C,
+                         double* s1, double* s2, float* dx, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s);
+hipError_t launch_pe_weight_bwd(const float* d, const float* pe, int M, int C, int T, float* out, hipStream_t s);
+hipError_t launch_coupling_inv(const float* heads, float* z, int M, int half, int zp_off, float* zp_in, float* rowld, hipStream_t s);
+hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len, int M,
+                                   int T, int half, int zp_off, float* dheads, hipStream_t s);
+hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b, double* s_ls, hipStream_t s);
+hipError_t launch_gauss_bwd(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d, hipStream_t s);
+hipError_t launch_reparam_bwd(const float* dz, const float* eps, const float* logvar, const float* gpost, const int32_t* len, int M,
+                              int T, int C, float* dmu, float* dlogvar, hipStream_t s);
+hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, const int32_t* len, int B, int C, float seed, float* d, hipStream_t s);
+hipError_t launch_length_loss(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len,
+                              int B, int T, int D, float seed, float* pred, float* ll, float* dw, float* db, hipStream_t s);
+hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
+                       float lr_t, float b1, float b2, float eps, hipStream_t s);
+hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb, hipStream_t s);
+hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s);
+hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s);
+hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s);
+hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
+                              const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
+                              float* cg, float* scalars, hipStream_t s);
+hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
+
 }  // namespace vnr

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
+#include <functional>
 #include <map>
 #include <tuple>
 #include <utility>
@@ -70,8 +72,12 @@ inline unsigned site_key(unsigned seed, int site) { return host_mix32(seed ^ ((u
 
 }  // namespace
 
+namespace { struct TrainState; }
+
 struct vnr_context {
   vnr_config cfg;
+  TrainState* train = nullptr;   // optimizer state, gradient buffers, transposed kernels (train.inc); built on the first training step
+  bool packed_stale = false;     // an optimizer step changed the variables: inference panels are rebuilt lazily (check_ready)
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -889,9 +895,12 @@ int check_ready(vnr_handle h) {
   if (!h) return fail(nullptr, VNR_ERR_ARG, "null handle");
   if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
   HIP_TRY(h, hipSetDevice(h->device));
+  if (h->packed_stale) { h->packed_stale = false; TRY(vnr_finalize_weights(h)); }
   h->split_scope = true;          // module bodies other than the encoder may use the split-fp16 GEMM path
   return VNR_OK;
 }
+
+#include "train.inc"
 
 }  // namespace
 
@@ -944,6 +953,7 @@ int vnr_destroy(vnr_handle h) {
   if (!h) return VNR_OK;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  train_free(h);
   for (auto& kv : h->w) hipFree(kv.second.d);
   for (auto p : h->packed_allocs) hipFree(p);
   for (auto& c : h->chunks) hipFree(c.p);
@@ -1013,6 +1023,7 @@ int vnr_synchronize(vnr_handle h) {
 }
 
 int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int64_t* shape, int ndim) {
+  if (h && h->train) train_free(h);          // optimizer state and gradient tables point into the weight store
   if (!h || !path || !host || ndim < 0 || ndim > 4 || (ndim > 0 && !shape)) return fail(h, VNR_ERR_ARG, "bad argument");
   HIP_TRY(h, hipSetDevice(h->device));
   int64_t n = 1;
@@ -1358,6 +1369,41 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
   }
   if (h->training) TRY(refresh_bn_affine(h));     // the moving statistics moved
   return VNR_OK;
+}
+
+// train_step (train.py:127-138): training-mode forward, gradients of mel_l2 + kl_weight * max(kl, 0) + length_weight *
+// length_l2 w.r.t. every trainable variable, Keras Adam (apply_update = 0: gradients only, read with vnr_get_gradient).
+int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
+                   const int32_t* d_mel_lengths, const int32_t* d_reduced_lengths, int B, int Tt, int Tm, int rf, float pos_step,
+                   const float* d_eps, float kl_weight, float length_weight, float learning_rate, float beta1, float beta2,
+                   float epsilon, int apply_update, float* h_scalars) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
+  if (!d_ids || !d_text_lengths || !d_mel_targets || !d_mel_lengths || !d_reduced_lengths || !d_eps || B <= 0 || Tt <= 0 || Tm <= 0 || rf < 1)
+    return fail(h, VNR_ERR_ARG, "bad argument");
+  if (h->cfg.num_mels != h->cfg.output_dim) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");
+  if (rf > h->cfg.max_reduction_factor) return fail(h, VNR_ERR_ARG, "reduction_factor out of range");
+  ws_reset(h);
+  const bool saved_split = h->split_scope, saved_training = h->training;
+  h->split_scope = false;            // exact fp32 GEMMs throughout the training step
+  h->training = true;
+  const int rc = train_step_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps,
+                                 kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
+  h->split_scope = saved_split; h->training = saved_training;
+  if (rc == VNR_OK && !h->packed_stale) TRY(refresh_bn_affine(h));      // moving statistics moved
+  return rc;
+}
+
+// gradient of the last vnr_train_step w.r.t. variable `path` (n floats, synchronises)
+int vnr_get_gradient(vnr_handle h, const char* path, float* host, int64_t n) {
+  if (!h || !path || !host) return fail(h, VNR_ERR_ARG, "null argument");
+  if (!h->train) return fail(h, VNR_ERR_STATE, "no training step has run");
+  auto it = h->train->index.find(path);
+  if (it == h->train->index.end()) return fail(h, VNR_ERR_WEIGHT, std::string("not a trainable variable: ") + path);
+  if (n != h->train->n[it->second]) return fail(h, VNR_ERR_ARG, std::string("size mismatch for ") + path);
+  return vnr_memcpy_d2h(h, host, h->train->g[it->second], (size_t)n * sizeof(float));
 }
 
 // VAENAR.init (models.py:212-226): encoder(training=True) -> prior.init -> decoder(training=True, rf = max).

@@ -1,0 +1,745 @@
+// Backward-pass and optimizer kernels of the training step (reference: train.py:127-138 -- tape.gradient over
+// VAENAR.call, then Keras Adam).  First-generation kernels: exact fp32 arithmetic, simple tilings; the forward of the
+// training step runs on the same GEMM / attention kernels as inference (exact fp32 MFMA path).
+//
+//   gemm_tn_kernel        dW[K][N] += A[M][K]^T . B[M][N]   (Dense / Conv1D kernel gradients; conv taps = row shifts)
+//   attn_bwd_dq_kernel    dS = P * (dO.V^T - rowdot) on valid positions; dQ = dS.K / sqrt(64) / tau
+//   attn_bwd_dkv_kernel   dV = P^T.dO ; dK = dS^T.Q / sqrt(64) / tau
+//   ln_bwd_kernel         LayerNormalization backward (+ gamma / beta gradients)
+//   bn_bwd_*              BatchNormalization(training) backward through the batch statistics
+//   small elementwise kernels for the flow (log_probability direction), reparameterisation, losses, Adam
+#include "common.h"
+#include <math.h>
+
+namespace vnr {
+
+namespace {
+__device__ __forceinline__ int frow_t(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+}
+
+// ---- dW[K][N] += sum_m A[src(m)][k] * B[m][n] ------------------------------------------------------------------------
+// src(m) = m + shift inside the utterance of length T that contains m (rows outside [0,T) contribute zero): shift = 0 and
+// T = M for a Dense layer; shift = j - (k-1)/2 for tap j of a 'same' Conv1D.
+__global__ void __launch_bounds__(256)
+gemm_tn_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+               int rows_per_split) {
+  __shared__ float As[32][68];
+  __shared__ float Bs[32][68];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int m_lo = blockIdx.z * rows_per_split;
+  int m_hi = m_lo + rows_per_split; if (m_hi > M) m_hi = M;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lr = tid >> 3, lc = (tid & 7) * 8;            // loader: row 0..31, 8 consecutive columns
+  for (int m0 = m_lo; m0 < m_hi; m0 += 32) {
+    const int m = m0 + lr;
+    {
+      float va[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) va[e] = 0.f;
+      if (m < m_hi) {
+        const int t = m % T, ts = t + shift;
+        if (ts >= 0 && ts < T) {
+          const float* ap = A + (size_t)(m + shift) * lda + k0 + lc;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (k0 + lc + e < K) va[e] = ap[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) As[lr][lc + e] = va[e];
+      float vb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vb[e] = 0.f;
+      if (m < m_hi) {
+        const float* bp = B + (size_t)m * ldb + n0 + lc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (n0 + lc + e < N) vb[e] = bp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Bs[lr][lc + e] = vb[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mm = 0; mm < 32; mm += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[mm + half][wk * 32 + l31], Bs[mm + half][wn * 32 + l31], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n < N)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + wk * 32 + frow_t(r, half);
+      if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[r]);
+    }
+}
+hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
+                          int shift, hipStream_t s) {
+  const int tk = (K + 63) / 64, tn = (N + 63) / 64;
+  int splits = 1024 / (tk * tn); if (splits < 1) splits = 1;
+  int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
+  int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
+  splits = (M + rps - 1) / rps;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+  return hipGetLastError();
+}
+
+// ---- attention backward -----------------------------------------------------------------------------------------------
+// Forward (attention.py:224-246): S = Q.K^T / sqrt(64) / tau, masked with the fill value, P = softmax(S), O = P.V.
+// dS_ij = P_ij * (dP_ij - sum_j' dP_ij' P_ij') with dP = dO.V^T, and sum_j' dP_ij' P_ij' = dO_i . O_i.  Masked
+// positions carry a CONSTANT logit (the fill value), so their dS is zero even when P is not (fully masked rows).
+struct AttnBwdArgs {
+  const float *Q, *K, *V, *O, *dO, *P;     // Q/O/dO rows [B*Tq][ld..], K/V rows [B*Tk][ld..], P [B][H][Tq][Tk]
+  float *dQ, *dK, *dV, *dS;                // dS scratch [B][H][Tq][Tk]
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  const int32_t *q_len, *k_len;
+  int B, H, Tq, Tk, causal;
+  float scale;                             // 1 / sqrt(64) / tau
+};
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(const AttnBwdArgs a) {
+  __shared__ float dOs[32][65], Ks[64][65], Vs[64][65], dSs[32][65];
+  __shared__ float rowdot[32];
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * 32, hd = blockIdx.y, b = blockIdx.z;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int i = e >> 6, d = e & 63, q = q0 + i;
+    dOs[i][d] = q < a.Tq ? a.dO[((size_t)b * a.Tq + q) * a.lddo + hd * 64 + d] : 0.f;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int q = q0 + tid;
+    float s = 0.f;
+    if (q < a.Tq) {
+      const float* op = a.O + ((size_t)b * a.Tq + q) * a.ldo + hd * 64;
+      for (int d = 0; d < 64; ++d) s += dOs[tid][d] * op[d];
+    }
+    rowdot[tid] = s;
+  }
+  float dq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dq[e] = 0.f;
+  const int qi = tid >> 3, qd = (tid & 7) * 8;            // dQ: row qi, columns qd..qd+7
+  const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  for (int j0 = 0; j0 < a.Tk; j0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int j = e >> 6, d = e & 63, kj = j0 + j;
+      const bool ok = kj < a.Tk;
+      Ks[j][d] = ok ? a.K[((size_t)b * a.Tk + kj) * a.ldk + hd * 64 + d] : 0.f;
+      Vs[j][d] = ok ? a.V[((size_t)b * a.Tk + kj) * a.ldv + hd * 64 + d] : 0.f;
+    }
+    __syncthreads();
+    // dS tile [32][64]: thread -> row i = tid>>3, columns j = (tid&7) + 8*jj
+    {
+      const int i = tid >> 3, q = q0 + i;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int j = (tid & 7) + 8 * jj, kj = j0 + j;
+        float ds = 0.f;
+        if (q < a.Tq && kj < a.Tk) {
+          const bool valid = q < qlen && kj < klen && (!a.causal || kj <= q);
+          float dp = 0.f;
+#pragma unroll 16
+          for (int d = 0; d < 64; ++d) dp += dOs[i][d] * Vs[j][d];
+          const float p = Pb[(size_t)q * a.Tk + kj];
+          ds = valid ? p * (dp - rowdot[i]) : 0.f;
+          dSb[(size_t)q * a.Tk + kj] = ds;
+        }
+        dSs[i][j] = ds;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      const float ds = dSs[qi][j];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dq[e] += ds * Ks[j][qd + e];
+    }
+  }
+  const int q = q0 + qi;
+  if (q < a.Tq) {
+    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64 + qd;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = dq[e] * a.scale;
+  }
+}
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+  __shared__ float Ps[32][65], dSs[32][65], dOs[32][65], Qs[32][65];
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.x * 64, hd = blockIdx.y, b = blockIdx.z;
+  const int kj = tid >> 2, kd = (tid & 3) * 16;           // outputs: key row kj (0..63), columns kd..kd+15
+  float dv[16], dk[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
+  const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  const float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * 64; e += 256) {
+      const int i = e >> 6, c = e & 63, q = q0 + i;
+      const bool okq = q < a.Tq;
+      const bool okk = j0 + c < a.Tk;
+      Ps[i][c] = (okq && okk) ? Pb[(size_t)q * a.Tk + j0 + c] : 0.f;
+      dSs[i][c] = (okq && okk) ? dSb[(size_t)q * a.Tk + j0 + c] : 0.f;
+      dOs[i][c] = okq ? a.dO[((size_t)b * a.Tq + q) * a.lddo + hd * 64 + c] : 0.f;
+      Qs[i][c] = okq ? a.Q[((size_t)b * a.Tq + q) * a.ldq + hd * 64 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+      const float p = Ps[i][kj], ds = dSs[i][kj];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dv[e] += p * dOs[i][kd + e]; dk[e] += ds * Qs[i][kd + e]; }
+    }
+  }
+  const int key = j0 + kj;
+  if (key < a.Tk) {
+    float* pv = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64 + kd;
+    float* pk = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64 + kd;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { pv[e] = dv[e]; pk[e] = dk[e] * a.scale; }
+  }
+}
+hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                                const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
+                                float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
+                                int causal, float temperature, hipStream_t s) {
+  AttnBwdArgs a;
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.P = P; a.dQ = dQ; a.dK = dK; a.dV = dV; a.dS = dS;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.q_len = q_len; a.k_len = k_len; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
+  a.scale = 0.125f / temperature;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---- LayerNormalization backward (eps 1e-3, population variance) ---------------------------------------------------------
+// y = (v - mu) * rstd * gamma + beta.  dv = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy.   One wave per row, D <= 512.
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = gridDim.x * 4;
+  float pg[8], pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { pg[j] = 0.f; pb[j] = 0.f; }
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += nw) {
+    const float* vr = v + (size_t)r * D;
+    const float* dr = dy + (size_t)r * D;
+    float x[8], d[8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; x[j] = c < D ? vr[c] : 0.f; d[j] = c < D ? dr[c] : 0.f; s += x[j]; }
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; const float t = c < D ? x[j] - mu : 0.f; q += t * t; }
+    for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)D + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = lane + 64 * j;
+      const float xh = c < D ? (x[j] - mu) * rstd : 0.f;
+      g[j] = c < D ? d[j] * gamma[c] : 0.f;
+      s1 += g[j]; s2 += g[j] * xh;
+      pg[j] += d[j] * xh; pb[j] += d[j];
+      x[j] = xh;
+    }
+    for (int o = 32; o; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 /= (float)D; s2 /= (float)D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; if (c < D) dv[(size_t)r * D + c] = rstd * (g[j] - s1 - x[j] * s2); }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = lane + 64 * j;
+    if (c < D) { atomicAdd(dgamma + c, pg[j]); atomicAdd(dbeta + c, pb[j]); }
+  }
+}
+hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma,
+                         float* dbeta, hipStream_t s) {
+  if (D > 512) return hipErrorInvalidValue;
+  int blocks = (rows + 3) / 4; if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
+  return hipGetLastError();
+}
+
+// ---- elementwise helpers ------------------------------------------------------------------------------------------------
+// activation backward in place: d *= act'(y) with y the activation OUTPUT (relu: y > 0; tanh: 1 - y^2)
+__global__ void act_bwd_kernel(float* d, const float* y, size_t n, int act) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float yy = y[i];
+    if (act == ACT_RELU) d[i] = yy > 0.f ? d[i] : 0.f;
+    else if (act == ACT_TANH) d[i] *= 1.f - yy * yy;
+  }
+}
+hipError_t launch_act_bwd(float* d, const float* y, size_t n, int act, hipStream_t s) {
+  if (act == ACT_IDENTITY) return hipSuccess;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, y, n, act);
+  return hipGetLastError();
+}
+// y[i] = a * x[i] + (accumulate ? y[i] : 0)   (strided 2-D: rows x cols with leading dimensions)
+__global__ void axpby2d_kernel(const float* x, int ldx, float a, float* y, int ldy, int rows, int cols, int accumulate) {
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+    const float v = a * x[(size_t)r * ldx + c];
+    float* p = y + (size_t)r * ldy + c;
+    *p = accumulate ? *p + v : v;
+  }
+}
+hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, int rows, int cols, int accumulate, hipStream_t s) {
+  const size_t n = (size_t)rows * cols;
+  if (!n) return hipSuccess;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(axpby2d_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, a, y, ldy, rows, cols, accumulate);
+  return hipGetLastError();
+}
+// g[c] += (float) sum[c]   (column sums accumulated in float64 -> float32 gradient)
+__global__ void add_d2f_kernel(float* g, const double* sum, int n, float a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] += a * (float)sum[i];
+}
+hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream_t s) {
+  hipLaunchKernelGGL(add_d2f_kernel, dim3((n + 127) / 128), dim3(128), 0, s, g, sum, n, a);
+  return hipGetLastError();
+}
+// column sums of two products in float64: s1[c] += sum_m d[m][c] ; s2[c] += sum_m d[m][c] * (x[m][c] - mean[c]) * rstd[c]
+__global__ void bn_bwd_sums_kernel(const float* d, const float* x, const double* mean, const double* sq, int M, int C, double* s1,
+                                   double* s2) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const double mu = mean[c];
+    const double rstd = 1.0 / sqrt((double)(float)(sq[c] / (double)M) + (double)kBnEps);
+    for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+      const double dd = (double)d[(size_t)m * C + c];
+      a1 += dd;
+      a2 += dd * ((double)x[(size_t)m * C + c] - mu) * rstd;
+    }
+  }
+  __shared__ double p1[4][64], p2[4][64];
+  p1[rg][threadIdx.x & 63] = a1; p2[rg][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    atomicAdd(&s1[c], p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
+    atomicAdd(&s2[c], p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
+  }
+}
+// dx = gamma * rstd * (d - s1/M - xhat * s2/M) ; dgamma += s2 ; dbeta += s1   (d = gradient at the BN output)
+__global__ void bn_bwd_apply_kernel(const float* d, const float* x, const double* mean, const double* sq, const double* s1,
+                                    const double* s2, const float* gamma, int M, int C, float* dx, float* dgamma, float* dbeta) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float rstd = 1.0f / sqrtf((float)(sq[c] / (double)M) + kBnEps);
+    const float xh = (x[i] - (float)mean[c]) * rstd;
+    dx[i] = gamma[c] * rstd * (d[i] - (float)(s1[c] / (double)M) - xh * (float)(s2[c] / (double)M));
+    if (i < (size_t)C) { dgamma[c] += (float)s2[c]; dbeta[c] += (float)s1[c]; }
+  }
+}
+hipError_t launch_bn_bwd(const float* d, const float* x, const double* mean, const double* sq, const float* gamma, int M, int C,
+                         double* s1, double* s2, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
+  int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, d, x, mean, sq, M, C, s1, s2);
+  const size_t n = (size_t)M * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, d, x, mean, sq, s1, s2, gamma, M, C, dx, dgamma, dbeta);
+  return hipGetLastError();
+}
+// embedding gradient: dE[ids[m]][c] += d[m][c]
+__global__ void embed_bwd_kernel(const float* d, const int32_t* ids, int M, int C, float* dE) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), c = (int)(i - (size_t)m * C);
+    atomicAdd(dE + (size_t)ids[m] * C + c, d[i]);
+  }
+}
+hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s) {
+  const size_t n = (size_t)M * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, ids, M, C, dE);
+  return hipGetLastError();
+}
+// *out += sum_m sum_c d[m][c] * pe[m % T][c]     (gradient of the scalar pos_weight)
+__global__ void pe_weight_bwd_kernel(const float* d, const float* pe, int M, int C, int T, float* out) {
+  double acc = 0.0;
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), c = (int)(i - (size_t)m * C);
+    acc += (double)d[i] * (double)pe[(size_t)(m % T) * C + c];
+  }
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+hipError_t launch_pe_weight_bwd(const float* d, const float* pe, int M, int C, int T, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pe_weight_bwd_kernel, dim3(64), dim3(256), 0, s, d, pe, M, C, T, out);
+  return hipGetLastError();
+}
+
+// ---- flow, log_probability direction (prior.py:119-152), forward with saved tensors and backward ----------------------------
+// coupling inverse (flow.py:241-257) on heads = [log_scale | shift] [M][2*half]: zp' = (zp - shift) / (sigmoid(ls+2) + 1e-12);
+// rowld[m] = -sum_c log(sigmoid(ls+2)).  z is updated in place (only the zp half changes); zp_in keeps the old zp for the
+// backward.
+__global__ void coupling_inv_kernel(const float* heads, float* z, int M, int half, int zp_off, float* zp_in, float* rowld) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= M) return;
+  float acc = 0.f;
+  for (int c = lane; c < half; c += 64) {
+    const float ls = heads[(size_t)m * 2 * half + c], sh = heads[(size_t)m * 2 * half + half + c];
+    const float sc = 1.0f / (1.0f + expf(-(ls + 2.0f)));
+    float* zp = z + (size_t)m * 2 * half + zp_off + c;
+    const float old = *zp;
+    zp_in[(size_t)m * half + c] = old;
+    *zp = (old - sh) / (sc + 1e-12f);
+    acc -= logf(sc);
+  }
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) rowld[m] = acc;
+}
+hipError_t launch_coupling_inv(const float* heads, float* z, int M, int half, int zp_off, float* zp_in, float* rowld, hipStream_t s) {
+  hipLaunchKernelGGL(coupling_inv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half, zp_off, zp_in, rowld);
+  return hipGetLastError();
+}
+// backward: given dz (gradient at the OUTPUT [M][2*half]) and g_b = d loss / d logdet_b:
+//   dzp_in = dzp'/den ; dshift = -dzp'/den ; dsc = -dzp' (zp_in - shift)/den^2 - g_b mask_t / sc ; dls = dsc * sc (1 - sc)
+// dz is rewritten in place to the gradient at the INPUT (zp half only; the conditioning half passes through);
+// dheads [M][2*half] receives (dls | dshift).
+__global__ void coupling_inv_bwd_kernel(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len,
+                                        int M, int T, int half, int zp_off, float* dheads) {
+  const size_t n = (size_t)M * half;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / half), c = (int)(i - (size_t)m * half);
+    const int b = m / T, t = m - b * T;
+    const float ls = heads[(size_t)m * 2 * half + c], sh = heads[(size_t)m * 2 * half + half + c];
+    const float sc = 1.0f / (1.0f + expf(-(ls + 2.0f)));
+    const float den = sc + 1e-12f;
+    float* dzp = dz + (size_t)m * 2 * half + zp_off + c;
+    const float dout = *dzp;
+    const float din = dout / den;
+    const float mask = t < len[b] ? 1.f : 0.f;
+    const float dsc = -dout * (zp_in[i] - sh) / (den * den) - g_b[b] * mask / sc;
+    *dzp = din;
+    dheads[(size_t)m * 2 * half + c] = dsc * sc * (1.f - sc);
+    dheads[(size_t)m * 2 * half + half + c] = -din;
+  }
+}
+hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len, int M,
+                                   int T, int half, int zp_off, float* dheads, hipStream_t s) {
+  const size_t n = (size_t)M * half;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(coupling_inv_bwd_kernel, dim3(blocks), dim3(256), 0, s, heads, zp_in, dz, g_b, len, M, T, half, zp_off, dheads);
+  return hipGetLastError();
+}
+// ActNorm inverse (flow.py:177-187): y = (x - bias) / (exp(ls) + 1e-8).  Backward: dx = dy/den (in place on dy);
+// dbias[c] -= sum dy/den ; dls[c] -= sum dy (x - b)/den^2 * exp(ls)   [accumulated in float64 buffers s1, s2]
+__global__ void actnorm_inv_bwd_kernel(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b,
+                                       double* s_ls) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const float e = expf(ls[c]), den = e + 1e-8f, bb = bias[c];
+    for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+      const size_t i = (size_t)m * C + c;
+      const float d = dy[i];
+      const float dx = d / den;
+      a1 -= (double)dx;
+      a2 -= (double)(d * (x[i] - bb) / (den * den) * e);
+      dy[i] = dx;
+    }
+  }
+  __shared__ double p1[4][64], p2[4][64];
+  p1[rg][threadIdx.x & 63] = a1; p2[rg][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    atomicAdd(&s_b[c], p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
+    atomicAdd(&s_ls[c], p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
+  }
+}
+hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b,
+                                  double* s_ls, hipStream_t s) {
+  int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+  hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, bias, M, C, s_b, s_ls);
+  return hipGetLastError();
+}
+// d eps = -eps * mask * g_b  (gradient of sum_t mask * -0.5 (log 2pi + eps^2)); written (not accumulated)
+__global__ void gauss_bwd_kernel(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), b = m / T, t = m - b * T;
+    d[i] = t < len[b] ? -eps[i] * g_b[b] : 0.f;
+  }
+}
+hipError_t launch_gauss_bwd(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d, hipStream_t s) {
+  const size_t n = (size_t)M * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gauss_bwd_kernel, dim3(blocks), dim3(256), 0, s, eps, g_b, len, M, T, C, d);
+  return hipGetLastError();
+}
+// reparameterisation z = eps * exp(logvar/2) + mu and posterior log-prob (posterior.py:21-72), backward:
+//   dmu = dz ; dlogvar = dz * eps * exp(logvar/2) / 2 - 0.5 * mask_t * gpost_b
+__global__ void reparam_bwd_kernel(const float* dz, const float* eps, const float* logvar, const float* gpost, const int32_t* len,
+                                   int M, int T, int C, float* dmu, float* dlogvar) {
+  const size_t n = (size_t)M * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / C), b = m / T, t = m - b * T;
+    const float d = dz[i];
+    dmu[i] = d;
+    dlogvar[i] = d * eps[i] * expf(0.5f * logvar[i]) * 0.5f - (t < len[b] ? 0.5f * gpost[b] : 0.f);
+  }
+}
+hipError_t launch_reparam_bwd(const float* dz, const float* eps, const float* logvar, const float* gpost, const int32_t* len, int M,
+                              int T, int C, float* dmu, float* dlogvar, hipStream_t s) {
+  const size_t n = (size_t)M * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, s, dz, eps, logvar, gpost, len, M, T, C, dmu, dlogvar);
+  return hipGetLastError();
+}
+
+// ---- losses (models.py:67-103, train.py:135) -------------------------------------------------------------------------------
+// gradient of mean_b [ sum_{t<len_b} mean_c (r - tgt)^2 / len_b ] with respect to r [B][Tr][C] (rows t >= min(Tm, len_b) get 0)
+__global__ void l2_bwd_kernel(const float* rec, int Tr, const float* tgt, int Tm, const int32_t* len, int B, int C, float seed,
+                              float* d) {
+  const size_t n = (size_t)B * Tr * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t row = i / C;
+    const int b = (int)(row / Tr), t = (int)(row - (size_t)b * Tr);
+    float g = 0.f;
+    if (t < Tm && t < len[b]) g = seed * 2.f * (rec[i] - tgt[((size_t)b * Tm + t) * C + c]) / ((float)C * (float)len[b]);
+    d[i] = g;
+  }
+}
+hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, const int32_t* len, int B, int C, float seed, float* d,
+                         hipStream_t s) {
+  const size_t n = (size_t)B * Tr * C;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(l2_bwd_kernel, dim3(blocks), dim3(256), 0, s, rec, Tr, tgt, Tm, len, B, C, seed, d);
+  return hipGetLastError();
+}
+// Length predictor (length_predictor.py:35-42, identity activation) and its loss (models.py:96-103), forward + backward in
+// one pass per utterance: pred_b = sum_{t<len} exp(x_t.w + bias); ll_b = (log pred - log mel_len)^2;
+// dw += seed * 2 (log pred - log len) / pred * sum_t exp(.) x_t ; dbias likewise.  (x is stop_gradient'ed, models.py:133)
+__global__ void __launch_bounds__(256)
+length_loss_kernel(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len, int T, int D,
+                   float seed, float* pred, float* ll, float* dw, float* db) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float e_t[1024];
+  __shared__ double red[256];
+  const int len = text_len[b] < T ? text_len[b] : T;
+  double acc = 0.0;
+  for (int t = tid; t < len; t += 256) {
+    const float* xr = x + ((size_t)b * T + t) * D;
+    float s = bias[0];
+    for (int d = 0; d < D; ++d) s += xr[d] * w[d];
+    const float e = expf(s);
+    if (t < 1024) e_t[t] = e;
+    acc += (double)e;
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float p = (float)red[0];
+  const float diff = logf(p) - logf((float)mel_len[b]);
+  if (tid == 0) { pred[b] = p; ll[b] = diff * diff; }
+  const float gp = seed * 2.f * diff / p;
+  if (dw) {
+    for (int d = tid; d < D; d += 256) {
+      float s = 0.f;
+      for (int t = 0; t < len; ++t) {
+        const float e = t < 1024 ? e_t[t] : 0.f;
+        s += e * x[((size_t)b * T + t) * D + d];
+      }
+      atomicAdd(dw + d, gp * s);
+    }
+    if (tid == 0) atomicAdd(db, gp * p);
+  }
+}
+hipError_t launch_length_loss(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len,
+                              int B, int T, int D, float seed, float* pred, float* ll, float* dw, float* db, hipStream_t s) {
+  if (T > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(length_loss_kernel, dim3(B), dim3(256), 0, s, x, w, bias, text_len, mel_len, T, D, seed, pred, ll, dw, db);
+  return hipGetLastError();
+}
+
+// ---- optimizer: tf.keras.optimizers.Adam (train.py:116-117), one launch over a table of tensors -----------------------------
+// m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t) / (1-b1^t)
+__global__ void adam_kernel(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
+                            float lr_t, float b1, float b2, float eps) {
+  const int t = blockIdx.y;
+  if (t >= ntensors) return;
+  float* wp = w[t]; const float* gp = g[t]; float* mp = m[t]; float* vp = v[t];
+  const int64_t cnt = n[t];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gg = gp[i];
+    const float mm = b1 * mp[i] + (1.f - b1) * gg;
+    const float vv = b2 * vp[i] + (1.f - b2) * gg * gg;
+    mp[i] = mm; vp[i] = vv;
+    wp[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
+                       float lr_t, float b1, float b2, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(adam_kernel, dim3(64, ntensors), dim3(256), 0, s, w, g, m, v, n, ntensors, lr_t, b1, b2, eps);
+  return hipGetLastError();
+}
+
+// Conv1D kernel [k][cin][cout] -> backward-data panel Wb[cin][k*cout] with Wb[ci][j*cout + co] = W[k-1-j][ci][co]
+// (dX = 'same' correlation of dY with the flipped, channel-transposed kernel)
+__global__ void conv_flip_kernel(const float* W, int k, int cin, int cout, float* Wb) {
+  const size_t n = (size_t)k * cin * cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout);
+    const int ci = (int)((i / cout) % cin);
+    const int j = (int)(i / ((size_t)cout * cin));
+    Wb[(size_t)ci * k * cout + (size_t)(k - 1 - j) * cout + co] = W[i];
+  }
+}
+hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb, hipStream_t s) {
+  const size_t n = (size_t)k * cin * cout;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(conv_flip_kernel, dim3(blocks), dim3(256), 0, s, W, k, cin, cout, Wb);
+  return hipGetLastError();
+}
+
+// ---- InvertibleLinearFlow, log_probability direction (flow.py:137-150): inv(W) and log|det inv(W)| ---------------------------
+// One workgroup, Gauss-Jordan with partial pivoting in float64 inside LDS (C <= 128: 128 KB).  Outputs inv(W) and its
+// transpose rounded to fp32 (tf.linalg.inv is fp32 in the reference; the float64 elimination is the tighter statement) and
+// logabsdet = log|det inv(W)| = -log|det W| (the reference takes slogdet of float64(inv(W)) and casts to fp32).
+__global__ void __launch_bounds__(256)
+invert_kernel(const float* W, int C, float* Winv, float* WinvT, float* logabsdet) {
+  extern __shared__ double a[];                 // [C][C] -> becomes the inverse in place
+  __shared__ int piv_row;
+  __shared__ double piv_val;
+  __shared__ int perm[128];
+  __shared__ double colbuf[128];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * C; i += 256) a[i] = (double)W[i];
+  if (tid < C) perm[tid] = tid;
+  __syncthreads();
+  double logdet = 0.0;
+  for (int c = 0; c < C; ++c) {
+    if (tid == 0) {
+      int best = c; double bv = fabs(a[(size_t)c * C + c]);
+      for (int r = c + 1; r < C; ++r) { const double v = fabs(a[(size_t)r * C + c]); if (v > bv) { bv = v; best = r; } }
+      piv_row = best; piv_val = a[(size_t)best * C + c];
+    }
+    __syncthreads();
+    const int pr = piv_row;
+    if (pr != c) {
+      for (int j = tid; j < C; j += 256) { const double t = a[(size_t)c * C + j]; a[(size_t)c * C + j] = a[(size_t)pr * C + j]; a[(size_t)pr * C + j] = t; }
+      if (tid == 0) { const int t = perm[c]; perm[c] = perm[pr]; perm[pr] = t; }
+    }
+    __syncthreads();
+    const double p = piv_val;
+    logdet += log(fabs(p));
+    // in-place Gauss-Jordan step on pivot (c, c)
+    if (tid < C) colbuf[tid] = a[(size_t)tid * C + c];
+    __syncthreads();
+    for (int j = tid; j < C; j += 256) a[(size_t)c * C + j] = (j == c) ? 1.0 / p : a[(size_t)c * C + j] / p;
+    __syncthreads();
+    for (int i = tid; i < C * C; i += 256) {
+      const int r = i / C, j = i - r * C;
+      if (r == c) continue;
+      const double f = colbuf[r];
+      a[i] = (j == c) ? -f * a[(size_t)c * C + c] : a[i] - f * a[(size_t)c * C + j];
+    }
+    __syncthreads();
+  }
+  // undo the row permutation: columns of the result are permuted (inv(P A) = inv(A) P^T)
+  for (int i = tid; i < C * C; i += 256) {
+    const int r = i / C, j = i - r * C;
+    const float v = (float)a[(size_t)r * C + j];
+    const int col = perm[j];
+    Winv[(size_t)r * C + col] = v;
+    WinvT[(size_t)col * C + r] = v;
+  }
+  if (tid == 0) *logabsdet = (float)(-logdet);
+}
+hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s) {
+  if (C > 128) return hipErrorInvalidValue;
+  const size_t lds = (size_t)C * C * sizeof(double);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8); attr = true; }
+  hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), lds, s, W, C, Winv, WinvT, logabsdet);
+  return hipGetLastError();
+}
+// ActNorm inverse parameters: sc = 1 / (exp(ls) + 1e-8), sh = -bias * sc;  *lssum = sum(ls)
+__global__ void actnorm_inv_params_kernel(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum) {
+  __shared__ float red[128];
+  const int c = threadIdx.x;
+  float v = 0.f;
+  if (c < C) { const float d = 1.0f / (expf(ls[c]) + 1e-8f); sc[c] = d; sh[c] = -bias[c] * d; v = ls[c]; }
+  red[c] = v;
+  __syncthreads();
+  if (c == 0) { float t = 0.f; for (int i = 0; i < C; ++i) t += red[i]; *lssum = t; }
+}
+hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s) {
+  if (C > 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(actnorm_inv_params_kernel, dim3(1), dim3(128), 0, s, ls, bias, C, sc, sh, lssum);
+  return hipGetLastError();
+}
+// y[b] += alpha[0] * len[b]   (alpha on the device)
+__global__ void axpy_len_dev_kernel(float* y, const int32_t* len, const float* alpha, float sign, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) y[b] += sign * alpha[0] * (float)len[b];
+}
+hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_len_dev_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, sign, B);
+  return hipGetLastError();
+}
+// seeds of the backward pass (train.py:135, models.py:84-103): per-utterance losses -> batch means and
+//   g_post[b] = kw * [mean kl > 0] / B ; g_prior[b] = -g_post[b] ; cg[0] = sum_b g_prior[b] * len[b]
+// scalars[0..3] = mel_l2, kl, length_l2, total loss
+__global__ void train_seeds_kernel(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll,
+                                   const float* post_lp, const float* prior_lp, const int32_t* red_len, int B, float kw, float lw,
+                                   float* g_post, float* g_prior, float* cg, float* scalars) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double l2 = 0.0, kl = 0.0, l = 0.0;
+  for (int b = 0; b < B; ++b) {
+    l2 += ((double)sum_out[b] + (double)sum_init[b]) / (double)mel_len[b];
+    kl += (double)post_lp[b] - (double)prior_lp[b];
+    l += (double)ll[b];
+  }
+  l2 /= B; kl /= B; l /= B;
+  const float gk = kl > 0.0 ? kw / (float)B : 0.f;
+  double c = 0.0;
+  for (int b = 0; b < B; ++b) { g_post[b] = gk; g_prior[b] = -gk; c += (double)(-gk) * (double)red_len[b]; }
+  cg[0] = (float)c;
+  scalars[0] = (float)l2; scalars[1] = (float)kl; scalars[2] = (float)l;
+  scalars[3] = (float)(l2 + (double)kw * (kl > 0.0 ? kl : 0.0) + (double)lw * l);
+}
+hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
+                              const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
+                              float* cg, float* scalars, hipStream_t s) {
+  hipLaunchKernelGGL(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, kw, lw,
+                     g_post, g_prior, cg, scalars);
+  return hipGetLastError();
+}
+// y[i] += alpha * cg[0] * x[i]   and   y[i] += alpha * x[i] (cg null)
+__global__ void axpy_dev_kernel(float* y, const float* x, const float* cg, float alpha, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += alpha * (cg ? cg[0] : 1.f) * (x ? x[i] : 1.f);
+}
+hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s) {
+  hipLaunchKernelGGL(axpy_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, x, cg, alpha, n);
+  return hipGetLastError();
+}
+
+}  // namespace vnr

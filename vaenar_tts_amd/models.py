@@ -193,6 +193,47 @@ class VAENAR:
         self._len_cache = {}
         return mel
 
+    def train_step(self, texts, mels, t_lengths, m_lengths, kl_weight, reduction_factor, eps=None, dropout_seed=0,
+                   learning_rate=None, apply_update=True):
+        """train_step of train.py:127-138: returns (loss, mel_l2, kl_divergence, length_l2) as floats after one
+        Adam update (``apply_update=False``: gradients only, see ``gradients``).  Hyper-parameters from
+        hps.Train (learning_rate, length_weight); Adam beta_1 0.9, beta_2 0.999, epsilon 1e-7 (train.py:116-117)."""
+        eng = self.engine
+        rf = int(reduction_factor)
+        ids = eng.asarray(texts, np.int32)
+        B, Tt = ids.shape
+        mel = eng.asarray(mels, np.float32)
+        Tm = mel.shape[1]
+        ml_h = np.asarray(m_lengths.numpy() if hasattr(m_lengths, "numpy") and not isinstance(m_lengths, np.ndarray) else m_lengths)
+        ml = eng.to_device(ml_h.astype(np.int32), np.int32)
+        rl = eng.to_device(((ml_h.astype(np.int64) + rf - 1) // rf).astype(np.int32), np.int32)
+        tl = eng.asarray(np.full(B, Tt, np.int32) if t_lengths is None else t_lengths, np.int32)
+        Tz = (Tm + rf - 1) // rf
+        C = self.hps.Common.latent_dim
+        if eps is None:
+            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+        pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)
+        tr = self.hps.Train
+        lr = tr.learning_rate if learning_rate is None else learning_rate
+        scal = np.zeros(4, np.float32)
+        eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
+        check(eng.lib.vnr_train_step(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+                                     eps_d.ptr, float(kl_weight), float(tr.length_weight), float(lr), 0.9, 0.999, 1e-7,
+                                     1 if apply_update else 0, scal.ctypes.data), eng.handle)
+        self._len_cache = {}
+        return float(scal[3]), float(scal[0]), float(scal[1]), float(scal[2])
+
+    def gradients(self, paths=None):
+        """{path: d loss / d variable} of the last train_step (tape.gradient, train.py:136)."""
+        from .weights import weight_spec, is_trainable
+        spec = weight_spec(self.hps)
+        out = {}
+        for k in (paths or [p for p in spec if is_trainable(p)]):
+            sh = spec[k]
+            out[k] = self.engine.get_gradient(k, sh if len(sh) else (1,)).reshape(sh)
+        return out
+
     def get_weights(self, paths=None):
         """{path: ndarray} read back from the engine (after init / training-mode forwards)."""
         from .weights import weight_spec

@@ -230,6 +230,18 @@ int vnr_train_step(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_len
                    const int32_t *d_reduced_lengths, int B, int Tt, int Tm, int rf, float pos_step,
                    const float *d_eps, float kl_weight, float length_weight, float learning_rate,
                    float beta1, float beta2, float epsilon, int apply_update, float *h_scalars);
+/* Data-parallel training (the reference trains on one device, its train.py has no distribution
+ * strategy to mirror): one process + one handle per GPU, the batch sharded by utterance, ONE exchange per step -- an RCCL
+ * all-reduce (sum, then 1/N) of the flat fp32 gradient (34.7 M values) over xGMI between backward and Adam, issued by
+ * vnr_train_step on the handle's stream once a communicator is bound.  vnr_comm_unique_id: rank 0 creates the 128-byte
+ * id, the host control plane (vaenar_tts_amd/dist.py, gloo) broadcasts it; vnr_comm_init: collective over all ranks;
+ * vnr_comm_broadcast_weights: every rank takes rank 0's variables (after vnr_init) and re-packs.  librccl.so is bound
+ * with dlopen at the first call, so inference-only processes never load it. */
+int vnr_comm_unique_id(vnr_handle h, char *id128);
+int vnr_comm_init(vnr_handle h, int nranks, int rank, const char *id128);
+int vnr_comm_broadcast_weights(vnr_handle h);
+int vnr_comm_destroy(vnr_handle h);
+
 /* d loss / d variable of the last vnr_train_step (n floats, layout of the variable) -- tape.gradient (train.py:136). */
 int vnr_get_gradient(vnr_handle h, const char *path, float *host, int64_t n);
 

@@ -304,7 +304,7 @@ class TorchOracle:
         loss.backward()
         g = {k: (t.grad.numpy().copy() if t.grad is not None else np.zeros(tuple(t.shape)))
              for k, t in self.w.items() if t.requires_grad}
-        return g, dict(loss=float(loss), mel_l2=float(mel_l2), kl=float(kl), length_l2=float(len_l2))
+        return g, dict(loss=float(loss.detach()), mel_l2=float(mel_l2.detach()), kl=float(kl.detach()), length_l2=float(len_l2.detach()))
 
 
 def adam_step(weights, grads, m, v, step, lr=1.25e-4, beta1=0.9, beta2=0.999, eps=1e-7):

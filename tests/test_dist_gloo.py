@@ -67,3 +67,64 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _train_worker(rank, world, port, out_dir):
+    """Data-parallel training, host side: the RCCL id travels as bytes, every rank keeps its shard of the global batch,
+    and the gradient that the ranks average equals the gradient of the global batch when the per-rank losses are means
+    over equally sized shards (the device all-reduce is replaced by a gloo all-reduce of the autograd oracle's gradients)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as tdist
+    from oracle.vaenar_torch import TorchOracle
+    from vaenar_tts_amd import dist
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.weights import init_weights
+    dist.init("gloo")
+    uid = dist.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+    assert uid == bytes(range(128))
+    hps = tiny_hps()
+    w = init_weights(hps, seed=5)
+    batch = make_batch(4, 7, 16, latent_dim=hps.Common.latent_dim, ragged=False)
+    r = np.random.Generator(np.random.PCG64(1))
+    batch["mels"] = r.standard_normal((4, 16, hps.Audio.num_mels))
+    batch["eps"] = r.standard_normal((4, 8, hps.Common.latent_dim))
+    sh = dist.shard_batch(batch, rank, world)
+    assert sh["mels"].shape[0] == 2
+    o = TorchOracle(hps, w)
+    o.update_moving_stats = False
+    # dropout off and rates irrelevant: BatchNorm batch statistics are per replica (SURVEY section 8e), so compare a
+    # variable downstream of no BatchNorm: the posterior heads and the flow
+    g, sc = o.gradients(sh["ids"], sh["mels"], sh["mel_lengths"], sh["text_lengths"], 2, sh["eps"], kl_weight=1.0, dropout_seed=None)
+    key = "prior/glow/0/0/log_scale"
+    t = torch.tensor(g[key]); tdist.all_reduce(t); t /= world
+    assert abs(dist.mean_over_ranks(float(rank)) - 0.5) < 1e-12
+    if rank == 0:
+        np.save(os.path.join(out_dir, "avg_grad.npy"), t.numpy())
+    dist.barrier()
+
+
+def test_data_parallel_gradient_average_world2(tmp_path):
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle.vaenar_torch import TorchOracle
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.weights import init_weights
+    hps = tiny_hps()
+    batch = make_batch(4, 7, 16, latent_dim=hps.Common.latent_dim, ragged=False)
+    r = np.random.Generator(np.random.PCG64(1))
+    mels = r.standard_normal((4, 16, hps.Audio.num_mels)); eps = r.standard_normal((4, 8, hps.Common.latent_dim))
+    o = TorchOracle(hps, init_weights(hps, seed=5))
+    o.update_moving_stats = False
+    g, _ = o.gradients(batch["ids"], mels, batch["mel_lengths"], batch["text_lengths"], 2, eps, kl_weight=1.0, dropout_seed=None)
+    got = np.load(tmp_path / "avg_grad.npy")
+    # the ActNorm log_scale of the LAST flow step applied in log_probability order sees z only through the posterior,
+    # whose PreNet / blocks contain no BatchNorm but whose input text_embd does (encoder prenet): per-replica batch
+    # statistics make the sharded average differ slightly from the global-batch gradient -- same sign, same scale
+    ref = g["prior/glow/0/0/log_scale"]
+    assert np.corrcoef(got, ref)[0, 1] > 0.99 and abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) < 0.1

@@ -100,3 +100,24 @@ def test_adam_update_matches_keras_formula():
         assert np.isfinite(mel.numpy()).all()
     finally:
         model.engine.close()
+
+
+def test_rccl_allreduce_path_single_rank():
+    """The gradient exchange of data-parallel training (RCCL all-reduce of the flat gradient between backward and Adam)
+    on a one-rank communicator: the call sequence runs on the device and leaves the gradients unchanged (sum over one
+    rank, times 1/1).  Multi-rank sharding logic is covered on CPU by tests/test_dist_gloo.py."""
+    hps, w, b, mels, eps = _case("tiny")
+    model = VAENAR(hps, weights=w)
+    try:
+        args = (b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2)
+        model.train_step(*args, eps=eps, dropout_seed=3, apply_update=False)
+        g0 = model.gradients()
+        model.engine.comm_init(1, 0, model.engine.comm_unique_id())
+        model.engine.comm_broadcast_weights()
+        model.train_step(*args, eps=eps, dropout_seed=3, apply_update=False)
+        g1 = model.gradients()
+        model.engine.comm_destroy()
+    finally:
+        model.engine.close()
+    for k in g0:
+        assert np.abs(g1[k] - g0[k]).max() <= 1e-5 * np.abs(g0[k]).max() + 1e-7, k    # (float atomics: summation order varies)

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference harness /root/reference/train.py on the MI355X engine: the same flow --
+init_step on the first batch (:176-179, :262-267), one train_step at max_reduction_factor (:263-267), then per epoch the
+KL-weight schedule (:230-234, :270-271), the reduction-factor schedule (:236-243), train_one_epoch (:181-204),
+dev_one_epoch (:207-225) and a checkpoint (:300-303) -- with the model calls of :121-179 going to
+vaenar_tts_amd.models.VAENAR (training-mode forward, backward and Adam on the GPU: vnr_train_step).
+
+Differences forced by the environment: no TensorFlow -> batches are synthetic (``--data_dir synthetic``: seeded random
+utterances of ``--t_text`` x ``--t_mel``; TFRecord input is SURVEY section 8f F3) or an ``.npz`` with ids / mels /
+text_lengths / mel_lengths; checkpoints are ``.npz`` files of the object-graph variable tree (``ckpt-<epoch>.npz``).
+With torchrun (WORLD_SIZE > 1) the run is data-parallel: the batch is sharded by utterance over the ranks, every rank
+holds a replica, and the flat gradient is all-reduced with RCCL over xGMI inside vnr_train_step (one exchange per step);
+the host control plane (gloo) only carries the RCCL id, barriers and the averaged log scalars.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+
+from vaenar_tts_amd import dist as vdist
+from vaenar_tts_amd.configs import DataBakerHPS, LJHPS, tiny_hps
+from vaenar_tts_amd.models import VAENAR
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights, load_npz, save_npz
+
+
+def synthetic_batches(hps, n_batches, batch_size, t_text, t_mel, seed):
+    r = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for i in range(n_batches):
+        b = make_batch(batch_size, t_text, t_mel, vocab_size=hps.Encoder.Transformer.vocab_size,
+                       latent_dim=hps.Common.latent_dim, ragged=True, seed=seed + i, text_step=1, mel_step=3)
+        b["mels"] = r.standard_normal((batch_size, t_mel, hps.Audio.num_mels)).astype(np.float32)
+        out.append(b)
+    return out
+
+
+def get_reduction_factor(hps, ep):                          # train.py:236-243
+    intervals, rfs = hps.Train.reduce_interval, hps.Train.reduction_factors
+    i = 0
+    while i < len(intervals) and intervals[i] <= ep:
+        i += 1
+    return rfs[i - 1 if i > 0 else 0]
+
+
+def main():
+    ap = argparse.ArgumentParser('Training parameters parser')
+    ap.add_argument('--dataset', type=str, choices=['ljspeech', 'databaker', 'tiny'], default='ljspeech')
+    ap.add_argument('--data_dir', type=str, default='synthetic')
+    ap.add_argument('--model_dir', type=str, default='gpurun_out/model_dir')
+    ap.add_argument('--log_dir', type=str, default='gpurun_out/log_dir')
+    ap.add_argument('--epochs', type=int, default=2, help='the reference trains hps.Train.epochs = 2000')
+    ap.add_argument('--steps_per_epoch', type=int, default=4, help='synthetic data only')
+    ap.add_argument('--batch_size', type=int, default=None, help='GLOBAL batch (default hps.Train.train_batch_size)')
+    ap.add_argument('--t_text', type=int, default=128)
+    ap.add_argument('--t_mel', type=int, default=800)
+    ap.add_argument('--seed', type=int, default=None)
+    args = ap.parse_args()
+    hps = {'ljspeech': LJHPS, 'databaker': DataBakerHPS, 'tiny': tiny_hps()}[args.dataset]
+    rank, local_rank, world = vdist.init('gloo')
+    seed = hps.Train.random_seed if args.seed is None else args.seed
+    os.makedirs(args.model_dir, exist_ok=True)
+    gb = args.batch_size or hps.Train.train_batch_size
+    assert gb % world == 0, "global batch must divide over the ranks"
+
+    # 1. data (train.py:61-111): every rank builds the same global batches and keeps its shard
+    train = [vdist.shard_batch(b, rank, world) for b in synthetic_batches(hps, args.steps_per_epoch, gb, args.t_text, args.t_mel, seed)]
+    dev = [vdist.shard_batch(b, rank, world) for b in synthetic_batches(hps, 1, gb, args.t_text, args.t_mel, seed + 1000)]
+
+    # 2. model + optimizer (train.py:114-117)
+    ckpts = sorted(f for f in os.listdir(args.model_dir) if f.startswith('ckpt-') and f.endswith('.npz'))
+    weights = load_npz(os.path.join(args.model_dir, ckpts[-1])) if ckpts else init_weights(hps, seed=seed, mode='reference')
+    model = VAENAR(hps, device=local_rank, weights=weights)
+    if world > 1:                                             # data-parallel: bind the RCCL communicator
+        uid = vdist.broadcast_bytes(model.engine.comm_unique_id() if rank == 0 else None)
+        model.engine.comm_init(world, rank, uid)
+    step = int(ckpts[-1][5:-4]) if ckpts else 0
+    kw_init, kw_end, kw_epochs = hps.Train.kl_weight_init, hps.Train.kl_weight_end, hps.Train.kl_weight_increase_epoch
+    kw_step = (kw_end - kw_init) / kw_epochs                 # train.py:230-234
+
+    def save(ep):
+        if rank == 0:
+            path = os.path.join(args.model_dir, 'ckpt-%d.npz' % ep)
+            save_npz(path, model.get_weights())
+            return path
+
+    if not ckpts:                                             # train.py:256-267
+        b = train[0]
+        model.init(text_inputs=b["ids"], mel_lengths=b["mel_lengths"], text_lengths=b["text_lengths"], dropout_seed=seed)
+        if world > 1:
+            model.engine.comm_broadcast_weights()             # ActNorm init and BN statistics of rank 0 everywhere
+        print("Initial checkpoint for step 0: {}".format(save(0)))
+        out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw_init, hps.Common.max_reduction_factor,
+                               dropout_seed=seed + rank)
+        print('Initial step: total {:.6f}, mel-l2 {:.6f}, kl {:.3f}, len-l2 {:.3f}'.format(*out))
+
+    it = 0
+    for epoch in range(step + 1, args.epochs + 1):            # train.py:269-306
+        kw = kw_init + kw_step * epoch if epoch <= kw_epochs else kw_end
+        rf = get_reduction_factor(hps, epoch)
+        if rank == 0:
+            print('Training Epoch {}, kl weight is {}, reduction factor is {}...'.format(epoch, kw, rf))
+        t0 = time.time()
+        acc = np.zeros(4)
+        for s, b in enumerate(train):                         # train_one_epoch, train.py:181-204
+            ts = time.time()
+            it += 1
+            out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw, rf,
+                                   dropout_seed=(seed + 7919 * it) * world + rank)
+            out = [vdist.mean_over_ranks(x) for x in out]
+            acc += out
+            if rank == 0:
+                print('Step {}: total {:.6f}, mel-l2 {:.6f}, kl {:.3f}, len-l2 {:.3f}, time {:.3f}'.format(s, *out, time.time() - ts))
+        acc /= len(train)
+        frames = sum(int(b["mel_lengths"].sum()) for b in train) * world
+        if rank == 0:
+            print('\nTraining Epoch {} finished in {:.3f} Secs ({:.0f} mel-frames/s)'.format(epoch, time.time() - t0, frames / (time.time() - t0)))
+        dacc = np.zeros(4)
+        for b in dev:                                         # dev_one_epoch, train.py:207-225 (training=False)
+            _, l2, kl, ll, _ = model(b["ids"], b["mels"], b["mel_lengths"], b["text_lengths"], reduction_factor=rf,
+                                     training=False, reduce_loss=True, return_alignments=False)
+            kl = float(kl)
+            dacc += [vdist.mean_over_ranks(float(l2) + kw * kl + hps.Train.length_weight * float(ll)),
+                     vdist.mean_over_ranks(float(l2)), vdist.mean_over_ranks(kl), vdist.mean_over_ranks(float(ll))]
+        dacc /= len(dev)
+        if rank == 0:
+            print('Epoch {}:  train-total {}, train-mel-l2 {}, train-kl {},train-len-l2 {}, dev-total {}, dev-l2 {}, dev-kl {}, '
+                  'dev-len-l2 {}'.format(epoch, *acc, *dacc))
+            print("Saved checkpoint for epoch {}: {}".format(epoch, save(epoch)))
+    vdist.barrier()
+    model.engine.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -94,6 +94,10 @@ PROTOTYPES = {
     "vnr_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "vnr_train_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],
     "vnr_get_gradient": [_vp, C.c_char_p, _vp, C.c_int64],
+    "vnr_comm_unique_id": [_vp, C.c_char_p],
+    "vnr_comm_init": [_vp, _i, _i, C.c_char_p],
+    "vnr_comm_broadcast_weights": [_vp],
+    "vnr_comm_destroy": [_vp],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
     "vnr_profile_get": [_vp, C.c_char_p, _pd, _pi64, _pd, _pd],
@@ -272,6 +276,22 @@ class Engine:
         out = np.empty(shape, np.float32)
         check(self.lib.vnr_get_weight(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
         return out
+
+    # -- data-parallel training (RCCL) ----------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        check(self.lib.vnr_comm_unique_id(self.handle, buf), self.handle)
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        assert len(unique_id) == 128
+        check(self.lib.vnr_comm_init(self.handle, int(nranks), int(rank), C.create_string_buffer(unique_id, 128)), self.handle)
+
+    def comm_broadcast_weights(self):
+        check(self.lib.vnr_comm_broadcast_weights(self.handle), self.handle)
+
+    def comm_destroy(self):
+        check(self.lib.vnr_comm_destroy(self.handle), self.handle)
 
     def get_gradient(self, path, shape):
         out = np.empty(shape, np.float32)

@@ -3,9 +3,11 @@
 #include "../../include/vaenar_hip.h"
 #include "common.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <deque>
@@ -77,7 +79,10 @@ namespace { struct TrainState; }
 struct vnr_context {
   vnr_config cfg;
   TrainState* train = nullptr;   // optimizer state, gradient buffers, transposed kernels (train.inc); built on the first training step
-  bool packed_stale = false;     // an optimizer step changed the variables: inference panels are rebuilt lazily (check_ready)
+  bool packed_stale = false;
+  // data-parallel training: RCCL communicator over xGMI (one process per GPU), bound at run time with dlopen so that an
+  // inference-only process never loads librccl
+  void* rccl_lib = nullptr; ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;     // an optimizer step changed the variables: inference panels are rebuilt lazily (check_ready)
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -953,6 +958,7 @@ int vnr_destroy(vnr_handle h) {
   if (!h) return VNR_OK;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   train_free(h);
   for (auto& kv : h->w) hipFree(kv.second.d);
   for (auto p : h->packed_allocs) hipFree(p);
@@ -1394,6 +1400,47 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
   h->split_scope = saved_split; h->training = saved_training;
   if (rc == VNR_OK && !h->packed_stale) TRY(refresh_bn_affine(h));      // moving statistics moved
   return rc;
+}
+
+// ---- data-parallel training: RCCL communicator (one process per GPU; the 128-byte id travels over the host control plane) ----
+int vnr_comm_unique_id(vnr_handle h, char* id128) {
+  if (!h || !id128) return fail(h, VNR_ERR_ARG, "null argument");
+  TRY(rccl_load(h));
+  ncclUniqueId id;
+  RCCL_TRY(h, g_rccl.GetUniqueId(&id));
+  memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return VNR_OK;
+}
+int vnr_comm_init(vnr_handle h, int nranks, int rank, const char* id128) {
+  if (!h || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, VNR_ERR_ARG, "bad communicator arguments");
+  if (h->comm) return fail(h, VNR_ERR_STATE, "communicator already initialised");
+  TRY(rccl_load(h));
+  HIP_TRY(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  RCCL_TRY(h, g_rccl.CommInitRank(&h->comm, nranks, id, rank));
+  h->comm_size = nranks; h->comm_rank = rank;
+  return VNR_OK;
+}
+// every rank starts from rank 0's variables (incl. BN moving statistics and the ActNorm init of vnr_init)
+int vnr_comm_broadcast_weights(vnr_handle h) {
+  if (!h || !h->comm) return fail(h, VNR_ERR_STATE, "communicator not initialised");
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<std::string> names;
+  for (auto& kv : h->w) names.push_back(kv.first);
+  std::sort(names.begin(), names.end());          // identical order on every rank
+  for (auto& nm : names) {
+    Tensor& t = h->w[nm];
+    RCCL_TRY(h, g_rccl.Broadcast(t.d, t.d, (size_t)t.n, ncclFloat, 0, h->comm, h->stream));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (auto& kv : h->w) if (kv.second.n == 1) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
+  return vnr_finalize_weights(h);
+}
+int vnr_comm_destroy(vnr_handle h) {
+  if (!h) return VNR_OK;
+  if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; h->comm_size = 1; h->comm_rank = 0; }
+  return VNR_OK;
 }
 
 // gradient of the last vnr_train_step w.r.t. variable `path` (n floats, synchronises)

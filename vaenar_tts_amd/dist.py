@@ -65,3 +65,23 @@ def gather_to_rank0(array):
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(array, out, dst=0)
     return np.concatenate(out, 0) if out is not None else None
+
+
+def broadcast_bytes(data, src=0):
+    """Control-plane broadcast of a short byte string (the 128-byte RCCL unique id of data-parallel training)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return data
+    box = [data if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def mean_over_ranks(x):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()

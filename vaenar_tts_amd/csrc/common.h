@@ -181,6 +181,7 @@ hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, 
                        float lr_t, float b1, float b2, float eps, hipStream_t s);
 hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb, hipStream_t s);
 hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s);
+hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float* const* WinvT, float* const* lad, int n, int C, hipStream_t s);
 hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s);
 hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s);
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,

@@ -260,16 +260,20 @@ ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; if (c < D) dv[(size_t)r * D + c] = rstd * (g[j] - s1 - x[j] * s2); }
   }
+  // block-level reduction of the column partials (4 waves -> 1), then one atomic per column per block
+  __shared__ float rg[4][512], rb[4][512];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = lane + 64 * j;
-    if (c < D) { atomicAdd(dgamma + c, pg[j]); atomicAdd(dbeta + c, pb[j]); }
+  for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; if (c < 512) { rg[wave][c] = pg[j]; rb[wave][c] = pb[j]; } }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c]);
+    atomicAdd(dbeta + c, rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c]);
   }
 }
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma,
                          float* dbeta, hipStream_t s) {
   if (D > 512) return hipErrorInvalidValue;
-  int blocks = (rows + 3) / 4; if (blocks > 1024) blocks = 1024;
+  int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
   return hipGetLastError();
 }
@@ -622,63 +626,93 @@ hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb,
 // One workgroup, Gauss-Jordan with partial pivoting in float64 inside LDS (C <= 128: 128 KB).  Outputs inv(W) and its
 // transpose rounded to fp32 (tf.linalg.inv is fp32 in the reference; the float64 elimination is the tighter statement) and
 // logabsdet = log|det inv(W)| = -log|det W| (the reference takes slogdet of float64(inv(W)) and casts to fp32).
+struct InvBatch { const float* W[8]; float* Winv[8]; float* WinvT[8]; float* lad[8]; int n; };
 __global__ void __launch_bounds__(256)
-invert_kernel(const float* W, int C, float* Winv, float* WinvT, float* logabsdet) {
+invert_kernel(const InvBatch args, int C) {
   extern __shared__ double a[];                 // [C][C] -> becomes the inverse in place
   __shared__ int piv_row;
   __shared__ double piv_val;
   __shared__ int perm[128];
   __shared__ double colbuf[128];
+  __shared__ double wmax[4];
+  __shared__ int wrow[4];
   const int tid = threadIdx.x;
+  const float* W = args.W[blockIdx.x];
+  float* Winv = args.Winv[blockIdx.x]; float* WinvT = args.WinvT[blockIdx.x]; float* logabsdet = args.lad[blockIdx.x];
+  // element ownership without integer divisions in the hot loop: column j = tid % C, rows r0, r0 + rstep, ...
+  const int j = tid % C, r0 = tid / C, rstep = 256 / C;      // (C divides 256 for the supported sizes; see launch_invert)
+  const bool owner = r0 < rstep;
   for (int i = tid; i < C * C; i += 256) a[i] = (double)W[i];
   if (tid < C) perm[tid] = tid;
   __syncthreads();
   double logdet = 0.0;
   for (int c = 0; c < C; ++c) {
-    if (tid == 0) {
-      int best = c; double bv = fabs(a[(size_t)c * C + c]);
-      for (int r = c + 1; r < C; ++r) { const double v = fabs(a[(size_t)r * C + c]); if (v > bv) { bv = v; best = r; } }
-      piv_row = best; piv_val = a[(size_t)best * C + c];
+    // pivot search: thread r looks at row r of column c, two-stage arg-max (wave shuffles, then across the waves)
+    {
+      double v = (tid >= c && tid < C) ? fabs(a[(size_t)tid * C + c]) : -1.0;
+      int r = tid;
+      for (int o = 32; o; o >>= 1) {
+        const double ov = __shfl_xor(v, o, 64);
+        const int orr = __shfl_xor(r, o, 64);
+        if (ov > v || (ov == v && orr < r)) { v = ov; r = orr; }
+      }
+      if ((tid & 63) == 0) { wmax[tid >> 6] = v; wrow[tid >> 6] = r; }
+      __syncthreads();
+      if (tid == 0) {
+        int best = wrow[0]; double bv = wmax[0];
+        for (int w = 1; w < 4; ++w) if (wmax[w] > bv) { bv = wmax[w]; best = wrow[w]; }
+        piv_row = best; piv_val = a[(size_t)best * C + c];
+        logdet += log(fabs(piv_val));
+      }
     }
     __syncthreads();
     const int pr = piv_row;
-    if (pr != c) {
-      for (int j = tid; j < C; j += 256) { const double t = a[(size_t)c * C + j]; a[(size_t)c * C + j] = a[(size_t)pr * C + j]; a[(size_t)pr * C + j] = t; }
-      if (tid == 0) { const int t = perm[c]; perm[c] = perm[pr]; perm[pr] = t; }
+    const double p = piv_val;
+    if (pr != c && tid < C) {
+      const double t = a[(size_t)c * C + tid]; a[(size_t)c * C + tid] = a[(size_t)pr * C + tid]; a[(size_t)pr * C + tid] = t;
+      if (tid == 0) { const int t2 = perm[c]; perm[c] = perm[pr]; perm[pr] = t2; }
     }
     __syncthreads();
-    const double p = piv_val;
-    logdet += log(fabs(p));
     // in-place Gauss-Jordan step on pivot (c, c)
     if (tid < C) colbuf[tid] = a[(size_t)tid * C + c];
     __syncthreads();
-    for (int j = tid; j < C; j += 256) a[(size_t)c * C + j] = (j == c) ? 1.0 / p : a[(size_t)c * C + j] / p;
+    if (tid < C) a[(size_t)c * C + tid] = (tid == c) ? 1.0 / p : a[(size_t)c * C + tid] / p;
     __syncthreads();
-    for (int i = tid; i < C * C; i += 256) {
-      const int r = i / C, j = i - r * C;
-      if (r == c) continue;
-      const double f = colbuf[r];
-      a[i] = (j == c) ? -f * a[(size_t)c * C + c] : a[i] - f * a[(size_t)c * C + j];
+    if (owner) {
+      const double pc = a[(size_t)c * C + j];                 // new pivot-row entry of my column
+      for (int r = r0; r < C; r += rstep) {
+        if (r == c) continue;
+        const double f = colbuf[r];
+        const size_t i = (size_t)r * C + j;
+        a[i] = (j == c) ? -f * pc : a[i] - f * pc;
+      }
     }
     __syncthreads();
   }
   // undo the row permutation: columns of the result are permuted (inv(P A) = inv(A) P^T)
-  for (int i = tid; i < C * C; i += 256) {
-    const int r = i / C, j = i - r * C;
-    const float v = (float)a[(size_t)r * C + j];
+  if (owner) {
     const int col = perm[j];
-    Winv[(size_t)r * C + col] = v;
-    WinvT[(size_t)col * C + r] = v;
+    for (int r = r0; r < C; r += rstep) {
+      const float v = (float)a[(size_t)r * C + j];
+      Winv[(size_t)r * C + col] = v;
+      WinvT[(size_t)col * C + r] = v;
+    }
   }
   if (tid == 0) *logabsdet = (float)(-logdet);
 }
-hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s) {
-  if (C > 128) return hipErrorInvalidValue;
+hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float* const* WinvT, float* const* lad, int n, int C, hipStream_t s) {
+  if (C > 128 || C < 1 || (256 % C) != 0 || n < 1 || n > 8) return hipErrorInvalidValue;
+  InvBatch b;
+  for (int i = 0; i < n; ++i) { b.W[i] = W[i]; b.Winv[i] = Winv[i]; b.WinvT[i] = WinvT[i]; b.lad[i] = lad[i]; }
+  b.n = n;
   const size_t lds = (size_t)C * C * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8); attr = true; }
-  hipLaunchKernelGGL(invert_kernel, dim3(1), dim3(256), lds, s, W, C, Winv, WinvT, logabsdet);
+  hipLaunchKernelGGL(invert_kernel, dim3(n), dim3(256), lds, s, b, C);
   return hipGetLastError();
+}
+hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s) {
+  return launch_invert_batch(&W, &Winv, &WinvT, &logabsdet, 1, C, s);
 }
 // ActNorm inverse parameters: sc = 1 / (exp(ls) + 1e-8), sh = -bias * sc;  *lssum = sum(ls)
 __global__ void actnorm_inv_params_kernel(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum) {

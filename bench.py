@@ -173,17 +173,41 @@ def main():
         orc = Oracle(hps, weights, np.float32)
         ref = None
         t_cpu = []
-        for _ in range(args.cpu_iters):
+        for _ in range(max(1, args.cpu_iters - 1)):
             t1 = time.perf_counter()
             ref, _ = orc.inference(batch["ids"], batch["mel_lengths"], batch["text_lengths"], rf, batch["eps"])
             t_cpu.append(time.perf_counter() - t1)
-        best = min(t_cpu)
+        best_np = min(t_cpu)
+        # second stand-in: the torch-CPU restatement in fp32 (oneDNN / MKL GEMMs, all host cores) -- the
+        # closest thing in class to the reference's TF2 + MKL-DNN CPU path.  The FASTER of the two is the baseline.
+        best_t, t_threads = None, None
+        try:
+            import torch
+            from oracle.vaenar_torch import TorchOracle
+            torc = TorchOracle(hps, weights, torch.float32)
+            # the GEMMs of one S1 batch are too small for every core of a large host: sweep the thread count and keep the
+            # best (16 threads on the 256-CPU GPU box; more threads are slower)
+            cand = sorted({n for n in (8, 16, 32, min(32, torch.get_num_threads())) if n <= (os.cpu_count() or 1)})
+            for n in cand:
+                torch.set_num_threads(n)
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    torc.inference(batch["ids"], batch["mel_lengths"], batch["text_lengths"], rf, batch["eps"])
+                    d = time.perf_counter() - t1
+                    if best_t is None or d < best_t:
+                        best_t, t_threads = d, n
+        except Exception:
+            pass
+        use_torch = best_t is not None and best_t < best_np
+        best = best_t if use_torch else best_np
         out["cpu_baseline"] = {
-            "value": B * Tm / best, "unit": "mel-frames/s", "cores": int(threads), "kind": "port",
-            "sample": "the full S1 batch (16 x 800 frames), best of %d runs of oracle/vaenar_numpy.py in fp32 "
-                      "(NumPy/OpenBLAS); the reference's TF2-CPU path cannot run here (no TensorFlow)"
-                      % args.cpu_iters,
+            "value": B * Tm / best, "unit": "mel-frames/s", "cores": int(t_threads if use_torch else threads), "kind": "port",
+            "sample": "the full S1 batch (16 x 800 frames), best run of %s; the reference's TF2-CPU path cannot run here (no "
+                      "TensorFlow)" % ("oracle/vaenar_torch.py in fp32 (torch CPU: oneDNN/MKL, %d threads)" % t_threads if use_torch
+                                       else "oracle/vaenar_numpy.py in fp32 (NumPy/OpenBLAS)"),
             "seconds_per_batch": best, "host_cpus": os.cpu_count(),
+            "candidates_mel_frames_per_s": {"numpy_fp32_oracle": B * Tm / best_np,
+                                            "torch_cpu_fp32_restatement": (B * Tm / best_t) if best_t else None},
         }
         got = mel.numpy()
         out["parity"] = {"max_abs_mel_err": float(np.abs(got - ref).max()),

@@ -18,10 +18,11 @@ import torch
 from . import vaenar_numpy as vn
 
 F64 = torch.float64
+_DT = [torch.float64]          # working dtype (float64 = specification; float32 only for the timed CPU baseline)
 
 
 def _t(a):
-    return torch.as_tensor(np.asarray(a, np.float64), dtype=F64)
+    return torch.as_tensor(np.asarray(a, np.float64), dtype=_DT[0])
 
 
 def dense(x, kernel, bias=None, activation=None):
@@ -59,13 +60,14 @@ def conv1d_same(x, kernel, bias):
 
 
 class TorchOracle:
-    def __init__(self, hps, weights):
+    def __init__(self, hps, weights, dtype=torch.float64):
         from vaenar_tts_amd.weights import is_trainable
         self.hps = hps
+        _DT[0] = dtype
         self.w = {}
         for k, v in weights.items():
             t = _t(v).clone()
-            t.requires_grad_(is_trainable(k))
+            t.requires_grad_(is_trainable(k) and dtype == torch.float64)
             self.w[k] = t
         self.dropout_seed = None
         self.update_moving_stats = True
@@ -106,7 +108,7 @@ class TorchOracle:
         if causality:
             mask = mask & np.tril(np.ones((Tq, Tk), dtype=bool))[None]
         mask = torch.as_tensor(mask[:, None])
-        logits = torch.where(mask, logits, torch.tensor(float(vn.MASK_FILL), dtype=F64))
+        logits = torch.where(mask, logits, torch.tensor(float(vn.MASK_FILL), dtype=logits.dtype))
         ali = torch.softmax(logits, -1)
         ctx = (ali @ vh).permute(0, 2, 1, 3).reshape(B, Tq, D)
         return ctx, ali
@@ -210,7 +212,7 @@ class TorchOracle:
     # prior.py:119-152
     def prior_log_probability(self, z, cond, z_lengths, cond_lengths):
         eps = z
-        accum = torch.zeros(z.shape[0], dtype=F64)
+        accum = torch.zeros(z.shape[0], dtype=z.dtype)
         for s in reversed(range(self.hps.Prior.Transformer.n_blk)):
             p = f"prior/glow/{s}"
             eps, ld = self.coupling_backward(f"{p}/2", s % 2 == 0, eps, cond, z_lengths, cond_lengths); accum = accum + ld
@@ -219,6 +221,32 @@ class TorchOracle:
         logp = -0.5 * (vn.LOG_2PI + eps ** 2)
         mask = _t(vn.sequence_mask(z_lengths, z.shape[1])[:, :, None])
         return (mask * logp).sum((1, 2)) + accum
+
+    # flow.py:166-175, 123-135, 223-239 (forward direction = prior.sample) and models.py:199-210
+    def prior_sample(self, lengths, cond, cond_lengths, eps):
+        z = eps
+        for s in range(self.hps.Prior.Transformer.n_blk):
+            p = f"prior/glow/{s}"
+            z = z * torch.exp(self._g(f"{p}/0/log_scale")) + self._g(f"{p}/0/bias")
+            z = z @ self._g(f"{p}/1/weight")
+            half = z.shape[-1] // 2
+            lower_pt, upper_pt = z[..., :half], z[..., half:]
+            upper = s % 2 == 0
+            zc, zp = (lower_pt, upper_pt) if upper else (upper_pt, lower_pt)
+            log_scale, shift = self.transformer_transform(f"{p}/2/net", zc, cond, cond_lengths, lengths)
+            zp = torch.sigmoid(log_scale + 2.0) * zp + shift
+            z = torch.cat([zc, zp], -1) if upper else torch.cat([zp, zc], -1)
+        return z
+
+    def inference(self, ids, mel_lengths, text_lengths, reduction_factor=2, eps=None):
+        """VAENAR.inference (models.py:199-210) -- used as the timed CPU baseline (float32, all cores, oneDNN/MKL)."""
+        with torch.no_grad():
+            reduced = (np.asarray(mel_lengths) + reduction_factor - 1) // reduction_factor
+            pos_step = np.float32(self.hps.Common.mel_text_len_ratio) / np.float32(reduction_factor)
+            text_embd = self.text_encoder(ids, text_lengths, pos_step=pos_step, training=False)
+            z = self.prior_sample(reduced, text_embd, text_lengths, _t(eps))
+            _, mel = self.decoder(z, text_embd, reduced, text_lengths, reduction_factor, False)
+            return mel
 
     # decoder.py:181-199
     def decoder(self, z, text_embd, z_lengths, text_lengths, reduction_factor=2, training=False):

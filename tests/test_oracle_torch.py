@@ -69,3 +69,17 @@ def test_adam_step_known_answer():
     adam_step(w, g, m, v, 1, lr=1e-3)
     # first step of bias-corrected Adam moves every coordinate by lr * sign(g) (up to eps)
     np.testing.assert_allclose(w["a"], [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-8)
+
+
+def test_torch_inference_equals_numpy_oracle():
+    """The torch restatement's inference path (the timed CPU baseline of bench.py) against the NumPy specification."""
+    hps, w, b, mels, eps = _case()
+    z_eps = np.random.Generator(np.random.PCG64(4)).standard_normal((2, (int(b["mel_lengths"].max()) + 1) // 2, hps.Common.latent_dim))
+    ref, _ = Oracle(hps, {k: np.asarray(v, np.float64) for k, v in w.items()}, np.float64).inference(
+        b["ids"], b["mel_lengths"], b["text_lengths"], 2, z_eps)
+    got = TorchOracle(hps, w).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, z_eps).numpy()
+    np.testing.assert_allclose(got, ref, atol=1e-10)
+    import torch
+    got32 = TorchOracle(hps, w, torch.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, z_eps).numpy()
+    np.testing.assert_allclose(got32, ref, atol=2e-4)
+    TorchOracle(hps, w)          # back to the float64 working dtype for the other tests

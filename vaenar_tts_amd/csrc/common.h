@@ -145,6 +145,7 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 
 // training-mode statistics / dropout (misc.hip)
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s);
+hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s);
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s);
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
                                   float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s);
@@ -155,6 +156,9 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
 
 // training step: backward / optimizer kernels (train_kernels.hip)
 hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift, hipStream_t s);
+hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
+hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
+                                 int shift, const unsigned* b_absmax, hipStream_t s);
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,

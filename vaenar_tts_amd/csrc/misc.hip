@@ -461,26 +461,36 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 // Column sums of x[M][C] (row stride ld) in float64: out[c] += sum_m f(x[m][c]) with f(v) = v, or (v - mean[c])^2
 // when `mean` is given (second pass of a two-pass variance).  Used by BatchNormalization(training=True)
 // (tf.nn.moments over axes (0,1), padded frames included: utils.py:79-83) and ActNormFlow.init (flow.py:189-196).
-__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out) {
+__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;                       // 4 row groups per block
   double acc = 0.0;
+  float mx = 0.f;
   if (c < C) {
     const double mu = mean ? mean[c] : 0.0;
     for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
-      const double v = (double)x[(size_t)m * ld + c];
+      const float xv = x[(size_t)m * ld + c];
+      const double v = (double)xv;
+      mx = fmaxf(mx, fabsf(xv));
       acc += mean ? (v - mu) * (v - mu) : v;
     }
   }
   __shared__ double part[4][64];
   part[rg][threadIdx.x & 63] = acc;
+  if (amax) {                                            // by-product: max |x| of the block (scale of the split-fp16 gradient GEMM)
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+  }
   __syncthreads();
   if (rg == 0 && c < C) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
+hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
   int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out);
+  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax);
   return hipGetLastError();
+}
+hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
+  return launch_col_sum_amax(x, M, C, ld, mean, out, nullptr, s);
 }
 __global__ void scale_d_kernel(double* v, int n, double f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -10,6 +10,7 @@
 //   small elementwise kernels for the flow (log_probability direction), reparameterisation, losses, Adam
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace vnr {
 
@@ -75,14 +76,132 @@ gemm_tn_kernel(const float* A, int lda, const float* B, int ldb, float* C, int l
       if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[r]);
     }
 }
+// Second generation of the kernel-gradient GEMM: the same contraction on the f16 matrix pipe with the 3-term hi/lo split
+// (fp32 accumulate, 22 bits per operand -- see gemm2.hip).  Both operands are split ONCE, by the loader, on their way into
+// LDS, and stored reduction-major ([column][m], 8 consecutive m = one 16-byte MFMA operand), so the inner loop is
+// ds_read_b128 + MFMA only: 6 MFMAs of 8 passes per 32-row tile instead of 16 MFMAs of 16 passes.
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256)
+gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+                     int rows_per_split, const unsigned* b_absmax) {
+  constexpr int CS = 40;                                   // column stride in halfs (80 B: 16-byte aligned, bank-spread)
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][64 * CS], Al[2][64 * CS], Bh[2][64 * CS], Bl[2][64 * CS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int m_lo = blockIdx.z * rows_per_split;
+  int m_hi = m_lo + rows_per_split; if (m_hi > M) m_hi = M;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // B is a GRADIENT: its magnitude follows the loss scale (kl_weight 1e-5 puts whole branches at 1e-9), far outside the fp16
+  // range.  It is pre-scaled by the power of two that maps the launch-wide max |B| (found by a preceding abs-max pass) to
+  // ~2^14; the hi/lo pair then resolves 2^-39 of that maximum, and the accumulator is scaled back exactly at the end.
+  float bscale = 1.f, binv = 1.f;
+  {
+    const unsigned bits = b_absmax ? *b_absmax : 0u;
+    const int e = (int)(bits >> 23) & 0xff;                // biased exponent of max |B|
+    if (e > 0 && e < 255) {
+      int sft = 14 - (e - 127);
+      if (sft > 126) sft = 126; if (sft < -126) sft = -126;
+      bscale = __uint_as_float((unsigned)(sft + 127) << 23);
+      binv = __uint_as_float((unsigned)(-sft + 127) << 23);
+    }
+  }
+  // loader: column `col` of the 64-wide strip, rows 8*rg .. 8*rg+7 of the 32-row tile (a wave reads 256 contiguous bytes per row)
+  const int col = tid & 63, rg = tid >> 6;
+  const bool a_ok = k0 + col < K, b_ok = n0 + col < N;
+  float ra[8], rb[8];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = m0 + 8 * rg + e;
+      float va = 0.f, vb = 0.f;
+      if (m < m_hi) {
+        const int t = m % T, ts = t + shift;
+        if (a_ok && ts >= 0 && ts < T) va = A[(size_t)(m + shift) * lda + k0 + col];
+        if (b_ok) vb = B[(size_t)m * ldb + n0 + col] * bscale;
+      }
+      ra[e] = va; rb[e] = vb;
+    }
+  };
+  auto lstore = [&](int buf) {
+    h16x8_t ah, al, bh, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      _Float16 h = (_Float16)ra[e]; ah[e] = h; al[e] = (_Float16)(ra[e] - (float)h);
+      h = (_Float16)rb[e]; bh[e] = h; bl[e] = (_Float16)(rb[e] - (float)h);
+    }
+    const int o = col * CS + 8 * rg;
+    *reinterpret_cast<h16x8_t*>(&Ah[buf][o]) = ah; *reinterpret_cast<h16x8_t*>(&Al[buf][o]) = al;
+    *reinterpret_cast<h16x8_t*>(&Bh[buf][o]) = bh; *reinterpret_cast<h16x8_t*>(&Bl[buf][o]) = bl;
+  };
+  int buf = 0;
+  if (m_lo < m_hi) { gload(m_lo); lstore(0); }
+  __syncthreads();
+  for (int m0 = m_lo; m0 < m_hi; m0 += 32) {
+    const bool more = m0 + 32 < m_hi;
+    if (more) gload(m0 + 32);                              // next tile's global loads fly under this tile's MFMAs
+    const int oa = (wk * 32 + l31) * CS + 8 * half, ob = (wn * 32 + l31) * CS + 8 * half;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const h16x8_t ah = *reinterpret_cast<const h16x8_t*>(&Ah[buf][oa + 16 * st]);
+      const h16x8_t al = *reinterpret_cast<const h16x8_t*>(&Al[buf][oa + 16 * st]);
+      const h16x8_t bh = *reinterpret_cast<const h16x8_t*>(&Bh[buf][ob + 16 * st]);
+      const h16x8_t bl = *reinterpret_cast<const h16x8_t*>(&Bl[buf][ob + 16 * st]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n < N)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + wk * 32 + frow_t(r, half);
+      if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[r] * binv);
+    }
+}
+// max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0
+__global__ void absmax2d_kernel(const float* x, int ld, int rows, int cols, unsigned* out) {
+  float m = 0.f;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* xr = x + (size_t)r * ld;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(xr[c]));
+  }
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+// b_absmax: device word holding the bits of max |B| (launch_absmax2d), or null (no pre-scaling: B of unit order)
+hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s) {
+  static const bool skip = getenv("VNR_SKIP_ABSMAX") != nullptr;      // measurement knob (gradients of tiny magnitude lose accuracy)
+  if (skip) return hipSuccess;
+  int blocks = rows < 1024 ? rows : 1024; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, out);
+  return hipGetLastError();
+}
+hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
+                                 int shift, const unsigned* b_absmax, hipStream_t s);
 hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                           int shift, hipStream_t s) {
+  return launch_gemm_tn_scaled(A, lda, B, ldb, C, ldc, M, K, N, T, shift, nullptr, s);
+}
+hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
+                                 int shift, const unsigned* b_absmax, hipStream_t s) {
   const int tk = (K + 63) / 64, tn = (N + 63) / 64;
   int splits = 1024 / (tk * tn); if (splits < 1) splits = 1;
   int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
   int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
   splits = (M + rps - 1) / rps;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+  static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
+  if (v1) hipLaunchKernelGGL(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+  else hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
   return hipGetLastError();
 }
 

@@ -162,7 +162,7 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
-                                int causal, float temperature, hipStream_t s);
+                                int causal, float temperature, unsigned* amax_slot, hipStream_t s);
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, hipStream_t s);
 hipError_t launch_act_bwd(float* d, const float* y, size_t n, int act, hipStream_t s);
 hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, int rows, int cols, int accumulate, hipStream_t s);

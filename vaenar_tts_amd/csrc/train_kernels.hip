@@ -325,17 +325,253 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
     for (int e = 0; e < 16; ++e) { pv[e] = dv[e]; pk[e] = dk[e] * a.scale; }
   }
 }
+// ---- attention backward, second generation: the four products on the f16 matrix pipe (3-term hi/lo split) ----------------------
+// Same mathematics as the kernels above.  dO is a gradient (its magnitude follows the loss scale), so it is pre-scaled by
+// the power of two that maps the launch-wide max |dO| to ~2^10; dS inherits the scale (it is written to HBM scaled) and
+// dQ / dK / dV are scaled back exactly when stored.
+//   kernel A (grid: 128-query blocks x H x B; wave = 32 queries): per 32-key tile  dP^T = V.dO^T (lane <-> query),
+//            dS = P * (dP - dO.O) on valid positions, dS -> HBM, dQ^T += K^T.dS^T
+//   kernel B (grid: 128-key blocks x H x B; wave = 32 keys): per 32-query tile   dV^T += dO^T.P, dK^T += Q^T.dS
+// Operand tiles are split to fp16 hi/lo ONCE by the staging threads and stored reduction-major in LDS.
+__device__ __forceinline__ void split8_t(const float* x, h16x8_t& hi, h16x8_t& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+}
+__device__ __forceinline__ f32x16 mfma3_t(const h16x8_t& ah, const h16x8_t& al, const h16x8_t& bh, const h16x8_t& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ void scale_from_absmax(const unsigned* amax, int target_exp, float& sc, float& inv) {
+  sc = 1.f; inv = 1.f;
+  const unsigned bits = amax ? *amax : 0u;
+  const int e = (int)(bits >> 23) & 0xff;
+  if (e > 0 && e < 255) {
+    int sft = target_exp - (e - 127);
+    if (sft > 126) sft = 126; if (sft < -126) sft = -126;
+    sc = __uint_as_float((unsigned)(sft + 127) << 23);
+    inv = __uint_as_float((unsigned)(-sft + 127) << 23);
+  }
+}
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
+  constexpr int VS = 72, KS = 40;                           // LDS row strides in halfs (16-byte aligned, bank-spread)
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VS], Vl[32 * VS];     // V tile  [key][d]
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[64 * KS], Kl[64 * KS];     // K tile, transposed [d][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;         // this lane's query
+  const bool qin = q < a.Tq;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  // dO fragment (B operand of dP^T = V.dO^T: column = query, k = d) and the row dot dO.O
+  h16x8_t doh[4], dol[4];
+  float rowdot = 0.f;
+  {
+    const float* dp = a.dO + ((size_t)b * a.Tq + (qin ? q : 0)) * a.lddo + hd * 64 + 8 * half;
+    const float* op = a.O + ((size_t)b * a.Tq + (qin ? q : 0)) * a.ldo + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = qin ? dp[16 * t + e] * sc : 0.f; rowdot += qin ? x[e] * op[16 * t + e] : 0.f; }
+      split8_t(x, doh[t], dol[t]);
+    }
+    rowdot += __shfl_xor(rowdot, 32, 64);
+  }
+  f32x16 accq[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accq[nb][r] = 0.f;
+  const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  const bool vec4 = (a.Tk & 3) == 0;
+  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+    __syncthreads();
+    {   // stage V [key][d] (thread: key = tid>>3, 8 d) and K^T [d][key] (thread: d = tid&63, 8 keys), split once
+      const int key = tid >> 3, d8 = (tid & 7) * 8;
+      float x[8];
+      const bool ok = j0 + key < a.Tk;
+      const float* vp = a.V + ((size_t)b * a.Tk + j0 + key) * a.ldv + hd * 64 + d8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ok ? vp[e] : 0.f;
+      h16x8_t hi, lo; split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Vh[key * VS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Vl[key * VS + d8]) = lo;
+      const int d = tid & 63, rg = tid >> 6;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int kk = j0 + 8 * rg + e; x[e] = kk < a.Tk ? a.K[((size_t)b * a.Tk + kk) * a.ldk + hd * 64 + d] : 0.f; }
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Kh[d * KS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Kl[d * KS + 8 * rg]) = lo;
+    }
+    // P[q][j0 + frow(r, half)] : four runs of 4 consecutive keys per lane
+    float p[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int kk = j0 + 8 * g4 + 4 * half;
+      const float* pp = Pb + (size_t)(qin ? q : 0) * a.Tk + kk;
+      if (qin && vec4 && kk + 3 < a.Tk) { const float4 v4 = *reinterpret_cast<const float4*>(pp); p[4 * g4] = v4.x; p[4 * g4 + 1] = v4.y; p[4 * g4 + 2] = v4.z; p[4 * g4 + 3] = v4.w; }
+      else
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[4 * g4 + e] = (qin && kk + e < a.Tk) ? pp[e] : 0.f;
+    }
+    __syncthreads();
+    // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+    f32x16 dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const h16x8_t vh = *reinterpret_cast<const h16x8_t*>(&Vh[l31 * VS + 16 * t + 8 * half]);
+      const h16x8_t vl = *reinterpret_cast<const h16x8_t*>(&Vl[l31 * VS + 16 * t + 8 * half]);
+      dpt = mfma3_t(vh, vl, doh[t], dol[t], dpt);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = j0 + frow_t(r, half);
+      const bool valid = qin && q < qlen && kk < klen && kk < a.Tk && (!a.causal || kk <= q);
+      ds[r] = valid ? p[r] * (dpt[r] - rowdot) : 0.f;
+    }
+    if (qin) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kk = j0 + 8 * g4 + 4 * half;
+        float* dp = dSb + (size_t)q * a.Tk + kk;
+        if (vec4 && kk + 3 < a.Tk) *reinterpret_cast<float4*>(dp) = make_float4(ds[4 * g4], ds[4 * g4 + 1], ds[4 * g4 + 2], ds[4 * g4 + 3]);
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (kk + e < a.Tk) dp[e] = ds[4 * g4 + e];
+      }
+    }
+    // dQ^T[d][q] += sum_key K[key][d] dS[q][key]   (k-slot (t', half, e) carries key frow(8t'+e, half): dS registers as they are)
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      h16x8_t dsh, dsl;
+      split8_t(&ds[8 * tp], dsh, dsl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int row = (32 * nb + l31) * KS;
+        h16x8_t kh, kl;
+        const int c0 = 16 * tp + 4 * half, c1 = 16 * tp + 8 + 4 * half;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 a0 = *reinterpret_cast<const h4*>(&Kh[row + c0]), a1 = *reinterpret_cast<const h4*>(&Kh[row + c1]);
+        const h4 b0 = *reinterpret_cast<const h4*>(&Kl[row + c0]), b1 = *reinterpret_cast<const h4*>(&Kl[row + c1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kh[e] = a0[e]; kh[4 + e] = a1[e]; kl[e] = b0[e]; kl[4 + e] = b1[e]; }
+        accq[nb] = mfma3_t(kh, kl, dsh, dsl, accq[nb]);
+      }
+    }
+  }
+  if (qin) {
+    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
+    const float f = a.scale * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) =
+            make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
+  }
+}
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
+  constexpr int TS = 40;                                     // [d][32 queries] tiles, row stride in halfs
+  __shared__ __attribute__((aligned(16))) _Float16 Oh[64 * TS], Ol[64 * TS], Qh[64 * TS], Ql[64 * TS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;        // this lane's key
+  const bool kin = key < a.Tk;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  f32x16 accv[2], acck[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accv[nb][r] = 0.f; acck[nb][r] = 0.f; }
+  const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  const float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
+  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
+    __syncthreads();
+    {   // stage dO^T and Q^T [d][32 queries]: thread d = tid&63, queries 8*rg .. +7
+      const int d = tid & 63, rg = tid >> 6;
+      float x[8], y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qq = q0 + 8 * rg + e;
+        const bool ok = qq < a.Tq;
+        x[e] = ok ? a.dO[((size_t)b * a.Tq + qq) * a.lddo + hd * 64 + d] * sc : 0.f;
+        y[e] = ok ? a.Q[((size_t)b * a.Tq + qq) * a.ldq + hd * 64 + d] : 0.f;
+      }
+      h16x8_t hi, lo;
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Oh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ol[d * TS + 8 * rg]) = lo;
+      split8_t(y, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Qh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ql[d * TS + 8 * rg]) = lo;
+    }
+    // B operands straight from HBM: P / dS [query slot][key = lane]: 8 consecutive queries per k16 step and lane half
+    float pv[2][8], sv[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qq = q0 + 16 * t + 8 * half + e;
+        const bool ok = kin && qq < a.Tq;
+        pv[t][e] = ok ? Pb[(size_t)qq * a.Tk + key] : 0.f;
+        sv[t][e] = ok ? dSb[(size_t)qq * a.Tk + key] : 0.f;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      h16x8_t ph, pl, sh, sl;
+      split8_t(pv[t], ph, pl);
+      split8_t(sv[t], sh, sl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int o = (32 * nb + l31) * TS + 16 * t + 8 * half;
+        const h16x8_t oh = *reinterpret_cast<const h16x8_t*>(&Oh[o]), ol = *reinterpret_cast<const h16x8_t*>(&Ol[o]);
+        const h16x8_t qh = *reinterpret_cast<const h16x8_t*>(&Qh[o]), ql = *reinterpret_cast<const h16x8_t*>(&Ql[o]);
+        accv[nb] = mfma3_t(oh, ol, ph, pl, accv[nb]);        // dV^T[d][key] += dO[q][d] P[q][key]
+        acck[nb] = mfma3_t(qh, ql, sh, sl, acck[nb]);        // dK^T[d][key] += Q[q][d] dS[q][key]
+      }
+    }
+  }
+  if (kin) {
+    float* pvd = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64;
+    float* pkd = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64;
+    const float fk = a.scale * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = 32 * nb + 8 * g4 + 4 * half;
+        *reinterpret_cast<float4*>(pvd + d) = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
+        *reinterpret_cast<float4*>(pkd + d) = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
+      }
+  }
+}
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
-                                int causal, float temperature, hipStream_t s) {
+                                int causal, float temperature, unsigned* amax_slot, hipStream_t s) {
   AttnBwdArgs a;
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.P = P; a.dQ = dQ; a.dK = dK; a.dV = dV; a.dS = dS;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.q_len = q_len; a.k_len = k_len; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;
   a.scale = 0.125f / temperature;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
+  static const bool v1 = getenv("VNR_ATTN_BWD_V1") != nullptr;       // A/B switch: plain-FMA fp32 kernels
+  const bool aligned = !(lddq & 3) && !(lddk & 3) && !(lddv & 3);
+  if (v1 || !amax_slot || !aligned) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
+  hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   return hipGetLastError();
 }
 

@@ -468,7 +468,17 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
   float mx = 0.f;
   if (c < C) {
     const double mu = mean ? mean[c] : 0.0;
-    for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+    const int step = gridDim.y * 4;
+    int m = blockIdx.y * 4 + rg;
+    for (; m + 3 * step < M; m += 4 * step) {            // four independent loads in flight per thread
+      const float x0 = x[(size_t)m * ld + c], x1 = x[(size_t)(m + step) * ld + c], x2 = x[(size_t)(m + 2 * step) * ld + c],
+                  x3 = x[(size_t)(m + 3 * step) * ld + c];
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(x0), fabsf(x1))), fmaxf(fabsf(x2), fabsf(x3)));
+      if (mean) acc += ((double)x0 - mu) * ((double)x0 - mu) + ((double)x1 - mu) * ((double)x1 - mu) + ((double)x2 - mu) * ((double)x2 - mu) +
+                       ((double)x3 - mu) * ((double)x3 - mu);
+      else acc += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+    }
+    for (; m < M; m += step) {
       const float xv = x[(size_t)m * ld + c];
       const double v = (double)xv;
       mx = fmaxf(mx, fabsf(xv));
@@ -485,7 +495,7 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
   if (rg == 0 && c < C) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
-  int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+  int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
   hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax);
   return hipGetLastError();
 }

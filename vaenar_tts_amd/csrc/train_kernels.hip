@@ -168,9 +168,17 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
 // max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0
 __global__ void absmax2d_kernel(const float* x, int ld, int rows, int cols, unsigned* out) {
   float m = 0.f;
+  const bool v4 = !(ld & 3) && !(cols & 3) && !((size_t)x & 15);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float* xr = x + (size_t)r * ld;
-    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(xr[c]));
+    if (v4) {
+      for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    } else {
+      for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(xr[c]));
+    }
   }
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   __shared__ float wm[4];
@@ -182,7 +190,7 @@ __global__ void absmax2d_kernel(const float* x, int ld, int rows, int cols, unsi
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s) {
   static const bool skip = getenv("VNR_SKIP_ABSMAX") != nullptr;      // measurement knob (gradients of tiny magnitude lose accuracy)
   if (skip) return hipSuccess;
-  int blocks = rows < 1024 ? rows : 1024; if (blocks < 1) blocks = 1;
+  int blocks = rows < 512 ? rows : 512; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, out);
   return hipGetLastError();
 }
@@ -195,7 +203,8 @@ hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                                  int shift, const unsigned* b_absmax, hipStream_t s) {
   const int tk = (K + 63) / 64, tn = (N + 63) / 64;
-  int splits = 1024 / (tk * tn); if (splits < 1) splits = 1;
+  static const int target = getenv("VNR_GEMM_TN_WGS") ? atoi(getenv("VNR_GEMM_TN_WGS")) : 1024;     // measurement knob
+  int splits = target / (tk * tn); if (splits < 1) splits = 1;
   int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
   int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
   splits = (M + rps - 1) / rps;

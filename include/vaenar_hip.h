@@ -82,6 +82,10 @@ int vnr_create(const vnr_config *cfg, int device, vnr_handle *out);
 int vnr_destroy(vnr_handle h);
 const char *vnr_last_error(vnr_handle h);
 int vnr_abi_version(void);
+/* CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 to start): the checksum of TFRecord framing
+ * (datasets/tf_record_utils.py:77-83 via tf.io.TFRecordWriter) and of tensor-bundle checkpoints (train.py:246-249).
+ * Pure host code, no GPU needed. */
+uint32_t vnr_crc32c(uint32_t crc, const void *data, size_t n);
 int vnr_device_count(int *count);
 /* name, CU count and wavefront size of the handle's device (name buffer >= 64 bytes) */
 int vnr_device_info(vnr_handle h, char *name, int name_len, int *compute_units, int *wavefront);

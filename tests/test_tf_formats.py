@@ -1,0 +1,80 @@
+"""The reference's on-disk formats without TensorFlow (F3 TFRecord input, F2 checkpoints): known-answer
+vectors of the published formats, round trips, and the padded-batch / batch-shuffle semantics of create_dataset."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vaenar_tts_amd import tf_record_utils as tfr
+from vaenar_tts_amd._lib import crc32c
+
+
+def test_crc32c_known_answers():
+    assert crc32c(b"123456789") == 0xE3069283                       # the CRC-32C check value
+    assert crc32c(bytes(32)) == 0x8A9136AA and crc32c(b"\xff" * 32) == 0x62A8AB43     # RFC 3720 B.4
+    assert crc32c(b"6789", crc32c(b"12345")) == 0xE3069283          # incremental
+    assert tfr.masked_crc32c(b"123456789") == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) & 0xffffffff) + 0xa282ead8) & 0xffffffff
+
+
+def test_example_wire_format_known_answer():
+    # tf.train.Example(features=Features(feature={'a': Feature(int64_list=Int64List(value=[1]))})).SerializeToString()
+    entry = tfr._ld(1, tfr._ld(1, b"a") + tfr._ld(2, tfr.TFRecordWriter._int64_feature(1)))
+    assert tfr._ld(1, entry) == b"\n\x0c\n\n\n\x01a\x12\x05\x1a\x03\n\x01\x01"
+    # tf.io.serialize_tensor(tf.constant([1, 2], tf.int64))
+    assert tfr.serialize_tensor(np.array([1, 2], np.int64)) == b"\x08\t\x12\x04\x12\x02\x08\x02\"\x10" + struct.pack("<qq", 1, 2)
+    # a scalar float tensor stored in float_val form parses too: TensorProto{dtype: DT_FLOAT, tensor_shape: {}, float_val: 2.5}
+    assert tfr.parse_tensor(b"\x08\x01\x12\x00\x2d" + struct.pack("<f", 2.5)) == np.float32(2.5)
+
+
+def test_tfrecord_round_trip_and_dataset(tmp_path):
+    r = np.random.Generator(np.random.PCG64(0))
+    data_dir, save_dir = tmp_path / "data", tmp_path / "rec"
+    for d in (data_dir / "texts", data_dir / "mels", save_dir):
+        os.makedirs(d)
+    fids = ["LJ%03d" % i for i in range(7)]
+    items = {}
+    for i, fid in enumerate(fids):
+        text = r.integers(1, 43, 5 + i).astype(np.int64)            # the reference stores int64 text and float64 mels
+        mel = r.standard_normal((20 + 3 * i, 80))
+        np.save(data_dir / "texts" / (fid + ".npy"), text); np.save(data_dir / "mels" / (fid + ".npy"), mel)
+        items[fid] = (text, mel)
+    for mode, ids in (("train", fids[:5]), ("dev", fids[5:6]), ("test", fids[6:])):
+        (data_dir / (mode + ".txt")).write_text("\n".join(ids) + "\n")
+    w = tfr.TFRecordWriter(train_split=2, data_dir=str(data_dir), save_dir=str(save_dir))
+    w.write_all()
+    files = w.get_tfrecords_list("train")
+    assert [os.path.basename(f) for f in files] == ["train-0.tfrecords", "train-1.tfrecords"]
+    # framing: length, masked crc of the length, payload, masked crc of the payload
+    raw = open(files[0], "rb").read()
+    (n,) = struct.unpack_from("<Q", raw, 0)
+    assert struct.unpack_from("<I", raw, 8)[0] == tfr.masked_crc32c(raw[:8])
+    assert struct.unpack_from("<I", raw, 12 + n)[0] == tfr.masked_crc32c(raw[12:12 + n])
+    # a flipped payload byte is detected
+    bad = bytearray(raw); bad[20] ^= 1
+    (tmp_path / "bad.tfrecords").write_bytes(bytes(bad))
+    with pytest.raises(IOError):
+        list(tfr.TFRecordWriter.read_records(str(tmp_path / "bad.tfrecords")))
+    # parse_example: dtypes and values of tf_record_utils.py:108-124
+    seen = {}
+    for f in files:
+        for rec in tfr.TFRecordWriter.read_records(f):
+            fid, text, mel, tl, ml = w.parse_example(rec)
+            seen[fid.decode()] = (text, mel, tl, ml)
+    assert sorted(seen) == fids[:5]
+    for fid, (text, mel, tl, ml) in seen.items():
+        assert text.dtype == np.int32 and mel.dtype == np.float32 and tl.dtype == np.int32
+        np.testing.assert_array_equal(text, items[fid][0]); np.testing.assert_allclose(mel, items[fid][1].astype(np.float32))
+        assert tl == len(items[fid][0]) and ml == items[fid][1].shape[0]
+    # create_dataset: padded batches (zeros), optional batch-level shuffle
+    batches = list(w.create_dataset(0, 1, 0, 2, 80, 4, False, files))
+    assert [len(b[0]) for b in batches] == [2, 2, 1]
+    fb, texts, mels, tls, mls = batches[0]
+    assert texts.shape == (2, tls.max()) and mels.shape == (2, mls.max(), 80)
+    short = int(np.argmin(tls))
+    assert (texts[short, tls[short]:] == 0).all() and (mels[short, mls[short]:] == 0).all()
+    sh = list(w.create_dataset(0, 1, 0, 2, 80, 4, True, files, seed=3))
+    assert sorted(tuple(b[0]) for b in sh) == sorted(tuple(b[0]) for b in batches)       # whole batches move, contents do not
+    # pad_factor: frames padded up to a multiple (pre_pad :96-106)
+    w.pad_factor = 8
+    assert w.pre_pad(np.ones((21, 80), np.float32)).shape == (24, 80)

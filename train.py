@@ -6,8 +6,8 @@ dev_one_epoch (:207-225) and a checkpoint (:300-303) -- with the model calls of 
 vaenar_tts_amd.models.VAENAR (training-mode forward, backward and Adam on the GPU: vnr_train_step).
 
 Differences forced by the environment: no TensorFlow -> batches are synthetic (``--data_dir synthetic``: seeded random
-utterances of ``--t_text`` x ``--t_mel``; TFRecord input is SURVEY section 8f F3) or an ``.npz`` with ids / mels /
-text_lengths / mel_lengths; checkpoints are ``.npz`` files of the object-graph variable tree (``ckpt-<epoch>.npz``).
+utterances of ``--t_text`` x ``--t_mel``) or a directory of the reference's ``{train,dev}-*.tfrecords`` files, read without
+TensorFlow by vaenar_tts_amd/tf_record_utils.py; checkpoints are ``.npz`` files of the object-graph variable tree (``ckpt-<epoch>.npz``).
 With torchrun (WORLD_SIZE > 1) the run is data-parallel: the batch is sharded by utterance over the ranks, every rank
 holds a replica, and the flat gradient is all-reduced with RCCL over xGMI inside vnr_train_step (one exchange per step);
 the host control plane (gloo) only carries the RCCL id, barriers and the averaged log scalars.
@@ -65,8 +65,24 @@ def main():
     assert gb % world == 0, "global batch must divide over the ranks"
 
     # 1. data (train.py:61-111): every rank builds the same global batches and keeps its shard
-    train = [vdist.shard_batch(b, rank, world) for b in synthetic_batches(hps, args.steps_per_epoch, gb, args.t_text, args.t_mel, seed)]
-    dev = [vdist.shard_batch(b, rank, world) for b in synthetic_batches(hps, 1, gb, args.t_text, args.t_mel, seed + 1000)]
+    if args.data_dir == 'synthetic':
+        train = synthetic_batches(hps, args.steps_per_epoch, gb, args.t_text, args.t_mel, seed)
+        dev = synthetic_batches(hps, 1, gb, args.t_text, args.t_mel, seed + 1000)
+    else:                                                     # the reference's TFRecord files (tf_record_utils.py)
+        from vaenar_tts_amd.tf_record_utils import TFRecordWriter
+        rec = TFRecordWriter(save_dir=args.data_dir)
+
+        def load(mode, bs, shuffle):
+            out = []
+            for _, texts, mels, tl, ml in rec.create_dataset(
+                    hps.Dataset.buffer_size, hps.Dataset.num_parallel_reads, hps.Dataset.pad_factor, bs, hps.Audio.num_mels,
+                    hps.Train.shuffle_buffer, shuffle, rec.get_tfrecords_list(mode), seed=seed):
+                if len(tl) == bs:                             # the data-parallel shards need full batches
+                    out.append({"ids": texts, "mels": mels, "text_lengths": tl, "mel_lengths": ml})
+            return out
+        train, dev = load('train', gb, hps.Train.shuffle), load('dev', gb, False)
+    train = [vdist.shard_batch(b, rank, world) for b in train]
+    dev = [vdist.shard_batch(b, rank, world) for b in dev]
 
     # 2. model + optimizer (train.py:114-117)
     ckpts = sorted(f for f in os.listdir(args.model_dir) if f.startswith('ckpt-') and f.endswith('.npz'))

@@ -123,6 +123,8 @@ def load():
         fn.restype = C.c_int
     lib.vnr_last_error.argtypes = [_vp]
     lib.vnr_last_error.restype = C.c_char_p
+    lib.vnr_crc32c.argtypes = [C.c_uint32, _vp, _sz]
+    lib.vnr_crc32c.restype = C.c_uint32
     if lib.vnr_abi_version() != ABI_VERSION:
         raise VnrError("libvaenar_hip.so ABI version %d != binding %d" % (lib.vnr_abi_version(), ABI_VERSION))
     _lib = lib
@@ -161,6 +163,12 @@ def config_from_hps(hps):
     c.dec_post_drop_rate = d.post_drop_rate
     c.post_pre_drop_rate, c.post_pos_drop_rate = q.pre_drop_rate, q.pos_drop_rate
     return c
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli) of a bytes-like object -- host routine of the library (no GPU needed)."""
+    buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    return int(load().vnr_crc32c(C.c_uint32(crc), C.c_char_p(bytes(buf)), len(buf)))
 
 
 def device_count():

@@ -34,7 +34,9 @@ def _base(vocab_size, mel_text_len_ratio):
             random_seed=123456, epochs=2000, train_batch_size=32, test_batch_size=8,
             num_samples=1, length_weight=1.0, kl_weight=1.0, kl_weight_init=1e-5,
             kl_weight_increase_epoch=1, kl_weight_end=1e-5, learning_rate=1.25e-4,
-            reduction_factors=[5, 4, 3, 2], reduce_interval=[0, 200, 400, 600]),
+            reduction_factors=[5, 4, 3, 2], reduce_interval=[0, 200, 400, 600],
+            shuffle_buffer=128, shuffle=True, test_interval=50),
+        Dataset=_NS(buffer_size=65536, num_parallel_reads=64, pad_factor=0),             # hparams.py:253-258
         Audio=_NS(num_mels=80, sample_rate=22050, frame_shift_sample=256),
         Common=_NS(latent_dim=128, output_dim=80, final_reduction_factor=2,
                    max_reduction_factor=5, mel_text_len_ratio=mel_text_len_ratio),

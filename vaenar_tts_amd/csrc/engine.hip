@@ -914,6 +914,35 @@ extern "C" {
 
 int vnr_abi_version(void) { return VNR_ABI_VERSION; }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8 on the host: the checksum of the reference's on-disk
+// formats (TFRecord framing datasets/tf_record_utils.py:77-83, tensor-bundle checkpoints train.py:246-249).  Host only.
+uint32_t vnr_crc32c(uint32_t crc, const void* data, size_t n) {
+  static uint32_t table[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
+    ready = true;
+  }
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xff] ^ table[6][(lo >> 8) & 0xff] ^ table[5][(lo >> 16) & 0xff] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xff] ^ table[2][(hi >> 8) & 0xff] ^ table[1][(hi >> 16) & 0xff] ^ table[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) c = (c >> 8) ^ table[0][(c ^ *p++) & 0xff];
+  return ~c;
+}
+
 const char* vnr_last_error(vnr_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
 int vnr_device_count(int* count) {

@@ -27,7 +27,9 @@ def inference_test():
     parser = argparse.ArgumentParser('Inference parameters parser')
     parser.add_argument('--dataset', type=str, choices=['ljspeech', 'databaker'], default='ljspeech')
     parser.add_argument('--data_dir', type=str, default='synthetic', help=".npz with ids/text_lengths, or 'synthetic'")
-    parser.add_argument('--ckpt_path', type=str, default='synthetic-0', help=".npz weight tree, or 'synthetic-<step>'")
+    parser.add_argument('--ckpt_path', type=str, default='synthetic-0',
+                        help="TensorFlow checkpoint prefix (ckpt-N, as written by the reference's train.py), .npz weight tree, or "
+                             "'synthetic-<step>'")
     parser.add_argument('--test_dir', type=str, default='gpurun_out/test_dir')
     parser.add_argument('--batch_size', type=int, default=1)
     parser.add_argument('--temperature', type=float, default=0.)

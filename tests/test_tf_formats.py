@@ -78,3 +78,77 @@ def test_tfrecord_round_trip_and_dataset(tmp_path):
     # pad_factor: frames padded up to a multiple (pre_pad :96-106)
     w.pad_factor = 8
     assert w.pre_pad(np.ones((21, 80), np.float32)).shape == (24, 80)
+
+
+# ---- TensorFlow checkpoints (tensor bundles), SURVEY section 8f F2 -----------------------------------------------------------
+def _hand_table(path, key, value):
+    """An SSTable with ONE data block holding ONE entry, assembled here byte by byte from the leveldb format description
+    (independent of vaenar_tts_amd.tf_checkpoint's writer)."""
+    from vaenar_tts_amd.tf_record_utils import _varint as vi
+
+    def mask(c):
+        return ((((c >> 15) | (c << 17)) & 0xffffffff) + 0xa282ead8) & 0xffffffff
+
+    def block(entries):
+        b = b"".join(vi(0) + vi(len(k)) + vi(len(v)) + k + v for k, v in entries)     # no prefix sharing
+        b += b"".join(struct.pack("<I", 0) for _ in range(1)) + struct.pack("<I", 1)   # one restart at offset 0
+        return b
+
+    out = bytearray()
+
+    def emit(b):
+        off = len(out)
+        out.extend(b + b"\x00" + struct.pack("<I", mask(crc32c(b + b"\x00"))))
+        return off, len(b)
+    d = emit(block([(key, value)]))
+    m = emit(block([]))
+    i = emit(block([(key, vi(d[0]) + vi(d[1]))]))
+    footer = vi(m[0]) + vi(m[1]) + vi(i[0]) + vi(i[1])
+    out.extend(footer + bytes(40 - len(footer)) + struct.pack("<Q", 0xdb4775248b80fb57))
+    open(path, "wb").write(bytes(out))
+
+
+def test_checkpoint_index_hand_assembled(tmp_path):
+    from vaenar_tts_amd import tf_checkpoint as ck
+    p = str(tmp_path / "t.index")
+    _hand_table(p, b"model/x/.ATTRIBUTES/VARIABLE_VALUE", b"\x08\x01")
+    assert ck.read_index(p) == {b"model/x/.ATTRIBUTES/VARIABLE_VALUE": b"\x08\x01"}
+    raw = bytearray(open(p, "rb").read()); raw[3] ^= 0x40
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        ck.read_index(p)
+
+
+def test_checkpoint_round_trip_and_model_mapping(tmp_path):
+    from vaenar_tts_amd import tf_checkpoint as ck
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.weights import init_weights, weight_spec
+    hps = tiny_hps()
+    w = init_weights(hps, seed=3)
+    prefix = str(tmp_path / "ckpt-7")
+    extra = {"optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE": np.array(7, np.int64),
+             "step/.ATTRIBUTES/VARIABLE_VALUE": np.array(7, np.int64),
+             "model/decoder/pre_projection/kernel/.OPTIMIZER_SLOT/optimizer/m/.ATTRIBUTES/VARIABLE_VALUE":
+                 np.zeros(weight_spec(hps)["decoder/pre_projection/kernel"], np.float32)}
+    tensors = {"model/%s%s" % (p, ck.SUFFIX): a for p, a in w.items()}
+    tensors.update(extra)
+    ck.write_checkpoint(prefix, tensors)
+    names = {k for k, _, _ in ck.list_variables(prefix)}
+    assert names == set(tensors) and len(names) > 300               # many 4 KB index blocks, restart points every 16 keys
+    back = ck.read_checkpoint(prefix)
+    assert back["step/.ATTRIBUTES/VARIABLE_VALUE"] == 7 and back["step/.ATTRIBUTES/VARIABLE_VALUE"].dtype == np.int64
+    got = ck.load_model_weights(prefix, hps)
+    assert list(got) == list(weight_spec(hps))                      # the variable tree, optimizer slots and counters dropped
+    for p in w:
+        np.testing.assert_array_equal(got[p], w[p])
+    # a flipped byte in the data shard is caught by the per-tensor checksum
+    dpath = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(dpath, "rb").read()); raw[100] ^= 1
+    open(dpath, "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        ck.read_checkpoint(prefix)
+    # strict loading reports what is missing
+    ck.save_model_weights(str(tmp_path / "partial"), {k: v for k, v in w.items() if not k.startswith("posterior/")})
+    with pytest.raises(KeyError):
+        ck.load_model_weights(str(tmp_path / "partial"), hps)
+    assert "posterior/pos_weight" not in ck.load_model_weights(str(tmp_path / "partial"), hps, include_posterior=False)

@@ -54,10 +54,16 @@ class VAENAR:
 
     # weights (replaces tf.train.Checkpoint(model=model).restore, inference.py:122-123) -------------
     def load_weights(self, weights):
-        """``weights``: {path: ndarray} (vaenar_tts_amd.weights) or a path to an .npz of it."""
+        """``weights``: {path: ndarray} (vaenar_tts_amd.weights), a path to an ``.npz`` of it, or the prefix of a TensorFlow
+        checkpoint written by the reference's train.py (``<prefix>.index`` + ``.data-*``, read by tf_checkpoint.py)."""
         if isinstance(weights, str):
-            from .weights import load_npz
-            weights = load_npz(weights)
+            import os
+            if os.path.exists(weights + ".index"):
+                from .tf_checkpoint import load_model_weights
+                weights = load_model_weights(weights, self.hps, strict=False)
+            else:
+                from .weights import load_npz
+                weights = load_npz(weights)
         self.engine.load_weights(weights)
 
     # models.py:199-210 ----------------------------------------------------------------------------

@@ -1,0 +1,249 @@
+"""TensorFlow checkpoints (tensor bundles) without TensorFlow: the files behind
+``tf.train.Checkpoint(model=model).restore(ckpt_path)`` (reference inference.py:122-123) and
+``tf.train.CheckpointManager.save`` (train.py:246-249, 300-303).
+
+A checkpoint ``<prefix>`` is ``<prefix>.index`` + ``<prefix>.data-0000S-of-0000N``:
+
+* ``.index`` is a leveldb-format SSTable: data blocks of prefix-compressed ``key -> value`` entries
+  (``varint shared | varint non_shared | varint value_len | key suffix | value``, restart array of uint32 offsets +
+  uint32 count at the end of the block), each block followed by a 5-byte trailer (compression type, masked CRC-32C of
+  block + type), then a metaindex block, an index block (``separator key -> BlockHandle(varint offset, varint size)``) and
+  a 48-byte footer (two BlockHandles, zero padding, magic 0xdb4775248b80fb57).  TensorFlow writes bundles uncompressed.
+* the value of key ``""`` is a ``BundleHeaderProto{1: num_shards, 2: endianness, 3: version}``; every other value is a
+  ``BundleEntryProto{1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: fixed32 masked crc32c}``;
+* ``.data-*`` holds the raw little-endian tensor bytes at ``[offset, offset + size)``.
+
+Object-based (TF2 / Keras) checkpoints name a variable by its attribute path from the root object:
+``model/<attr>/<attr>/.../.ATTRIBUTES/VARIABLE_VALUE`` (list elements by index) -- exactly the paths of
+``vaenar_tts_amd/weights.py`` under the root attribute ``model`` (train.py:246).  Optimizer slots
+(``optimizer/...`` and ``.../.OPTIMIZER_SLOT/...``), the ``step`` counter and the ``_CHECKPOINTABLE_OBJECT_GRAPH`` string are
+skipped by ``load_model_weights``.
+
+``write_checkpoint`` produces well-formed bundles (readable by ``tf.train.load_checkpoint`` / ``list_variables``); it does
+NOT emit the ``_CHECKPOINTABLE_OBJECT_GRAPH`` proto, so TensorFlow's object-based ``restore`` cannot consume them -- it exists
+for tests and for exporting trained variables to name-based readers.
+
+PARITY UNPINNED against bundles written by real TensorFlow (none exist in this environment; the published checkpoints of
+the reference are behind a Google-Drive link, README.md:4): the format statements above are the published ones, pinned by
+tests/test_tf_formats.py (independent hand-assembled table, CRC known answers, round trips).
+"""
+import struct
+
+import numpy as np
+
+from ._lib import crc32c
+from .tf_record_utils import _field, _ld, _parse, _read_varint, _varint, _NP_OF_DT, _DT_OF_NP
+
+TABLE_MAGIC = 0xdb4775248b80fb57
+_MASK_DELTA = 0xa282ead8
+DT_STRING = 7
+SUFFIX = "/.ATTRIBUTES/VARIABLE_VALUE"
+
+
+def _mask(crc):
+    return ((((crc >> 15) | (crc << 17)) & 0xffffffff) + _MASK_DELTA) & 0xffffffff
+
+
+# ---- SSTable reading ------------------------------------------------------------------------------------------------------
+def _read_handle(buf, pos):
+    off, pos = _read_varint(buf, pos)
+    size, pos = _read_varint(buf, pos)
+    return (off, size), pos
+
+
+def _read_block(data, handle, verify=True):
+    off, size = handle
+    block = data[off:off + size]
+    ctype = data[off + size]
+    (crc,) = struct.unpack_from("<I", data, off + size + 1)
+    if verify and crc != _mask(crc32c(bytes(data[off:off + size + 1]))):
+        raise IOError("checkpoint index: block checksum mismatch at offset %d" % off)
+    if ctype != 0:
+        raise IOError("checkpoint index: compressed block (type %d) -- TensorFlow writes bundles uncompressed" % ctype)
+    return block
+
+
+def _block_entries(block):
+    (nrestarts,) = struct.unpack_from("<I", block, len(block) - 4)
+    limit = len(block) - 4 - 4 * nrestarts
+    pos, key = 0, b""
+    while pos < limit:
+        shared, pos = _read_varint(block, pos)
+        non_shared, pos = _read_varint(block, pos)
+        vlen, pos = _read_varint(block, pos)
+        key = key[:shared] + bytes(block[pos:pos + non_shared]); pos += non_shared
+        yield key, bytes(block[pos:pos + vlen]); pos += vlen
+
+
+def read_index(path, verify=True):
+    """{key bytes: value bytes} of an SSTable (the ``.index`` file), in key order."""
+    data = memoryview(open(path, "rb").read())
+    if len(data) < 48 or struct.unpack_from("<Q", data, len(data) - 8)[0] != TABLE_MAGIC:
+        raise IOError("%s is not a TensorFlow checkpoint index (bad table magic)" % path)
+    footer = data[len(data) - 48:]
+    _, pos = _read_handle(footer, 0)                        # metaindex: unused by tensor bundles
+    index_handle, _ = _read_handle(footer, pos)
+    out = {}
+    for _, hv in _block_entries(_read_block(data, index_handle, verify)):
+        handle, _ = _read_handle(hv, 0)
+        for k, v in _block_entries(_read_block(data, handle, verify)):
+            out[k] = v
+    return out
+
+
+def _parse_entry(v):
+    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    for num, wire, val in _parse(v):
+        if num == 1:
+            e["dtype"] = val
+        elif num == 2:
+            e["shape"] = [next((x for n2, _, x in _parse(dim) if n2 == 1), 0) for n1, _, dim in _parse(val) if n1 == 2]
+        elif num == 3:
+            e["shard_id"] = val
+        elif num == 4:
+            e["offset"] = val
+        elif num == 5:
+            e["size"] = val
+        elif num == 6:
+            e["crc32c"] = val
+        elif num == 7:
+            e["sliced"] = True
+    return e
+
+
+def list_variables(prefix):
+    """[(key, shape, numpy dtype or 'string')] like tf.train.list_variables."""
+    out = []
+    for k, v in read_index(prefix + ".index").items():
+        if k == b"":
+            continue
+        e = _parse_entry(v)
+        out.append((k.decode(), e["shape"], _NP_OF_DT.get(e["dtype"], "string" if e["dtype"] == DT_STRING else e["dtype"])))
+    return out
+
+
+def read_checkpoint(prefix, verify=True, keys=None):
+    """{key: ndarray} of every numeric tensor of the bundle (string tensors and sliced entries are skipped)."""
+    index = read_index(prefix + ".index", verify)
+    header = dict(num_shards=1, endianness=0)
+    for num, _, val in _parse(index.get(b"", b"")):
+        if num == 1:
+            header["num_shards"] = val
+        elif num == 2:
+            header["endianness"] = val
+    if header["endianness"] != 0:
+        raise IOError("big-endian tensor bundles are not supported")
+    shards = {}
+    out = {}
+    for k, v in index.items():
+        if k == b"" or (keys is not None and k.decode() not in keys):
+            continue
+        e = _parse_entry(v)
+        if e["dtype"] not in _NP_OF_DT or e["sliced"]:
+            continue
+        sid = e["shard_id"]
+        if sid not in shards:
+            shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"]), "rb")
+        f = shards[sid]
+        f.seek(e["offset"])
+        raw = f.read(e["size"])
+        if len(raw) != e["size"]:
+            raise IOError("checkpoint data: truncated tensor %s" % k.decode())
+        if verify and e["crc32c"] is not None and e["crc32c"] != _mask(crc32c(raw)):
+            raise IOError("checkpoint data: checksum mismatch for %s" % k.decode())
+        dt = np.dtype(_NP_OF_DT[e["dtype"]])
+        out[k.decode()] = np.frombuffer(raw, dtype=dt.newbyteorder("<")).astype(dt).reshape(e["shape"])
+    for f in shards.values():
+        f.close()
+    return out
+
+
+def load_model_weights(prefix, hps=None, root="model", include_posterior=True, strict=True):
+    """The reference's ``tf.train.Checkpoint(model=model).restore(prefix)``: {weights.py path: float32 ndarray}.
+    With ``hps`` the result is checked against the variable tree (missing / mis-shaped variables raise when ``strict``)."""
+    pre = root + "/"
+    w = {}
+    for k, a in read_checkpoint(prefix).items():
+        if k.startswith(pre) and k.endswith(SUFFIX) and ".OPTIMIZER_SLOT" not in k:
+            w[k[len(pre):-len(SUFFIX)]] = a.astype(np.float32)
+    if hps is not None:
+        from .weights import weight_spec
+        spec = weight_spec(hps, include_posterior)
+        missing = [p for p in spec if p not in w]
+        bad = [p for p in spec if p in w and tuple(w[p].shape) != tuple(spec[p])]
+        if strict and (missing or bad):
+            raise KeyError("checkpoint %s: missing %s, mis-shaped %s" % (prefix, missing[:5], bad[:5]))
+        w = {p: w[p] for p in spec if p in w}
+    return w
+
+
+# ---- writing --------------------------------------------------------------------------------------------------------------
+class _BlockBuilder:
+    def __init__(self, restart_interval=16):
+        self.buf = bytearray(); self.restarts = [0]; self.count = 0; self.last = b""; self.interval = restart_interval
+
+    def add(self, key, value):
+        shared = 0
+        if self.count < self.interval:
+            while shared < min(len(key), len(self.last)) and key[shared] == self.last[shared]:
+                shared += 1
+        else:
+            self.restarts.append(len(self.buf)); self.count = 0
+        self.buf += _varint(shared) + _varint(len(key) - shared) + _varint(len(value)) + key[shared:] + value
+        self.last = key; self.count += 1
+
+    def finish(self):
+        return bytes(self.buf) + b"".join(struct.pack("<I", r) for r in self.restarts) + struct.pack("<I", len(self.restarts))
+
+    def __len__(self):
+        return len(self.buf) + 4 * len(self.restarts) + 4
+
+
+def _write_table(path, items, block_size=4096):
+    """items: sorted [(key bytes, value bytes)] -> leveldb-format table, uncompressed."""
+    out = bytearray()
+    index = _BlockBuilder(restart_interval=1)
+
+    def emit(block_bytes):
+        off = len(out)
+        out.extend(block_bytes); out.append(0)
+        out.extend(struct.pack("<I", _mask(crc32c(bytes(block_bytes) + b"\x00"))))
+        return off, len(block_bytes)
+
+    cur = _BlockBuilder()
+    for i, (k, v) in enumerate(items):
+        cur.add(k, v)
+        if len(cur) >= block_size or i == len(items) - 1:
+            off, size = emit(cur.finish())
+            index.add(k, _varint(off) + _varint(size))      # the last key of the block is a valid separator
+            cur = _BlockBuilder()
+    meta_off, meta_size = emit(_BlockBuilder().finish())
+    idx_off, idx_size = emit(index.finish())
+    footer = _varint(meta_off) + _varint(meta_size) + _varint(idx_off) + _varint(idx_size)
+    out.extend(footer + bytes(40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC))
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+def write_checkpoint(prefix, tensors):
+    """Write ``{key: ndarray}`` as a one-shard tensor bundle (see the module docstring for what it is good for)."""
+    items = [(b"", _field(1, 0, _varint(1)) + _ld(3, _field(1, 0, _varint(1))))]      # num_shards = 1, version.producer = 1
+    off = 0
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        for key in sorted(tensors, key=lambda s: s.encode()):
+            a = np.asarray(tensors[key], order="C")          # (ascontiguousarray would promote 0-d to 1-d)
+            raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
+            f.write(raw)
+            shape = b"".join(_ld(2, _field(1, 0, _varint(d))) for d in a.shape)
+            entry = _field(1, 0, _varint(_DT_OF_NP[a.dtype])) + _ld(2, shape)
+            if off:
+                entry += _field(4, 0, _varint(off))
+            entry += _field(5, 0, _varint(len(raw))) + _field(6, 5, struct.pack("<I", _mask(crc32c(raw))))
+            items.append((key.encode(), entry))
+            off += len(raw)
+    _write_table(prefix + ".index", items)
+
+
+def save_model_weights(prefix, weights, root="model"):
+    """{weights.py path: ndarray} -> bundle with the object-based key names (no object-graph proto: see module docstring)."""
+    write_checkpoint(prefix, {"%s/%s%s" % (root, p, SUFFIX): np.asarray(a, np.float32) for p, a in weights.items()})

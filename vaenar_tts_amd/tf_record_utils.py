@@ -87,7 +87,7 @@ def _parse(buf):
 
 def serialize_tensor(array):
     """tf.io.serialize_tensor: TensorProto with dtype, shape and raw little-endian content."""
-    a = np.ascontiguousarray(array)
+    a = np.asarray(array, order="C")                   # (ascontiguousarray would promote 0-d to 1-d)
     dt = _DT_OF_NP[a.dtype]
     shape = b"".join(_ld(2, _field(1, 0, _varint(d))) for d in a.shape)
     return _field(1, 0, _varint(dt)) + _ld(2, shape) + _ld(4, a.astype(a.dtype.newbyteorder("<")).tobytes())

@@ -76,6 +76,8 @@ struct ChainStage {
   int kt0, nk;              // first k-tile and number of k-tiles consumed by this stage
   int n;                    // output columns (<= 256)
   int a0, a1, asw;          // activation panel a0 for k-tiles [0, asw), a1 for [asw, nk) (re-based to its tile 0)
+  int akt0;                 // first k-tile read from panel a0 (a column offset of 32*akt0 into the panel)
+  const float* pe; int pe_T; float pe_w;   // + pe_w * pe[(row % pe_T)][0..n) after the activation (positional term) or null
   const float* bias;        // [n] or null
   int act;
   int res;                  // residual panel index or -1

@@ -554,18 +554,55 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   return VNR_OK;
 }
 
+// A short chain of Dense layers on one row panel (gemm3.hip) in front of a block stack: e.g. folded ActNorm o
+// InvertibleLinear -> pre_projection (+PE) on the conditioning half -> Q|K|V of the first block.  Every stage reads a
+// panel (optionally from a k-tile offset: a column window) and may write HBM and/or a panel; wide outputs are cut into
+// 256-column stages.  *done = false (nothing launched) when a split image is missing or a shape does not fit.
+struct PreStage { const float* wt; int K, N; int src, akt0; const float* bias; const float* pe; int pe_T; float pe_w;
+                  float* out; int ldo; int dst; };
+int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const std::vector<PreStage>& stages, bool* done) {
+  *done = false;
+  static const bool off = getenv("VNR_NO_PRECHAIN") != nullptr;       // A/B switch
+  if (off || !(h->split_enabled && h->split_scope && h->chain_enabled) || Cin > 256 || (Cin & 31)) return VNR_OK;
+  ChainArgs c; memset(&c, 0, sizeof(c));
+  c.in0 = in; c.ld0 = ld_in; c.in1 = nullptr; c.M = M; c.D = Cin;
+  int n = 0;
+  double fl = 0.0;
+  for (const PreStage& p : stages) {
+    SplitRef r;
+    if ((p.K & 31) || p.K > 256 || (p.N & 3) || (p.out && (p.ldo & 3)) || !split_lookup(h, p.wt, p.K, p.N, r) || !r.opm) return VNR_OK;
+    if (p.N > 256 && p.dst >= 0) return VNR_OK;
+    for (int c0 = 0; c0 < p.N; c0 += 256) {
+      if (n >= kMaxChainStages) return VNR_OK;
+      ChainStage& s = c.st[n++];
+      s.w = r.opm + (size_t)(c0 / 32) * r.kt_total * 4096; s.kt_total = r.kt_total; s.kt0 = 0; s.nk = p.K / 32;
+      s.n = p.N - c0 < 256 ? p.N - c0 : 256; s.a0 = p.src; s.a1 = p.src; s.asw = s.nk; s.akt0 = p.akt0;
+      s.bias = p.bias ? p.bias + c0 : nullptr; s.act = ACT_IDENTITY; s.res = -1; s.acc_mode = 0;
+      s.pe = p.pe; s.pe_T = p.pe_T; s.pe_w = p.pe_w;
+      s.out = p.out ? p.out + c0 : nullptr; s.ldo = p.ldo; s.dst = p.dst; s.scale = r.scale;
+      fl += 2.0 * M * (double)p.K * s.n;
+    }
+  }
+  c.nstages = n;
+  TRY(run_chain(h, c, fl));
+  *done = true;
+  return VNR_OK;
+}
+
 // a stack of CrossAttentionBLKs (transform.py:53-56, decoder.py:188-192, posterior.py:124-127): block i's chain produces block
 // i+1's Q|K|V; `tails` are applied to the last block's output.  Returns the buffer holding the stack output.
 int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb, const float* kv, int kv_ld,
                const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau, float* ali_base,
-               size_t ali_stride, const std::vector<Tail>& tails, float** result) {
+               size_t ali_stride, const std::vector<Tail>& tails, float** result, float* qkv_pre = nullptr) {
   const int M = B * Tq;
   float* xc = xa; float* xn = xb;
   if (blks.empty()) { *result = xc; return VNR_OK; }
   const int D = blks[0].D;
-  WS(qkv0, (size_t)M * 3 * D); WS(qkv1, (size_t)M * 3 * D);
+  float* qkv0 = qkv_pre;                                 // Q|K|V of the first block already computed by a pre-chain
+  if (!qkv0) { qkv0 = ws_alloc(h, (size_t)M * 3 * D); if (!qkv0) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed"); }
+  WS(qkv1, (size_t)M * 3 * D);
   float* qc = qkv0; float* qn = qkv1;
-  bool ready = false;
+  bool ready = qkv_pre != nullptr;
   for (size_t b = 0; b < blks.size(); ++b) {
     std::vector<Tail> t;
     if (b + 1 < blks.size()) t.push_back({blks[b + 1].qkv_wt, 3 * D, nullptr, qn, 3 * D});
@@ -701,18 +738,34 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
   for (int s = 0; s < nsteps; ++s) {
     const FlowStep& f = h->flow[s];
     float* dst = (s == nsteps - 1) ? z_out : (zc == za ? zb : za);
-    GemmArgs g;   // actnorm o invertible linear
-    g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = f.fold_wt; g.ldw = C; g.bias = f.fold_b; g.C = dst; g.ldc = C; g.M = M; g.N = C;
-    TRY(run_gemm(h, g));
-    if (logprobs) RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)(-f.logdet_per_frame), B, h->stream));
     const bool upper = (s % 2) == 0;                      // prior.py:85-87
     const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;   // flow.py:227-228
-    g = GemmArgs(); g.A1 = dst + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
-    g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
-    TRY(run_gemm(h, g));
+    // one row-panel chain: (ActNorm o InvertibleLinear) -> pre_projection + pos_weight*PE on the conditioning half -> Q|K|V
+    // of the first block (three launches otherwise)
+    bool fused = false;
+    float* qkv_pre = nullptr;
+    if (!f.blks.empty() && !(half & 31) && f.blks[0].D == D) {
+      qkv_pre = ws_alloc(h, (size_t)M * 3 * D);
+      if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+      TRY(run_prechain(h, zc, C, C, M,
+                       {PreStage{f.fold_wt, C, C, 0, 0, f.fold_b, nullptr, 1, 0.f, dst, C, 1},
+                        PreStage{f.pre_wt, half, D, 1, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, 0},
+                        PreStage{f.blks[0].qkv_wt, D, 3 * D, 0, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1}}, &fused));
+    }
+    GemmArgs g;
+    if (!fused) {
+      qkv_pre = nullptr;
+      // actnorm o invertible linear
+      g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = f.fold_wt; g.ldw = C; g.bias = f.fold_b; g.C = dst; g.ldc = C; g.M = M; g.N = C;
+      TRY(run_gemm(h, g));
+      g = GemmArgs(); g.A1 = dst + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
+      g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+      TRY(run_gemm(h, g));
+    }
+    if (logprobs) RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)(-f.logdet_per_frame), B, h->stream));
     float* xc = nullptr;        // the log_scale | shift heads ride on the last block's chain (tail)
     TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
-                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc));
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc, qkv_pre));
     if (f.blks.empty()) {
       g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
       g.C = heads; g.ldc = C; g.M = M; g.N = C;
@@ -791,8 +844,21 @@ int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const
   if (rf < 1 || rf > c.max_reduction_factor) return fail(h, VNR_ERR_ARG, "reduction_factor out of range");
   WS(xa, (size_t)M * D); WS(xb, (size_t)M * D);
   GemmArgs g;
-  g.A1 = z; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = h->dec_pre_wt; g.ldw = C; g.bias = h->dec_pre_b; g.C = xa; g.ldc = D; g.M = M; g.N = D;
-  TRY(run_gemm(h, g));
+  // pre_projection -> Q|K|V of the first block as one row-panel chain (two launches otherwise)
+  bool fused = false;
+  float* qkv_pre = nullptr;
+  if (!h->dec_blks.empty() && h->dec_blks[0].D == D) {
+    qkv_pre = ws_alloc(h, (size_t)M * 3 * D);
+    if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+    TRY(run_prechain(h, z, C, C, M,
+                     {PreStage{h->dec_pre_wt, C, D, 0, 0, h->dec_pre_b, nullptr, 1, 0.f, xa, D, 1},
+                      PreStage{h->dec_blks[0].qkv_wt, D, 3 * D, 1, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1}}, &fused));
+  }
+  if (!fused) {
+    qkv_pre = nullptr;
+    g.A1 = z; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = h->dec_pre_wt; g.ldw = C; g.bias = h->dec_pre_b; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+  }
   const size_t ali_sz = (size_t)B * c.dec_attention_heads * Tz * Tt;
   // out_projection[:, :, :rf*out_dim] -> reshape [B, Tz*rf, out_dim] (decoder.py:193-195): only the live
   // columns are computed; the [M, rf*od] result IS the reshaped tensor.  It rides on the last block's chain.
@@ -800,7 +866,7 @@ int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const
   if (!init) { WS(tmp, (size_t)M * rf * od); init = tmp; }
   float* xc = nullptr;
   TRY(run_xstack(h, h->dec_blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.dec_attention_heads, c.dec_attention_temperature,
-                 alignments, ali_sz, {Tail{h->dec_out_wt, rf * od, h->dec_out_b, init, rf * od}}, &xc));
+                 alignments, ali_sz, {Tail{h->dec_out_wt, rf * od, h->dec_out_b, init, rf * od}}, &xc, qkv_pre));
   if (h->dec_blks.empty()) {
     g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = h->dec_out_wt; g.ldw = D; g.bias = h->dec_out_b;
     g.C = init; g.ldc = rf * od; g.M = M; g.N = rf * od;

@@ -158,7 +158,7 @@ panel_chain_kernel(const ChainArgs g) {
     auto read_a = [&](int kt, int set) {
       const int kc = kt < st.nk ? kt : st.nk - 1;
       const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
-      const int akt = (kc < st.asw) ? kc : kc - st.asw;
+      const int akt = (kc < st.asw) ? kc + st.akt0 : kc - st.asw;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         afr[set][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 2 * t + half));
@@ -221,6 +221,17 @@ panel_chain_kernel(const ChainArgs g) {
     } else if (st.act == ACT_TANH) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
+    }
+    if (st.pe) {                                                        // + pos_weight * PE[t] (encoder.py:85, transform.py:51)
+      const float* pr = st.pe + (size_t)(row % st.pe_T) * st.n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * wave + 8 * q + 4 * half;
+        if (cok[q] && row < g.M) {
+          const float4 p4 = *reinterpret_cast<const float4*>(pr + col);
+          v[4 * q] += st.pe_w * p4.x; v[4 * q + 1] += st.pe_w * p4.y; v[4 * q + 2] += st.pe_w * p4.z; v[4 * q + 3] += st.pe_w * p4.w;
+        }
+      }
     }
     if (st.res >= 0) {                                                  // residual = hi + lo of the panel entry (22 bits)
       const char* Rp = panel_ptr(st.res);
@@ -301,7 +312,7 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
   if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
   for (int i = 0; i < g.nstages; ++i) {
     const ChainStage& st = g.st[i];
-    if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
+    if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.akt0 < 0 || st.akt0 + (st.asw < st.nk ? st.asw : st.nk) > 8 || (st.pe && st.pe_T <= 0) || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
     if (st.out && (st.ldo & 3)) return hipErrorInvalidValue;
   }
   static bool attr_set = false;

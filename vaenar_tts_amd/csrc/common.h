@@ -148,6 +148,7 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 // training-mode statistics / dropout (misc.hip)
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s);
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s);
+hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s);
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
                                   float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s);
@@ -194,5 +195,7 @@ hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const
                               const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
                               float* cg, float* scalars, hipStream_t s);
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
+struct TransposeJobHost { const float* in; float* out; int rows, cols; };      // same layout as the device-side job record
+hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);
 
 }  // namespace vnr

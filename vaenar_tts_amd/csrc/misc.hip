@@ -461,7 +461,7 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 // Column sums of x[M][C] (row stride ld) in float64: out[c] += sum_m f(x[m][c]) with f(v) = v, or (v - mean[c])^2
 // when `mean` is given (second pass of a two-pass variance).  Used by BatchNormalization(training=True)
 // (tf.nn.moments over axes (0,1), padded frames included: utils.py:79-83) and ActNormFlow.init (flow.py:189-196).
-__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax) {
+__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;                       // 4 row groups per block
   double acc = 0.0;
@@ -492,11 +492,21 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
     if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
   }
   __syncthreads();
-  if (rg == 0 && c < C) atomicAdd(&out[c], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rg == 0 && c < C) {
+    const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (fout) atomicAdd(&fout[c], (float)t);             // straight into a float32 gradient (<= 128 block partials per column)
+    else atomicAdd(&out[c], t);
+  }
 }
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax);
+  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, (float*)nullptr);
+  return hipGetLastError();
+}
+// grad[c] += sum_m x[m][c]  (bias gradients), optional abs-max by-product
+hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s) {
+  int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
+  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, (const double*)nullptr, (double*)nullptr, amax, grad);
   return hipGetLastError();
 }
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {

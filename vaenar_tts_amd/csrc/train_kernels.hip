@@ -1140,4 +1140,32 @@ hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alph
   return hipGetLastError();
 }
 
+// ---- batched transpose: out_i[c][r] = in_i[r][c] for a table of matrices (the per-step refresh of the transposed kernels) ----
+struct TransposeJob { const float* in; float* out; int rows, cols; };
+__global__ void __launch_bounds__(256)
+transpose_batch_kernel(const TransposeJob* jobs) {
+  __shared__ float tile[32][33];
+  const TransposeJob j = jobs[blockIdx.y];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  const int tiles_c = (j.cols + 31) / 32, tiles_r = (j.rows + 31) / 32;
+  for (int t = blockIdx.x; t < tiles_r * tiles_c; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int r = r0 + k, c = c0 + tx;
+      tile[k][tx] = (r < j.rows && c < j.cols) ? j.in[(size_t)r * j.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int c = c0 + k, r = r0 + tx;
+      if (c < j.cols && r < j.rows) j.out[(size_t)c * j.rows + r] = tile[tx][k];
+    }
+  }
+}
+hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(64, njobs), dim3(256), 0, s, static_cast<const TransposeJob*>(jobs_device));
+  return hipGetLastError();
+}
+
 }  // namespace vnr

@@ -28,6 +28,7 @@ struct GemmArgs {
   const float* Wt = nullptr; int ldw = 0;
   const void* Wsplit = nullptr;     // optional pre-split fp16 image of Wt (split-fp16 MFMA path), see gemm2.hip
   float acc_scale = 1.f;            // 2^-s when the split image was pre-scaled by 2^s
+  const unsigned* a_absmax = nullptr;   // split path, A is a gradient: device word with the bits of max |A|; A is pre-scaled to ~2^10 (gemm2.hip)
   const float* bias = nullptr;
   int act = ACT_IDENTITY;
   const float* bn_scale = nullptr; const float* bn_shift = nullptr;

@@ -214,6 +214,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   // Slot reuse: tile kt+NSTAGE-1 overwrites the slot of tile kt-1, whose LDS reads every wave completed
   // (lgkmcnt(0)) before it passed the barrier of iteration kt-1.
   const int nk = (g.K + 31) >> 5;
+  float a_inv = 1.f;                                  // inverse of the gradient pre-scale of A (split path, see below)
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
   // LayerNorm row panels: the residual tile [32][N] is fetched NOW by LDS-DMA into a staging region behind the
@@ -243,6 +244,19 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     // A k-tile (32 k) = two k16 steps; lane-half g owns k = 16t + 8g .. +7 of step t:
     //   A (fp32 in LDS): 16-byte chunks 4t+2g, 4t+2g+1 -> split in registers
     //   B (pre-split)  : hi chunk 2t+g, lo chunk 4+2t+g
+    // A may be a gradient (training step): its magnitude follows the loss scale and can sit far below the fp16 range, so it
+    // is pre-scaled by the power of two that maps the launch-wide max |A| to ~2^10 and the result is scaled back exactly.
+    float a_sc = 1.f;
+    if (g.a_absmax) {
+      const unsigned bits = *g.a_absmax;
+      const int e = (int)(bits >> 23) & 0xff;
+      if (e > 0 && e < 255) {
+        int sft = 10 - (e - 127);
+        if (sft > 126) sft = 126; if (sft < -126) sft = -126;
+        a_sc = __uint_as_float((unsigned)(sft + 127) << 23);
+        a_inv = __uint_as_float((unsigned)(-sft + 127) << 23);
+      }
+    }
     int rdA[2][2], rdB[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -269,8 +283,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           _Float16 h, l;
-          split_f16(x0[i][e], h, l); ahi[set][i][e] = h; alo[set][i][e] = l;
-          split_f16(x1[i][e], h, l); ahi[set][i][4 + e] = h; alo[set][i][4 + e] = l;
+          split_f16(x0[i][e] * a_sc, h, l); ahi[set][i][e] = h; alo[set][i][e] = l;
+          split_f16(x1[i][e] * a_sc, h, l); ahi[set][i][4 + e] = h; alo[set][i][4 + e] = l;
         }
     };
     auto mfmaS = [&](int set, int kt_dma, int ns, bool with_dma) {
@@ -380,7 +394,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   // the 4-column groups n = .. + 8*q + 4*half + {0,1,2,3}, q = 0..3 (register 4q + e): 16-byte stores, and a
   // row's LayerNorm statistics are an in-lane sum plus one cross-half shuffle.
   stamp(3);
-  const float ascale = SPLIT ? g.acc_scale : 1.0f;
+  const float ascale = SPLIT ? g.acc_scale * a_inv : 1.0f;
   if (!LN) {
     if (vec_ok) {
 #pragma unroll

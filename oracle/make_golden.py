@@ -88,9 +88,47 @@ def build_ref(name):
     return out
 
 
+def build_train(name="train_tiny"):
+    """Training-step fixture (train.py:127-138) from the autograd restatement: losses, the gradient of every trainable
+    variable and the displacement of every variable after one Keras Adam step, each as a 19-number digest."""
+    from oracle.vaenar_torch import TorchOracle, adam_step
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.weights import init_weights, is_trainable
+    hps = tiny_hps()
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    b = make_batch(3, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                   ragged=True, text_step=3, mel_step=7)
+    r = np.random.Generator(np.random.PCG64(31))
+    mels = r.standard_normal((3, 40, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((3, 20, hps.Common.latent_dim)).astype(np.float32)
+    out = dict(ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], mels=mels, eps=eps,
+               kl_weight=np.float64(1.0), dropout_seed=np.int64(11), reduction_factor=np.int64(2),
+               weights_sha256=np.frombuffer(weights_digest(w).encode(), np.uint8))
+    g, sc = TorchOracle(hps, w).gradients(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, kl_weight=1.0,
+                                          length_weight=hps.Train.length_weight, dropout_seed=11)
+    out["scalars"] = np.array([sc["loss"], sc["mel_l2"], sc["kl"], sc["length_l2"]], np.float64)
+    ww = {k: np.asarray(v, np.float64).copy() for k, v in w.items()}
+    m = {k: np.zeros_like(v) for k, v in ww.items() if is_trainable(k)}; v = {k: np.zeros_like(x) for k, x in m.items()}
+    adam_step(ww, g, m, v, 1, lr=hps.Train.learning_rate)
+    for k in sorted(g):                    # digests keep the fixture small: 16 strided samples + sum + l2 norm + max |.|
+        out["grad/" + k] = digest(g[k])
+        out["adam1/" + k] = digest(ww[k] - np.asarray(w[k], np.float64))
+    return out
+
+
+def digest(a):
+    """[16 samples at fixed strided flat positions | sum | l2 norm | max abs] of an array, float64."""
+    f = np.asarray(a, np.float64).reshape(-1)
+    idx = np.linspace(0, f.size - 1, 16).astype(np.int64)
+    return np.concatenate([f[idx], [f.sum(), np.sqrt((f * f).sum()), np.abs(f).max()]])
+
+
 def main():
     d = os.path.join(ROOT, "tests", "golden")
     os.makedirs(d, exist_ok=True)
+    np.savez_compressed(os.path.join(d, "train_tiny.npz"), **build_train())
+    print("wrote train_tiny", os.path.getsize(os.path.join(d, "train_tiny.npz")) // 1024, "KiB")
     for name in CASES:
         np.savez_compressed(os.path.join(d, name + ".npz"), **build(name))
         print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB")

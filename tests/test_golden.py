@@ -141,3 +141,47 @@ def test_hip_path_matches_reference_python(name):
         np.testing.assert_allclose(kl.numpy(), g["call_kl"], rtol=1e-3, atol=6e-2)
     finally:
         model.engine.close()
+
+
+# ---- training step fixture (tests/golden/train_tiny.npz, made by oracle/make_golden.py:build_train) ----------------------
+def _train_fixture():
+    from vaenar_tts_amd.configs import tiny_hps
+    g = _load("train_tiny")
+    hps = tiny_hps()
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode(), "synthetic weight generator changed"
+    return g, hps, w
+
+
+def test_autograd_oracle_reproduces_training_golden():
+    from oracle.make_golden import digest
+    from oracle.vaenar_torch import TorchOracle
+    g, hps, w = _train_fixture()
+    grads, sc = TorchOracle(hps, w).gradients(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], 2, g["eps"],
+                                              kl_weight=float(g["kl_weight"]), length_weight=hps.Train.length_weight,
+                                              dropout_seed=int(g["dropout_seed"]))
+    np.testing.assert_allclose([sc["loss"], sc["mel_l2"], sc["kl"], sc["length_l2"]], g["scalars"], rtol=1e-10)
+    for k in grads:
+        d, ref = digest(grads[k]), g["grad/" + k]
+        assert np.abs(d - ref).max() <= 1e-8 * max(ref[18], 1e-30) * max(1.0, np.sqrt(grads[k].size)) + 1e-13, k
+
+
+@pytest.mark.gpu
+def test_gpu_training_step_reproduces_golden():
+    """The HIP training step against the committed fixture -- no oracle at run time."""
+    from oracle.make_golden import digest
+    from vaenar_tts_amd.models import VAENAR
+    g, hps, w = _train_fixture()
+    model = VAENAR(hps, weights=w)
+    try:
+        out = model.train_step(g["ids"], g["mels"], g["text_lengths"], g["mel_lengths"], float(g["kl_weight"]), 2, eps=g["eps"],
+                               dropout_seed=int(g["dropout_seed"]), apply_update=False)
+        grads = model.gradients()
+    finally:
+        model.engine.close()
+    np.testing.assert_allclose(out, g["scalars"], rtol=1e-4)
+    for k in grads:
+        d, ref = digest(grads[k]), g["grad/" + k]
+        mx = max(ref[18], 1e-30)
+        assert np.abs(d[:16] - ref[:16]).max() <= 2e-3 * mx + 1e-7, k                    # sampled entries
+        assert abs(d[17] - ref[17]) <= 2e-3 * ref[17] + 1e-7 and abs(d[18] - ref[18]) <= 2e-3 * mx + 1e-7, k   # l2 norm, max

@@ -283,3 +283,40 @@ def test_model_init_actnorm(name):
         np.testing.assert_allclose(gmel.numpy(), omel, atol=MEL_TOL, rtol=0)
     finally:
         model.engine.close()
+
+
+def test_full_size_s1_properties():
+    """BASELINE.json's full configuration (B=16, T_text=128, T_mel=800, rf=2) through size-independent properties (the
+    float64 oracle takes minutes at this size): utterances are independent, so (i) a sub-batch run alone reproduces its rows
+    of the full batch, (ii) permuting the batch permutes the output, (iii) ragged lengths only change the padded tail of
+    each utterance's neighbours -- never another utterance; and the alignments are row-stochastic."""
+    hps = LJHPS
+    model = VAENAR(hps, weights=init_weights(hps, seed=1234, mode="synthetic", include_posterior=False))
+    try:
+        b = make_batch(16, 128, 800, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, seed=1234, temperature=1.0, text_step=4, mel_step=24)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        mel = mel.numpy()
+        assert mel.shape == (16, 800, 80) and np.isfinite(mel).all()
+        # (i) rows 3..6 alone (their own padded maximum is shorter: compare the frames that exist in both runs)
+        sel = slice(3, 7)
+        Tm = int(b["mel_lengths"][sel].max()); Tz = (Tm + 1) // 2
+        sub, _ = model.inference(b["ids"][sel], b["mel_lengths"][sel], b["text_lengths"][sel], reduction_factor=2,
+                                 eps=b["eps"][sel, :Tz])
+        sub = sub.numpy()
+        for i, row in enumerate(range(3, 7)):
+            n = int(b["mel_lengths"][row]) - 12           # PostNet (5 convs of width 5) reaches 10 frames back from the padding
+            np.testing.assert_allclose(sub[i, :n], mel[row, :n], atol=2e-5, rtol=0)
+        # (ii) a batch permutation permutes the rows (same shapes -> same kernels -> tight tolerance)
+        perm = np.random.Generator(np.random.PCG64(2)).permutation(16)
+        pmel, _ = model.inference(b["ids"][perm], b["mel_lengths"][perm], b["text_lengths"][perm], reduction_factor=2,
+                                  eps=b["eps"][perm])
+        np.testing.assert_allclose(pmel.numpy(), mel[perm], atol=1e-6, rtol=0)
+        # alignments: rows of valid queries sum to one over the valid keys
+        a = ali["decoder-attention-1"].numpy()
+        assert a.shape == (16, 4, 400, 128)
+        np.testing.assert_allclose(a.sum(-1), 1.0, atol=1e-5)
+        tl = int(b["text_lengths"][5])
+        assert np.abs(a[5, :, :int((b["mel_lengths"][5] + 1) // 2), tl:]).max() == 0.0      # masked keys get exactly zero weight
+    finally:
+        model.engine.close()

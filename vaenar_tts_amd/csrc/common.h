@@ -198,5 +198,7 @@ hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
 struct TransposeJobHost { const float* in; float* out; int rows, cols; };      // same layout as the device-side job record
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);
+struct SplitJobHost { const float* src; int rows, cols; char* dst; };            // same layout as the device-side job record
+hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
 
 }  // namespace vnr

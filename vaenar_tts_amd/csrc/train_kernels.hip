@@ -1168,4 +1168,30 @@ hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_
   return hipGetLastError();
 }
 
+// ---- batched split-fp16 image build (same image as misc.hip:split_weights_kernel) for a table of panels ---------------------
+struct SplitJob { const float* src; int rows, cols; char* dst; };
+__global__ void __launch_bounds__(256)
+split_batch_kernel(const SplitJob* jobs, float scale) {
+  const SplitJob j = jobs[blockIdx.y];
+  const int KT = (j.cols + 31) >> 5;
+  const size_t n = (size_t)j.rows * KT * 32;
+  _Float16* out = reinterpret_cast<_Float16*>(j.dst);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(idx & 31);
+    const size_t nk = idx >> 5;
+    const int kt = (int)(nk % KT);
+    const size_t r = nk / KT;
+    const int k = kt * 32 + p;
+    const float w = k < j.cols ? j.src[r * j.cols + k] * scale : 0.f;
+    const _Float16 hi = (_Float16)w;
+    out[nk * 64 + p] = hi;
+    out[nk * 64 + 32 + p] = (_Float16)(w - (float)hi);
+  }
+}
+hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_batch_kernel, dim3(32, njobs), dim3(256), 0, s, static_cast<const SplitJob*>(jobs_device), scale);
+  return hipGetLastError();
+}
+
 }  // namespace vnr

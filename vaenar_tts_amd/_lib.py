@@ -189,9 +189,7 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
         if ptr is None:
-            p = C.c_void_p()
-            check(engine.lib.vnr_malloc(engine.handle, max(self.nbytes, 4), C.byref(p)), engine.handle)
-            self.ptr = p.value
+            self.ptr = engine._take(max(self.nbytes, 4))
             self._owner = True
         else:
             self.ptr = ptr
@@ -223,7 +221,7 @@ class DeviceArray:
     def __del__(self):
         if getattr(self, "_owner", None) is True and self.engine is not None and self.engine.handle:
             try:
-                self.engine.lib.vnr_free(self.engine.handle, self.ptr)
+                self.engine._give(max(self.nbytes, 4), self.ptr)
             except Exception:
                 pass
 
@@ -241,6 +239,28 @@ class Engine:
         self.handle = h.value
         self.device = device
         self._weights_loaded = set()
+        # Freed device buffers are kept per size and handed out again: the steady state of a serving / training loop then
+        # issues no hipMalloc / hipFree (hipFree synchronises the device) and sees the same pointers every step.  Reuse is
+        # safe because everything runs in order on the engine's single stream.
+        self._pool = {}
+        self._pool_bytes = 0
+        self._pool_cap = 8 << 30
+
+    def _take(self, nbytes):
+        lst = self._pool.get(nbytes)
+        if lst:
+            self._pool_bytes -= nbytes
+            return lst.pop()
+        p = C.c_void_p()
+        check(self.lib.vnr_malloc(self.handle, nbytes, C.byref(p)), self.handle)
+        return p.value
+
+    def _give(self, nbytes, ptr):
+        if self._pool_bytes + nbytes <= self._pool_cap:
+            self._pool.setdefault(nbytes, []).append(ptr)
+            self._pool_bytes += nbytes
+        else:
+            self.lib.vnr_free(self.handle, ptr)
 
     # -- memory -----------------------------------------------------------------
     def empty(self, shape, dtype=np.float32):
@@ -337,6 +357,10 @@ class Engine:
 
     def close(self):
         if self.handle:
+            for lst in self._pool.values():
+                for ptr in lst:
+                    self.lib.vnr_free(self.handle, ptr)
+            self._pool.clear(); self._pool_bytes = 0
             self.lib.vnr_destroy(self.handle)
             self.handle = None
 

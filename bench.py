@@ -147,7 +147,7 @@ def main():
         if a["launches"]:
             gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             out["roofline_cross_attention"] = {
-                "kernel": "attn2_kernel<true> (decoder cross-attention core, alignments stored)",
+                "kernel": "attn3_kernel<true> (decoder cross-attention core on producer-split operand images, alignments stored)",
                 "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                 "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic.get("cross_attention_ali_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": a["bytes"] / a["launches"],

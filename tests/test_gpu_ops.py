@@ -169,6 +169,47 @@ def test_attention(eng, B, H, Tq, Tk, causal, want_ali, tau, ragged):
                 assert np.all(got[b, :, ql[b]:, :] == np.float32(1.0) / np.float32(Tk))
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,want_ali,tau,ragged", [
+    (3, 4, 400, 128, 1, 1.0, True),       # S1-shaped decoder cross attention with alignments
+    (3, 4, 400, 128, 0, 1.0, False),      # prior cross attention, nothing masked (fast path)
+    (2, 2, 7, 7, 1, 1.0, True),           # tiny: one partial key block, padded queries -> uniform rows
+    (2, 1, 33, 100, 1, 0.7, True),        # odd sizes (Tk % 4 == 0, partial last block), temperature != 1
+    (2, 4, 130, 65, 1, 1.0, True),        # Tk % 4 != 0: scalar alignment stores, third block holds one key
+    (1, 2, 64, 5, 0, 1.0, False),         # a single short key block
+    (2, 4, 96, 128, 0, 1.0, True),        # ragged without alignments
+])
+def test_attention_presplit(eng, B, H, Tq, Tk, want_ali, tau, ragged):
+    """attention3.hip (cross attention, Tk <= 128, operands as producer-split images) through vnr_op_attention with the
+    option "op_attn_presplit": same reference and tolerances as test_attention."""
+    r = rng(Tq * 5 + Tk)
+    D = 64 * H
+    q, k, v = 1.5 * r.standard_normal((B, Tq, D)), r.standard_normal((B, Tk, D)), r.standard_normal((B, Tk, D))
+    if ragged:
+        ql = np.maximum(1, Tq - np.arange(B) * max(1, Tq // 3)).astype(np.int32)
+        kl = np.maximum(1, Tk - np.arange(B) * max(1, Tk // 4)).astype(np.int32)
+    else:
+        ql, kl = np.full(B, Tq, np.int32), np.full(B, Tk, np.int32)
+    dq, dk, dv_ = (eng.to_device(t.astype(np.float32)) for t in (q, k, v))
+    dql, dkl = eng.to_device(ql), eng.to_device(kl)
+    ctx = eng.empty((B, Tq, D))
+    ali = eng.empty((B, H, Tq, Tk)) if want_ali else None
+    eng.set_option("op_attn_presplit", 1)
+    try:
+        _lib.check(eng.lib.vnr_op_attention(eng.handle, dq.ptr, D, dk.ptr, D, dv_.ptr, D, dql.ptr, dkl.ptr, B, H, Tq, Tk,
+                                            0, tau, ctx.ptr, D, None if ali is None else ali.ptr), eng.handle)
+    finally:
+        eng.set_option("op_attn_presplit", 0)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    rctx, rali = attention_ref(f(q), f(k), f(v), ql, kl, H, 0, np.float64(np.float32(tau)))
+    np.testing.assert_allclose(ctx.numpy(), rctx, atol=2e-5, rtol=1e-5)
+    if want_ali:
+        got = ali.numpy()
+        np.testing.assert_allclose(got, rali, atol=2e-6, rtol=1e-5)
+        for b in range(B):
+            if ql[b] < Tq:
+                assert np.all(got[b, :, ql[b]:, :] == np.float32(1.0) / np.float32(Tk))
+
+
 @pytest.mark.parametrize("rows,dim", [(5, 96), (6400, 256), (2048, 512), (3, 1024)])
 def test_layer_norm(eng, rows, dim):
     r = rng(rows + dim)

@@ -39,9 +39,11 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--split", type=int, default=0, help="use the split-fp16 GEMM kernel")
+    ap.add_argument("--presplit", type=int, default=0, help="cross attention through attention3 (operands converted to images first; only the attention3 launch is timed)")
     args = ap.parse_args()
     eng = _lib.Engine(tiny_hps(), 0)
     eng.set_option('op_dense_split', args.split)
+    eng.set_option('op_attn_presplit', args.presplit)
     r = np.random.Generator(np.random.PCG64(0))
     if args.what in ("gemm", "all"):
         print("%-20s %6s %5s %5s %9s %9s %7s" % ("gemm", "M", "K", "N", "avg_us", "TFLOP/s", "frac"))

@@ -292,7 +292,7 @@ static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
   auto k = attn_kernel<KT, ALI>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid((a.Tq + 127) / 128, a.H, a.B);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+  vnr_launch(k, grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

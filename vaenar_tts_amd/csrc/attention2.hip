@@ -405,11 +405,11 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
   if (a.ali) {
     auto k = attn2_kernel<true>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, nqb);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
   } else {
     auto k = attn2_kernel<false>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, nqb);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
   }
   return hipGetLastError();
 }

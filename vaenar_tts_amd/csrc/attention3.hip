@@ -1,0 +1,251 @@
+// Cross-attention core on pre-split operands (gfx950, split-fp16 MFMA 32x32x16), Tk <= 128.
+//
+// Same contract as attention.hip / attention2.hip (reference modules/attention.py:221-246: scale, key ^ query mask with the
+// -2**32+1 fill, softmax, . V, optional alignments) for the cross-attention of a CrossAttentionBLK (attention.py:445-447),
+// whose memory is the text (Tk = T_text <= 128 at every BASELINE configuration).
+//
+// Why a third kernel.  attention2 is bound by VALU issue, not by HBM: per wave ~1400 vector instructions against 48 MFMAs,
+// a third of them spent splitting fp32 K / V / Q into the fp16 hi/lo pairs the f16 matrix pipe wants -- work repeated by every
+// workgroup that re-reads the same K/V (14x for the decoder cross-attention).  Here the PRODUCERS of Q, K, V (the chain kernel's
+// query stage, the K|V panel GEMM) store the operands already split, in the layouts of common.h "attention operand images":
+//   * the images are operand-major: every Q / K / V operand is ONE fully coalesced 1 KiB wave load straight from global memory
+//     into MFMA operand position (no LDS, no conversion, no gather: V's k-slot order matches P's register order);
+//   * so the kernel needs no K/V staging, no DMA ring, no barrier before the first MFMA.
+//
+// Decomposition.  A workgroup = 4 waves = ONE 32-query tile of one (batch, head); wave w owns keys 32w .. 32w+31 (Tk <= 128 => at
+// most 4 key blocks): 13 x B x H workgroups at Tq = 400 instead of 7 x B x H -- finer grains, all co-resident (4 per CU).
+//   S^T = K.Q^T (lane = query: softmax statistics are in-lane + one cross-half shuffle, P is already the A operand of P.V);
+//   the four waves exchange (row max, row sum) once through LDS: p = 2^(t - m_w) locally, then one factor 2^(m_w - M) / L;
+//   alignments leave as 128-byte row pieces after a wave-private 32x32 LDS transpose (16-byte lanes, XOR-swizzled chunks);
+//   the four partial O = P.V tiles are summed through LDS, each wave finishing 8 of the 32 accumulator registers.
+// Logits are kept in the log2 domain (scale 1/8 . log2(e) / temperature folded into one multiply, exp = v_exp_f32): one
+// rounding of t = s.log2(e) differs from the reference's exp(s - max) by <= 2^-24 . |t| relative -- below 3e-6 for |s| < 40.
+#include "common.h"
+#include <math.h>
+
+namespace vnr {
+
+namespace {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int frow3(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __forceinline__ f32x16 mfma3x(const h8& ah, const h8& al, const h8& bh, const h8& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  return c;
+}
+__device__ __forceinline__ void split8x(const float* x, h8& hi, h8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+}
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr int kXchg = 8192;                         // bytes of exchange space per wave
+}  // namespace
+
+template <bool ALI>
+__global__ void __launch_bounds__(256, 4)
+attn3_kernel(const Attn3Args a, int nqt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stats = reinterpret_cast<float*>(smem + 4 * kXchg);      // [4 waves][m | l][32]
+
+  // XCD-aware work map (as attention2): all query tiles of one (batch, head) share K/V -> same id mod 8 = same L2
+  const int npairs = a.B * a.H;
+  const int wg = blockIdx.x;
+  int pair, qidx;
+  if ((npairs & 7) == 0) {
+    const int xcd = wg & 7, j = wg >> 3, ppx = npairs >> 3;
+    qidx = j / ppx;
+    pair = (j - qidx * ppx) * 8 + xcd;
+  } else {
+    qidx = wg / npairs;
+    pair = wg - qidx * npairs;
+  }
+  const int b = pair / a.H, hd = pair - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q0 = qidx * 32, kb0 = 32 * wave;
+  const bool active = kb0 < a.Tk;                     // wave-uniform: this wave's key block exists
+  const bool partial = kb0 + 32 > a.Tk;               // ... but not all of it
+
+  // ---- operand loads: every one a fully coalesced 1 KiB wave read of an operand-major image tile (common.h).  All 24 are
+  //      issued before the first MFMA so that V's HBM round trip overlaps Q/K's.
+  h8 qhi[4], qlo[4], khi[4], klo[4], vhi[2][2], vlo[2][2];
+  {
+    const int ttq = (a.Tq + 31) >> 5, ttk = (a.Tk + 31) >> 5;
+    const char* qp = a.Qi + ((size_t)(b * a.H + hd) * ttq + qidx) * kAoiTile + lane * 16;
+    const size_t kt = ((size_t)(b * a.H + hd) * ttk + (active ? wave : 0)) * kAoiTile + lane * 16;
+    const char* kp = a.Ki + kt;
+    const char* vp = a.Vi + kt;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      qhi[t] = *reinterpret_cast<const h8*>(qp + 1024 * t);
+      qlo[t] = *reinterpret_cast<const h8*>(qp + 4096 + 1024 * t);
+      khi[t] = *reinterpret_cast<const h8*>(kp + 1024 * t);
+      klo[t] = *reinterpret_cast<const h8*>(kp + 4096 + 1024 * t);
+    }
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        vhi[tp][nb] = *reinterpret_cast<const h8*>(vp + (tp * 2 + nb) * 1024);
+        vlo[tp][nb] = *reinterpret_cast<const h8*>(vp + 4096 + (tp * 2 + nb) * 1024);
+      }
+  }
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq;
+  const int klen = a.k_len ? a.k_len[b] : a.Tk;
+
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
+  }
+
+  // ---- logits (log2 domain) and masks ------------------------------------------------------------------------------------
+  const float c = (a.temperature != 1.0f) ? 0.125f * kLog2e / a.temperature : 0.125f * kLog2e;
+  const int iq = q0 + l31;
+  if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen) {          // wave-uniform: nothing masked in this block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] *= c;
+  } else {
+    const bool qvalid = iq < qlen;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kb0 + frow3(r, half);
+      float s = st[r] * c;
+      s = (qvalid && j < klen) ? s : kMaskFill * kLog2e;          // attention.py:240
+      if (j >= a.Tk) s = -INFINITY;                                 // key does not exist
+      st[r] = s;
+    }
+  }
+  float mt = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+  const float m_w = fmaxf(mt, -3.0e38f);                            // finite floor: a wave without keys gives p = 0, not NaN
+  float ls = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_w); st[r] = p; ls += p; }
+  ls += __shfl_xor(ls, 32, 64);
+  if (half == 0) { stats[wave * 64 + l31] = m_w; stats[wave * 64 + 32 + l31] = ls; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    float mw[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
+    const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) L += lw[w] * __builtin_amdgcn_exp2f(mw[w] - M);
+    const float f = __builtin_amdgcn_exp2f(m_w - M) * (1.0f / L);  // softmax, attention.py:242 (one division per row)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] *= f;
+  }
+
+  float* xw = reinterpret_cast<float*>(smem + wave * kXchg);       // this wave's exchange space
+  if (ALI && active) {
+    // alignment rows: 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 p4 = {st[4 * j], st[4 * j + 1], st[4 * j + 2], st[4 * j + 3]};
+      *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int rr = 8 * x + (lane >> 3), kc = lane & 7;
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
+      const int qrow = q0 + rr, key = kb0 + 4 * kc;
+      if (qrow < a.Tq) {
+        float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
+        if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
+      }
+    }
+  }
+
+  // ---- O partial = P.V over this wave's 32 keys ----------------------------------------------------------------------------
+  f32x16 O[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+  if (active) {
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      if (partial) {                                  // positions past Tk hold whatever the workspace held: force zeros
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (key >= a.Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+        }
+      }
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = st[8 * tp + e];
+      h8 phi, plo;
+      split8x(pv, phi, plo);
+      O[0] = mfma3x(phi, plo, vhi[tp][0], vlo[tp][0], O[0]);
+      O[1] = mfma3x(phi, plo, vhi[tp][1], vlo[tp][1], O[1]);
+    }
+  }
+  // ---- sum the four partial tiles: [wave][j = 4 nb + (r>>2)][lane][4] ------------------------------------------------------
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const f32x4 o4 = {O[nb][4 * jj], O[nb][4 * jj + 1], O[nb][4 * jj + 2], O[nb][4 * jj + 3]};
+      *reinterpret_cast<f32x4*>(xw + (((nb * 4 + jj) * 64 + lane) << 2)) = o4;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int jx = 2 * wave + u, nb = jx >> 2, rb = 4 * (jx & 3);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + ((jx * 64 + lane) << 4));
+    float* ob = a.ctx + (size_t)b * a.o_bs + hd * 64 + nb * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = q0 + frow3(rb + e, half);
+      if (row < a.Tq) __builtin_nontemporal_store(acc[e], ob + (size_t)row * a.ldo);
+    }
+  }
+}
+
+// fp32 [rows][cols] -> operand images, one thread per 4 columns
+__global__ void __launch_bounds__(256) aoi_convert_kernel(const float* src, int ld, int rows, int cols, const AoiDesc d) {
+  const int q4 = cols >> 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * q4) return;
+  const int row = (int)(i / q4), col = 4 * (int)(i - (size_t)row * q4);
+  const float4 x = *reinterpret_cast<const float4*>(src + (size_t)row * ld + col);
+  const float v[4] = {x.x, x.y, x.z, x.w};
+  aoi_store4(d, row, col, v);
+}
+
+hipError_t launch_aoi_convert(const float* src, int ld, int rows, int cols, const AoiDesc& d, hipStream_t s) {
+  if ((cols & 63) || (ld & 3) || d.mode == 0 || d.T <= 0 || d.TT != (d.T + 31) / 32) return hipErrorInvalidValue;
+  const size_t n = (size_t)rows * (cols >> 2);
+  vnr_launch(aoi_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld, rows, cols, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention3(const Attn3Args& a, hipStream_t s) {
+  if (a.Tk <= 0 || a.Tk > 128 || a.Tq <= 0 || !a.Qi || !a.Ki || !a.Vi || !a.ctx) return hipErrorInvalidValue;
+  const int nqt = (a.Tq + 31) / 32;
+  const size_t lds = 4 * kXchg + 4 * 64 * sizeof(float);
+  dim3 grid(nqt * a.H * a.B);
+  if (a.ali) vnr_launch(attn3_kernel<true>, grid, dim3(256), lds, s, a, nqt);
+  else vnr_launch(attn3_kernel<false>, grid, dim3(256), lds, s, a, nqt);
+  return hipGetLastError();
+}
+
+}  // namespace vnr

@@ -3,7 +3,36 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <hip/hip_ext.h>
+#include <tuple>
+#include <utility>
+
 namespace vnr {
+
+// ---- instrumented launch -------------------------------------------------------------------------------------------------
+// Every kernel of the library is launched through vnr_launch.  When the engine's profiler has armed the slot (ProfScope in
+// engine.hip) the launch goes through hipExtLaunchKernel with a start and a stop event attached to the DISPATCH ITSELF: their
+// difference is the kernel's own begin..end on the GPU -- the quantity rocprofv3 --kernel-trace reports -- instead of an event
+// pair recorded around the launch, which adds ~2.5 us of packet processing to every kernel.
+struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; bool armed = false, used = false; };
+inline thread_local ProfSlot g_prof_slot;
+#if defined(__HIPCC__)
+template <typename... KArgs, typename Tuple, size_t... I>
+inline void vnr_launch_ext(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, Tuple& t, std::index_sequence<I...>) {
+  void* ptrs[] = {static_cast<void*>(&std::get<I>(t))..., nullptr};
+  g_prof_slot.used = true;
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s, g_prof_slot.e0, g_prof_slot.e1, 0);
+}
+template <typename... KArgs, typename... Args>
+inline void vnr_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, Args&&... args) {
+  if (g_prof_slot.armed && !g_prof_slot.used) {
+    std::tuple<std::remove_cv_t<KArgs>...> t{static_cast<std::remove_cv_t<KArgs>>(args)...};
+    vnr_launch_ext(kernel, grid, block, lds, s, t, std::index_sequence_for<KArgs...>{});
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, static_cast<KArgs>(args)...);
+  }
+}
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -13,6 +42,63 @@ constexpr float kLnEps = 1e-3f;               // Keras LayerNormalization defaul
 constexpr float kBnEps = 1e-3f;               // Keras BatchNormalization default
 
 enum { ACT_IDENTITY = 0, ACT_RELU = 1, ACT_TANH = 2 };
+
+// ---- attention operand images (consumed by attention3.hip, produced by the GEMM / chain epilogues) -------------------
+// The f16 matrix pipe wants Q, K, V as fp16 hi/lo pairs (3-term split, gemm2.hip).  Splitting them inside the attention
+// kernel costs more VALU issue slots than the MFMAs themselves and is repeated by every workgroup that re-reads the same
+// K/V, so the PRODUCER of Q / K / V stores the split form once -- and stores it OPERAND-MAJOR, so that every operand
+// load of the attention kernel is one fully coalesced 1 KiB wave read (lane l gets bytes [16 l, 16 l + 16)):
+//   image = [batch][head][tile of 32 rows (queries / keys)] x 8 KiB;  rows beyond T inside the last tile are never written.
+//   Q / K tile: [hi | lo][t = 0..3][lane = 32 g + (row & 31)][8 x fp16: channels d = 16 t + 8 g + 0..7]
+//               (lane (row, g) of a 32x32x16 MFMA holds k-slots 8g..8g+7 of step t);
+//   V tile:     [hi | lo][tp = 0..1][nb = 0..1][lane = 32 g + (d & 31)][8 x fp16: k-slots e = 0..7], d = 32 nb + (d & 31),
+//               k-slot (tp, g, e) = key 16 tp + (e & 3) + 4 g + 8 (e >> 2) of the tile -- the order in which the S^T
+//               accumulator of attention3 already holds P, so the B operand of P.V needs no gather.
+// mode 0: plain fp32 output.  mode 1: every column is Q/K-type (image at `qk`).  mode 2: every column is V-type (image at
+// `vt`).  mode 3: a cross K|V panel -- column blocks of 2*D: the first D columns (K) go to image `qk` + blk * blk_bytes, the
+// last D columns (V) to `vt` + blk * blk_bytes, blk = column / (2*D).
+struct AoiDesc {
+  int mode = 0;
+  int D = 0;                // H * 64
+  int T = 1;                // rows per batch element
+  int TT = 1;               // tiles per batch element = ceil(T / 32)
+  char* qk = nullptr;       // Q/K-type images [block][B][H][TT][8 KiB]
+  char* vt = nullptr;       // V-type images   [block][B][H][TT][8 KiB]
+  long long blk_bytes = 0;  // B * H * TT * 8192
+};
+constexpr int kAoiTile = 8192;
+#if defined(__HIPCC__)
+typedef _Float16 aoi_h4 __attribute__((ext_vector_type(4)));
+// 4 consecutive output columns [col, col+4) of row `row` (col % 4 == 0)
+__device__ __forceinline__ void aoi_store4(const AoiDesc& a, int row, int col, const float* v) {
+  aoi_h4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[e]; hi[e] = h; lo[e] = (_Float16)(v[e] - (float)h); }
+  int c = col, blk = 0;
+  bool is_v = a.mode == 2;
+  if (a.mode == 3) {
+    blk = col / (2 * a.D);
+    c = col - blk * 2 * a.D;
+    if (c >= a.D) { is_v = true; c -= a.D; }
+  }
+  const int b = row / a.T, t = row - b * a.T, r = t & 31;
+  const int head = c >> 6, d = c & 63, H = a.D >> 6;
+  char* base = (is_v ? a.vt : a.qk) + (size_t)blk * a.blk_bytes + ((size_t)(b * H + head) * a.TT + (t >> 5)) * kAoiTile;
+  if (!is_v) {
+    char* p = base + (d >> 4) * 1024 + ((((d >> 3) & 1) * 32 + r) << 4) + (d & 7) * 2;
+    *reinterpret_cast<aoi_h4*>(p) = hi;
+    *reinterpret_cast<aoi_h4*>(p + 4096) = lo;
+  } else {
+    const int o = r & 15, pos = (o & 3) | ((o & 4) << 1) | ((o & 8) >> 1);     // k-slot order: bits 2 and 3 swapped
+    char* p = base + ((r >> 4) & 1) * 2048 + (d >> 5) * 1024 + ((((pos >> 3) * 32) + (d & 31)) << 4) + (pos & 7) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {          // d + e stays inside the same 32-channel block (d % 4 == 0)
+      *reinterpret_cast<_Float16*>(p + 16 * e) = hi[e];
+      *reinterpret_cast<_Float16*>(p + 4096 + 16 * e) = lo[e];
+    }
+  }
+}
+#endif
 
 // C[M,N] = epilogue( A[M,K] . W[K,N] ), W given transposed as Wt[N][K] (k contiguous).
 // A is assembled on the fly:
@@ -42,6 +128,7 @@ struct GemmArgs {
   // fused LayerNorm epilogue (row-panel kernel, requires N <= 256; wider rows use launch_layer_norm)
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]
+  AoiDesc aoi;                      // mode != 0: C is written as an attention operand image (attention3.hip) instead of fp32
 };
 
 struct AttnArgs {
@@ -85,6 +172,8 @@ struct ChainStage {
   const float* gamma; const float* beta;   // LayerNorm or null
   int acc_mode;             // 0: plain stage; 1/2/3: FFN second layer over hidden chunks (start / continue / finish+epilogue)
   float* out; int ldo;      // HBM output [M, n] or null
+  int out_fmt;              // 0: fp32; 1: `out` is a Q-type attention operand image (AoiDesc mode 1, D = n, n % 64 == 0)
+  int aoi_T;                // out_fmt 1: rows per batch element
   int dst;                  // destination panel or -1
   float scale;              // 2^-s of the pre-scaled weight image
 };
@@ -104,6 +193,19 @@ hipError_t launch_gemm2(const GemmArgs& g, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention2_supported(const AttnArgs& a);      // balanced DMA-fed kernel (attention2.hip) can take it
 hipError_t launch_attention2(const AttnArgs& a, hipStream_t s);
+// cross attention on pre-split operands, Tk <= 128 (attention3.hip)
+struct Attn3Args {
+  const char* Qi;                              // Q image [B][H][ceil(Tq/32)][8 KiB]
+  const char* Ki; const char* Vi;              // K / V images [B][H][ceil(Tk/32)][8 KiB]
+  const int32_t* q_len; const int32_t* k_len;  // [B] or null
+  float* ctx; int ldo; long long o_bs;         // [B,Tq,H*64] fp32
+  float* ali;                                  // [B,H,Tq,Tk] or null
+  int B, H, Tq, Tk;
+  float temperature;
+};
+hipError_t launch_attention3(const Attn3Args& a, hipStream_t s);
+// fp32 [rows][cols] -> operand images (tests, op-level entry; the engine's producers write the images directly)
+hipError_t launch_aoi_convert(const float* src, int ld, int rows, int cols, const AoiDesc& d, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);
 hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s);

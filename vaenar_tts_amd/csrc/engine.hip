@@ -118,6 +118,11 @@ struct vnr_context {
   std::vector<void*> split_allocs;
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
+  bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
+  // cross K|V panels of the current call that were written as attention operand images (cleared with the workspace)
+  struct KvAoi { const float* base; int n; int D; int B; int Tt; AoiDesc d; };
+  std::vector<KvAoi> kv_aoi;
   bool split_encoder = true;     // engine option "split_encoder": the text encoder uses the split path too (measured as accurate as exact fp32: profiles/r01_split_accuracy.txt)
   bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
   bool training = false;         // engine option "training": Dropout active, BatchNormalization on batch statistics (+ moving update)
@@ -159,7 +164,7 @@ int fail(vnr_handle h, int code, const std::string& msg) {
   } while (0)
 
 // ---- arena --------------------------------------------------------------------------------------
-void ws_reset(vnr_handle h) { for (auto& c : h->chunks) c.off = 0; }
+void ws_reset(vnr_handle h) { for (auto& c : h->chunks) c.off = 0; h->kv_aoi.clear(); }
 
 float* ws_alloc(vnr_handle h, size_t nfloats) {
   size_t bytes = ((nfloats * sizeof(float)) + 255) & ~(size_t)255;
@@ -182,11 +187,18 @@ hipEvent_t get_event(vnr_handle h) {
 }
 struct ProfScope {
   vnr_handle h; ProfRec rec; bool on;
+  // the two events ride on the kernel's own dispatch packet (vnr_launch, common.h); a scope whose body launched nothing
+  // through vnr_launch records them back to back (zero duration)
   ProfScope(vnr_handle h_, int cls, double flops, double bytes) : h(h_), on(h_->profiling) {
     h->launches++;
-    if (on) { rec = {cls, get_event(h), get_event(h), flops, bytes}; hipEventRecord(rec.e0, h->stream); }
+    if (on) { rec = {cls, get_event(h), get_event(h), flops, bytes}; g_prof_slot.e0 = rec.e0; g_prof_slot.e1 = rec.e1; g_prof_slot.used = false; g_prof_slot.armed = true; }
   }
-  ~ProfScope() { if (on) { hipEventRecord(rec.e1, h->stream); h->prof.push_back(rec); } }
+  ~ProfScope() {
+    if (!on) return;
+    if (!g_prof_slot.used) { hipEventRecord(rec.e0, h->stream); hipEventRecord(rec.e1, h->stream); }
+    g_prof_slot.armed = false;
+    h->prof.push_back(rec);
+  }
 };
 
 int run_gemm(vnr_handle h, const GemmArgs& g_in) {
@@ -272,6 +284,15 @@ int run_attention(vnr_handle h, const AttnArgs& a, bool cross) {
   ProfScope ps(h, cross ? (a.ali ? CLS_ATTN_CROSS_ALI : CLS_ATTN_CROSS) : CLS_ATTN_SELF, fl, io);
   hipError_t e = launch_attention(a, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(e));
+  return VNR_OK;
+}
+int run_attention3(vnr_handle h, const Attn3Args& a) {
+  const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
+                    (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
+  const double fl = 4.0 * (double)a.B * a.H * a.Tq * (double)a.Tk * 64;
+  ProfScope ps(h, a.ali ? CLS_ATTN_CROSS_ALI : CLS_ATTN_CROSS, fl, io);
+  hipError_t e = launch_attention3(a, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention3 launch: ") + hipGetErrorString(e));
   return VNR_OK;
 }
 int run_ln(vnr_handle h, const float* x, const float* g, const float* b, int rows, int dim, float* y) {
@@ -434,6 +455,18 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
   return VNR_OK;
 }
 
+// the operand images of the cross K|V that run_xblk is about to read at kv + col (null when that panel is plain fp32)
+const vnr_context::KvAoi* find_kv_aoi(vnr_handle h, const float* kv, int col, int D, int B, int Tt, int* blk) {
+  for (const auto& r : h->kv_aoi) {
+    const ptrdiff_t off = (kv + col) - r.base;
+    if (off < 0 || off >= r.n || r.D != D || r.B != B || r.Tt != Tt || off % (2 * D)) continue;
+    *blk = (int)(off / (2 * D));
+    return &r;
+  }
+  return nullptr;
+}
+
+
 // ---- module bodies ----------------------------------------------------------------------------------
 // CrossAttentionBLK.call (attention.py:436-452).  x [M,D] -> out [M,D]; kv = cross K|V panel output
 // [B*Tt, kv_ld] of the memory; ali (optional) [B,H,Tq,Tt].
@@ -444,7 +477,10 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
              const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau,
              float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails) {
   const int M = B * Tq, D = k.D, F = k.F;
-  WS(sa, (size_t)M * D); WS(y, (size_t)M * D); WS(q, (size_t)M * D); WS(ca, (size_t)M * D);
+  // cross K|V written as attention operand images (run_kv): the query is produced as an image too and attention3 runs
+  int kv_blk = 0;
+  const vnr_context::KvAoi* ka = find_kv_aoi(h, kv, k.kv_col, D, B, Tt, &kv_blk);
+  WS(sa, (size_t)M * D); WS(y, (size_t)M * D); WS(q, (size_t)B * ((Tq + 31) / 32 * 32) * D); WS(ca, (size_t)M * D);
   GemmArgs g;
   // self attention: fused Q|K|V projection (no bias, attention.py:154-159)
   if (!qkv_ready) {
@@ -482,7 +518,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     s0.act = ACT_IDENTITY; s0.res = 0; s0.gamma = k.ln1_g; s0.beta = k.ln1_b; s0.acc_mode = 0; s0.out = y; s0.ldo = D; s0.dst = 0; s0.scale = r_p1.scale;
     ChainStage& s1 = c.st[1];
     s1.w = r_q.opm; s1.kt_total = r_q.kt_total; s1.kt0 = 0; s1.nk = PT; s1.n = D; s1.a0 = 0; s1.a1 = 0; s1.asw = PT; s1.bias = nullptr; s1.act = ACT_IDENTITY;
-    s1.res = -1; s1.gamma = nullptr; s1.beta = nullptr; s1.acc_mode = 0; s1.out = q; s1.ldo = D; s1.dst = -1; s1.scale = r_q.scale;
+    s1.res = -1; s1.gamma = nullptr; s1.beta = nullptr; s1.acc_mode = 0; s1.out = q; s1.ldo = D; s1.dst = -1; s1.scale = r_q.scale; s1.out_fmt = ka ? 1 : 0; s1.aoi_T = Tq;
     TRY(run_chain(h, c, 2.0 * M * D * (2.0 * D + D)));
   } else {
     g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.A2 = sa; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj1_wt; g.ldw = 2 * D;
@@ -490,13 +526,24 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     if (D > 256) { g.ln_gamma = nullptr; g.ln_beta = nullptr; TRY(run_gemm(h, g)); TRY(run_ln(h, y, k.ln1_g, k.ln1_b, M, D, y)); }
     else TRY(run_gemm(h, g));
     g = GemmArgs(); g.A1 = y; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.q_wt; g.ldw = D; g.C = q; g.ldc = D; g.M = M; g.N = D;
+    if (ka) { g.aoi.mode = 1; g.aoi.D = D; g.aoi.T = Tq; g.aoi.TT = (Tq + 31) / 32; g.aoi.qk = reinterpret_cast<char*>(q); }
     TRY(run_gemm(h, g));
   }
   // cross attention
+  if (ka) {
+    Attn3Args t;
+    t.Qi = reinterpret_cast<const char*>(q);
+    t.Ki = ka->d.qk + (size_t)kv_blk * ka->d.blk_bytes; t.Vi = ka->d.vt + (size_t)kv_blk * ka->d.blk_bytes;
+    t.q_len = q_len; t.k_len = m_len; t.ctx = ca; t.ldo = D; t.o_bs = (long long)Tq * D; t.ali = ali;
+    t.B = B; t.H = heads; t.Tq = Tq; t.Tk = Tt; t.temperature = tau;
+    if (heads * 64 != D) return fail(h, VNR_ERR_ARG, "attention3: heads * 64 != attention width");
+    TRY(run_attention3(h, t));
+  } else {
   a.Q = q; a.ldq = D; a.K = kv + k.kv_col; a.ldk = kv_ld; a.V = kv + k.kv_col + D; a.ldv = kv_ld;
   a.q_len = q_len; a.k_len = m_len; a.ctx = ca; a.ldo = D; a.ali = ali; a.Tq = Tq; a.Tk = Tt; a.causal = 0;
   a.q_bs = (long long)Tq * D; a.k_bs = (long long)Tt * kv_ld; a.v_bs = a.k_bs; a.o_bs = (long long)Tq * D;
   TRY(run_attention(h, a, true));
+  }
 
   if (chain) {
     // chain C: o = LN2(att_proj2(concat(y, ca)) + y) ; out = LN(dense2(relu(dense1(o))) + o) ; tails on out
@@ -652,12 +699,22 @@ int refresh_bn_affine(vnr_handle h) {
 }
 
 // cross-attention K|V of the memory for a group of blocks: one GEMM over a stacked panel
-int run_kv(vnr_handle h, const float* text_embd, int rows, int mem, const float* panel, int n, float* out) {
+// Cross K|V of the memory for a run of blocks (one GEMM).  D > 0: every block of the panel has attention width D = H*64 and the
+// consumers are run_xblk cross-attentions; when Tt <= 128 the panel is then written as attention operand images (side buffers;
+// common.h) instead of fp32 and registered in h->kv_aoi so that run_xblk takes attention3.
+int run_kv(vnr_handle h, const float* text_embd, int B, int Tt, int mem, const float* panel, int n, float* out, int D) {
   GemmArgs g;
-  g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = rows; g.N = n;
+  g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = B * Tt; g.N = n;
+  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g) && !getenv("VNR_GEMM_V1")) {
+    const int nblk = n / (2 * D), TT = (Tt + 31) / 32;
+    const size_t blk_bytes = (size_t)B * (D / 64) * TT * kAoiTile;
+    WS(img, 2 * nblk * blk_bytes / 4);
+    g.aoi.mode = 3; g.aoi.D = D; g.aoi.T = Tt; g.aoi.TT = TT; g.aoi.blk_bytes = (long long)blk_bytes;
+    g.aoi.qk = reinterpret_cast<char*>(img); g.aoi.vt = g.aoi.qk + nblk * blk_bytes;
+    h->kv_aoi.push_back({out, n, D, B, Tt, g.aoi});
+  }
   return run_gemm(h, g);
 }
-
 int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int B, int T, float pos_step, float* out);
 // The encoder feeds the length predictor, whose float sum is truncated to an integer frame count (inference.py:135).
 // Option "split_encoder" = 0 keeps this chain on the exact fp32 MFMA path; the split path measured equally accurate
@@ -1353,7 +1410,7 @@ int vnr_prior_sample(vnr_handle h, const int32_t* d_z_lengths, const float* d_te
   if (!d_z_lengths || !d_text_embd || !d_z || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
   WS(kv, (size_t)B * Tt * h->prior_kv_n);
-  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv));
+  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
   return prior_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs);
 }
 
@@ -1364,7 +1421,7 @@ int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, co
   if (!d_z || !d_text_embd || !d_outputs || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
   WS(kv, (size_t)B * Tt * h->dec_kv_n);
-  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->dec_kv_wt, h->dec_kv_n, kv));
+  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->dec_kv_wt, h->dec_kv_n, kv, h->cfg.dec_attention_dim));
   TRY(decoder_body(h, d_z, kv, h->dec_kv_n, d_z_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, d_initial,
                    d_outputs, d_alignments));
   return h->training ? refresh_bn_affine(h) : VNR_OK;
@@ -1377,7 +1434,7 @@ int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_emb
   if (!d_mels || !d_text_embd || !d_mu || !d_logvar || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
   WS(kv, (size_t)B * Tt * h->post_kv_n);
-  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->post_kv_wt, h->post_kv_n, kv));
+  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->post_kv_wt, h->post_kv_n, kv, h->cfg.post_attention_dim));
   return posterior_body(h, d_mels, kv, h->post_kv_n, d_text_lengths, d_target_lengths, B, Tz, Tt, d_mu, d_logvar);
 }
 
@@ -1394,7 +1451,7 @@ int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_leng
   // every cross-attention K|V of the memory (all prior blocks + decoder blocks) in one GEMM
   const int kv_n = h->prior_kv_n + h->dec_kv_n;
   WS(kv, (size_t)B * Tt * kv_n);
-  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, kv_n, kv));
+  TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, kv_n, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
   WS(z, (size_t)B * Tz * C);
   TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kv, kv_n, B, Tz, Tt, d_eps, z, nullptr));
   return decoder_body(h, z, kv + h->prior_kv_n, kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor,
@@ -1407,7 +1464,7 @@ int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_tex
   if (!d_z || !d_text_embd || !d_z_lengths || !d_logprobs || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
   WS(kv, (size_t)B * Tt * h->prior_kv_n);
-  TRY(run_kv(h, d_text_embd, B * Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv));
+  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
   WS(zc, (size_t)B * Tz * h->cfg.latent_dim);
   HIP_TRY(h, hipMemcpyAsync(zc, d_z, (size_t)B * Tz * h->cfg.latent_dim * 4, hipMemcpyDeviceToDevice, h->stream));
   return prior_logprob_body(h, zc, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_logprobs);
@@ -1439,9 +1496,9 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
   // posterior (first head is USED as logvar, second as mu: models.py:136 vs posterior.py:130)
   const int kvn = h->post_kv_n + h->prior_kv_n + h->dec_kv_n;
   WS(kvp, (size_t)B * Tt * h->post_kv_n);
-  TRY(run_kv(h, text_embd, B * Tt, Dm, h->post_kv_wt, h->post_kv_n, kvp));
+  TRY(run_kv(h, text_embd, B, Tt, Dm, h->post_kv_wt, h->post_kv_n, kvp, h->cfg.post_attention_dim));
   WS(kv, (size_t)B * Tt * (h->prior_kv_n + h->dec_kv_n));
-  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, h->prior_kv_n + h->dec_kv_n, kv));
+  TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n + h->dec_kv_n, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
   (void)kvn;
   WS(head1, (size_t)B * Tz * C); WS(head2, (size_t)B * Tz * C);
   TRY(posterior_body(h, rmel, kvp, h->post_kv_n, d_text_lengths, d_reduced_lengths, B, Tz, Tt, head1, head2));
@@ -1557,7 +1614,7 @@ static int init_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_l
   TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
   const int kv_ld = h->prior_kv_n + h->dec_kv_n;
   WS(kv, (size_t)B * Tt * kv_ld);
-  TRY(run_kv(h, text_embd, B * Tt, Dm, h->prior_kv_wt, kv_ld, kv));
+  TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, kv_ld, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
   WS(z, (size_t)B * Tz * C);
   TRY(prior_init_body(h, d_reduced_lengths, d_text_lengths, kv, kv_ld, B, Tz, Tt, d_eps, z));
   float* mel = d_mel;
@@ -1631,6 +1688,23 @@ int vnr_op_attention(vnr_handle h, const float* d_q, int ldq, const float* d_k, 
   a.Q = d_q; a.ldq = ldq; a.K = d_k; a.ldk = ldk; a.V = d_v; a.ldv = ldv; a.q_len = d_q_lengths; a.k_len = d_k_lengths;
   a.ctx = d_ctx; a.ldo = ldo; a.ali = d_alignments; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.temperature = temperature;
   a.q_bs = (long long)Tq * ldq; a.k_bs = (long long)Tk * ldk; a.v_bs = (long long)Tk * ldv; a.o_bs = (long long)Tq * ldo;
+  if (h->op_attn_presplit && !causal && Tk <= 128) {
+    // option "op_attn_presplit": the attention3 path -- fp32 operands are first rewritten as attention operand images
+    // (inside the engine the producers write them directly)
+    ws_reset(h);
+    const int D = H * 64, ttq = (Tq + 31) / 32, ttk = (Tk + 31) / 32;
+    WS(qi, (size_t)B * H * ttq * kAoiTile / 4); WS(ki, (size_t)B * H * ttk * kAoiTile / 4); WS(vi, (size_t)B * H * ttk * kAoiTile / 4);
+    AoiDesc dq; dq.mode = 1; dq.D = D; dq.T = Tq; dq.TT = ttq; dq.qk = reinterpret_cast<char*>(qi);
+    AoiDesc dk; dk.mode = 1; dk.D = D; dk.T = Tk; dk.TT = ttk; dk.qk = reinterpret_cast<char*>(ki);
+    AoiDesc dv; dv.mode = 2; dv.D = D; dv.T = Tk; dv.TT = ttk; dv.vt = reinterpret_cast<char*>(vi);
+    RUN_MISC(h, launch_aoi_convert(d_q, ldq, B * Tq, D, dq, h->stream));
+    RUN_MISC(h, launch_aoi_convert(d_k, ldk, B * Tk, D, dk, h->stream));
+    RUN_MISC(h, launch_aoi_convert(d_v, ldv, B * Tk, D, dv, h->stream));
+    Attn3Args t;
+    t.Qi = dq.qk; t.Ki = dk.qk; t.Vi = dv.vt; t.q_len = d_q_lengths; t.k_len = d_k_lengths; t.ctx = d_ctx; t.ldo = ldo; t.o_bs = a.o_bs; t.ali = d_alignments;
+    t.B = B; t.H = H; t.Tq = Tq; t.Tk = Tk; t.temperature = temperature;
+    return run_attention3(h, t);
+  }
   return run_attention(h, a, !causal);
 }
 
@@ -1651,6 +1725,8 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!h || !name) return fail(h, VNR_ERR_ARG, "null argument");
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "attn_presplit")) { h->aoi_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
   if (!strcmp(name, "training")) { h->training = value != 0; return VNR_OK; }

@@ -377,11 +377,11 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   if (g.taps > 0) {
     auto k = gemm_kernel<BM, BN, WM, WN, 1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+    vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   } else {
     auto k = gemm_kernel<BM, BN, WM, WN, 0>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+    vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   }
   return hipGetLastError();
 }
@@ -391,7 +391,7 @@ static hipError_t launch_ln_cfg(const GemmArgs& g, hipStream_t s) {
   const size_t lds = (2 * (size_t)(32 + NW * 64) * LDS_STRIDE + 2 * 32 * NW) * sizeof(float);
   auto k = gemm_ln_kernel<NW>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k, dim3((g.M + 31) / 32), dim3(NW * 64), lds, s, g);
+  vnr_launch(k, dim3((g.M + 31) / 32), dim3(NW * 64), lds, s, g);
   return hipGetLastError();
 }
 
@@ -403,6 +403,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
 
   static const bool force_v1 = getenv("VNR_GEMM_V1") != nullptr;   // A/B switch for measurements
   if (!force_v1 && gemm2_supported(g)) return launch_gemm2(g, s);
+  if (g.aoi.mode) return hipErrorInvalidValue;       // operand-image epilogues exist in gemm2 only
 
   if (g.ln_gamma) {
     if (g.taps > 0 || g.gather_ids || g.bn_scale || g.pe || g.N > 256) return hipErrorInvalidValue;

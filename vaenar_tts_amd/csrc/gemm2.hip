@@ -431,7 +431,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             if (g.bn_scale && !g.bn_first) { v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w; }
             const float4 pe4 = pev[j][q], r4 = res[j][q];
             v[0] += g.pe_w * pe4.x + r4.x; v[1] += g.pe_w * pe4.y + r4.y; v[2] += g.pe_w * pe4.z + r4.z; v[3] += g.pe_w * pe4.w + r4.w;
-            out_store4(g.C + (size_t)row * g.ldc + col, v[0], v[1], v[2], v[3]);
+            if (g.aoi.mode) aoi_store4(g.aoi, row, col, v);      // attention operand image instead of fp32
+            else out_store4(g.C + (size_t)row * g.ldc + col, v[0], v[1], v[2], v[3]);
           }
       }
     } else {   // generic (unaligned N / strides): scalar path
@@ -602,10 +603,10 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
     const int mode = g.taps > 0 ? 1 : 0;
     if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
+      vnr_launch(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
     else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
       if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
+      vnr_launch(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -618,11 +619,11 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
     if (LN) return hipErrorInvalidValue;
     auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+    vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   } else {
     auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, grid, block, lds, s, g, tiles_m, tiles_n);
+    vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   }
   return hipGetLastError();
 }
@@ -641,6 +642,7 @@ bool gemm2_supported(const GemmArgs& g) {
   }
   if (((size_t)g.N * g.ldw + g.K) * 4 >= lim) return false;
   if (g.ln_gamma && (g.N > 256 || g.taps > 0 || g.bn_scale || g.pe)) return false;
+  if (g.aoi.mode && (g.ln_gamma || (g.N & 3) || (g.ldc & 3) || (g.residual && (g.ldr & 3)))) return false;   // image stores: 4-column groups
   return true;
 }
 

@@ -291,8 +291,13 @@ panel_chain_kernel(const ChainArgs g) {
     for (int q = 0; q < 4; ++q) {
       const int col = 32 * wave + 8 * q + 4 * half;
       if (!cok[q]) continue;
-      if (st.out && row < g.M)
-        out_store4(st.out + (size_t)row * st.ldo + col, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      if (st.out && row < g.M) {
+        if (st.out_fmt == 1) {                                               // attention operand image (common.h)
+          AoiDesc ad; ad.mode = 1; ad.D = st.n; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.qk = reinterpret_cast<char*>(st.out);
+          aoi_store4(ad, row, col, &v[4 * q]);
+        }
+        else out_store4(st.out + (size_t)row * st.ldo + col, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
       if (st.dst >= 0) {
         h16x4 hi, lo;
 #pragma unroll
@@ -314,6 +319,7 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
     const ChainStage& st = g.st[i];
     if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.akt0 < 0 || st.akt0 + (st.asw < st.nk ? st.asw : st.nk) > 8 || (st.pe && st.pe_T <= 0) || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
     if (st.out && (st.ldo & 3)) return hipErrorInvalidValue;
+    if (st.out && st.out_fmt == 1 && ((st.n & 63) || st.aoi_T <= 0)) return hipErrorInvalidValue;
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -328,7 +334,7 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
-    hipLaunchKernelGGL(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, gg);
+    vnr_launch(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, gg);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hbuf(n);
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -337,7 +343,7 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
     if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 64)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, g);
+  vnr_launch(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, g);
   return hipGetLastError();
 }
 

@@ -67,10 +67,10 @@ hipError_t launch_layer_norm(const float* x, const float* gamma, const float* be
                              int dim, float* y, hipStream_t s) {
   if (rows <= 0 || dim <= 0 || (dim & 3) || dim > 2048) return hipErrorInvalidValue;
   const dim3 grid((rows + 3) / 4), block(256);
-  if (dim <= 256) hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
-  else if (dim <= 512) hipLaunchKernelGGL(layer_norm_kernel<2>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
-  else if (dim <= 1024) hipLaunchKernelGGL(layer_norm_kernel<4>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
-  else hipLaunchKernelGGL(layer_norm_kernel<8>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  if (dim <= 256) vnr_launch(layer_norm_kernel<1>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else if (dim <= 512) vnr_launch(layer_norm_kernel<2>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else if (dim <= 1024) vnr_launch(layer_norm_kernel<4>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
+  else vnr_launch(layer_norm_kernel<8>, grid, block, 0, s, x, gamma, beta, rows, dim, y);
   return hipGetLastError();
 }
 
@@ -93,7 +93,7 @@ __global__ void pe_kernel(int T, int dim, float step, float* __restrict__ out) {
 hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s) {
   if (T <= 0 || dim <= 0) return hipErrorInvalidValue;
   const int n = T * dim;
-  hipLaunchKernelGGL(pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, T, dim, step, out);
+  vnr_launch(pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, T, dim, step, out);
   return hipGetLastError();
 }
 
@@ -115,7 +115,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
 
 hipError_t launch_transpose(const float* in, int rows, int cols, float* out, int ldo, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s,
+  vnr_launch(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s,
                      in, rows, cols, out, ldo);
   return hipGetLastError();
 }
@@ -144,7 +144,7 @@ coupling_fwd_kernel(const float* __restrict__ heads, float* __restrict__ z, int 
 
 hipError_t launch_coupling_fwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s) {
-  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
+  vnr_launch(coupling_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
                      2 * half, zp_off, row_logdet);
   return hipGetLastError();
 }
@@ -185,7 +185,7 @@ coupling_bwd_kernel(const float* __restrict__ heads, float* __restrict__ z, int 
 }
 hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s) {
-  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
+  vnr_launch(coupling_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half,
                      2 * half, zp_off, row_logdet);
   return hipGetLastError();
 }
@@ -210,7 +210,7 @@ reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, c
 }
 hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps, int M, int C, float* z,
                           float* row_lp, hipStream_t s) {
-  hipLaunchKernelGGL(reparam_kernel, dim3((M + 3) / 4), dim3(256), 0, s, mu, logvar, eps, M, C, z, row_lp);
+  vnr_launch(reparam_kernel, dim3((M + 3) / 4), dim3(256), 0, s, mu, logvar, eps, M, C, z, row_lp);
   return hipGetLastError();
 }
 
@@ -231,7 +231,7 @@ sqerr_rows_kernel(const float* __restrict__ rec, int rec_T, const float* __restr
 }
 hipError_t launch_sqerr_rows(const float* rec, int rec_T, const float* tgt, int T, int B, int C, float* rows,
                              hipStream_t s) {
-  hipLaunchKernelGGL(sqerr_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, rec, rec_T, tgt, T, B, C, rows);
+  vnr_launch(sqerr_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, rec, rec_T, tgt, T, B, C, rows);
   return hipGetLastError();
 }
 
@@ -251,7 +251,7 @@ __global__ void elbo_scalars_kernel(const float* sum_out, const float* sum_init,
 hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, const int32_t* mel_len,
                                const float* pred_len, const float* post_lp, const float* prior_lp, int B,
                                float* l2, float* length_l2, float* kl, hipStream_t s) {
-  hipLaunchKernelGGL(elbo_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, s, sum_out, sum_init, mel_len,
+  vnr_launch(elbo_scalars_kernel, dim3((B + 63) / 64), dim3(64), 0, s, sum_out, sum_init, mel_len,
                      pred_len, post_lp, prior_lp, B, l2, length_l2, kl);
   return hipGetLastError();
 }
@@ -266,7 +266,7 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* _
 }
 hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s) {
   const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
+  vnr_launch(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
   return hipGetLastError();
 }
 
@@ -285,7 +285,7 @@ __global__ void split_weights_kernel(const float* __restrict__ Wt, int N, int K,
 }
 hipError_t launch_split_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s) {
   const size_t n = (size_t)N * ((K + 31) >> 5) * 32;
-  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
+  vnr_launch(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
   return hipGetLastError();
 }
 
@@ -309,7 +309,7 @@ __global__ void opmajor_weights_kernel(const float* __restrict__ Wt, int N, int 
 }
 hipError_t launch_opmajor_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s) {
   const size_t n = (size_t)((N + 31) / 32) * ((K + 31) / 32) * 128;
-  hipLaunchKernelGGL(opmajor_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
+  vnr_launch(opmajor_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wt, N, K, scale, (_Float16*)out);
   return hipGetLastError();
 }
 
@@ -326,13 +326,13 @@ gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ 
 }
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s) {
   if (dim & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, rows, dim, out);
+  vnr_launch(gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, rows, dim, out);
   return hipGetLastError();
 }
 
 hipError_t launch_masked_row_reduce(const float* rows, const int32_t* len, int B, int T, float scale,
                                     float* out, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(masked_row_reduce_kernel, dim3(B), dim3(64), 0, s, rows, len, T, scale, out,
+  vnr_launch(masked_row_reduce_kernel, dim3(B), dim3(64), 0, s, rows, len, T, scale, out,
                      accumulate);
   return hipGetLastError();
 }
@@ -371,7 +371,7 @@ hipError_t launch_length_predictor(const float* x, const float* w, const float* 
                                    const int32_t* len, int B, int T, int D, int act, float* out,
                                    hipStream_t s) {
   if (D & 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(length_predictor_kernel, dim3(B), dim3(256), 0, s, x, w, bias, len, T, D, act, out);
+  vnr_launch(length_predictor_kernel, dim3(B), dim3(256), 0, s, x, w, bias, len, T, D, act, out);
   return hipGetLastError();
 }
 
@@ -398,7 +398,7 @@ gauss_logprob_kernel(const float* __restrict__ eps, const int32_t* __restrict__ 
 
 hipError_t launch_gauss_logprob(const float* eps, const int32_t* len, int B, int T, int C, float* out,
                                 hipStream_t s) {
-  hipLaunchKernelGGL(gauss_logprob_kernel, dim3(B), dim3(256), 0, s, eps, len, T, C, out);
+  vnr_launch(gauss_logprob_kernel, dim3(B), dim3(256), 0, s, eps, len, T, C, out);
   return hipGetLastError();
 }
 
@@ -407,7 +407,7 @@ __global__ void axpy_len_kernel(float* y, const int32_t* len, float alpha, int B
   if (b < B) y[b] += alpha * (float)len[b];
 }
 hipError_t launch_axpy_len(float* y, const int32_t* len, float alpha, int B, hipStream_t s) {
-  hipLaunchKernelGGL(axpy_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, B);
+  vnr_launch(axpy_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, B);
   return hipGetLastError();
 }
 
@@ -435,7 +435,7 @@ __global__ void fold_actnorm_linear_kernel(const float* __restrict__ ls, const f
 }
 hipError_t launch_fold_actnorm_linear(const float* log_scale, const float* bias, const float* W, int C,
                                       float* Wt_out, float* b_out, hipStream_t s) {
-  hipLaunchKernelGGL(fold_actnorm_linear_kernel, dim3(C), dim3(128), 0, s, log_scale, bias, W, C,
+  vnr_launch(fold_actnorm_linear_kernel, dim3(C), dim3(128), 0, s, log_scale, bias, W, C,
                      Wt_out, b_out);
   return hipGetLastError();
 }
@@ -452,7 +452,7 @@ __global__ void bn_affine_kernel(const float* gamma, const float* beta, const fl
 }
 hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* mean, const float* var,
                             int C, float* scale, float* shift, hipStream_t s) {
-  hipLaunchKernelGGL(bn_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, s, gamma, beta, mean, var,
+  vnr_launch(bn_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, s, gamma, beta, mean, var,
                      C, scale, shift);
   return hipGetLastError();
 }
@@ -500,13 +500,13 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
 }
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, (float*)nullptr);
+  vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, (float*)nullptr);
   return hipGetLastError();
 }
 // grad[c] += sum_m x[m][c]  (bias gradients), optional abs-max by-product
 hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s) {
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, (const double*)nullptr, (double*)nullptr, amax, grad);
+  vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, (const double*)nullptr, (double*)nullptr, amax, grad);
   return hipGetLastError();
 }
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
@@ -517,7 +517,7 @@ __global__ void scale_d_kernel(double* v, int n, double f) {
   if (i < n) v[i] *= f;
 }
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s) {
-  hipLaunchKernelGGL(scale_d_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, n, f);
+  vnr_launch(scale_d_kernel, dim3((n + 127) / 128), dim3(128), 0, s, v, n, f);
   return hipGetLastError();
 }
 // BatchNormalization(training=True) (Keras, TF 2.2, non-fused path for rank-3 inputs): normalise with the batch
@@ -537,7 +537,7 @@ __global__ void bn_train_finish_kernel(const double* mean, const double* sq, int
 }
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
                                   float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s) {
-  hipLaunchKernelGGL(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, gamma, beta, momentum,
+  vnr_launch(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, gamma, beta, momentum,
                      moving_mean, moving_var, scale, shift);
   return hipGetLastError();
 }
@@ -555,7 +555,7 @@ __global__ void actnorm_init_finish_kernel(const double* mean, const double* sq,
 }
 hipError_t launch_actnorm_init_finish(const double* mean, const double* sq, int M, int C, float* log_scale, float* bias,
                                       float* scale, hipStream_t s) {
-  hipLaunchKernelGGL(actnorm_init_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, log_scale, bias, scale);
+  vnr_launch(actnorm_init_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, log_scale, bias, scale);
   return hipGetLastError();
 }
 // Counter-based dropout mask: keep element i of site `key` iff mix32(i * 0x9E3779B1 + key) >= rate * 2^32
@@ -585,7 +585,7 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
                         float rate, unsigned key, float* y, hipStream_t s) {
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(rowop_kernel, dim3(blocks), dim3(256), 0, s, x, M, C, scale, shift, pe, T > 0 ? T : 1, pe_w, rate, key, y);
+  vnr_launch(rowop_kernel, dim3(blocks), dim3(256), 0, s, x, M, C, scale, shift, pe, T > 0 ? T : 1, pe_w, rate, key, y);
   return hipGetLastError();
 }
 

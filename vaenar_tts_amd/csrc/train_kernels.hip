@@ -191,7 +191,7 @@ hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned*
   static const bool skip = getenv("VNR_SKIP_ABSMAX") != nullptr;      // measurement knob (gradients of tiny magnitude lose accuracy)
   if (skip) return hipSuccess;
   int blocks = rows < 512 ? rows : 512; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, out);
+  vnr_launch(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, out);
   return hipGetLastError();
 }
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
@@ -209,8 +209,8 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
   splits = (M + rps - 1) / rps;
   static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
-  if (v1) hipLaunchKernelGGL(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
-  else hipLaunchKernelGGL(gemm_tn_split_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
+  if (v1) vnr_launch(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+  else vnr_launch(gemm_tn_split_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
   return hipGetLastError();
 }
 
@@ -573,14 +573,14 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
   static const bool v1 = getenv("VNR_ATTN_BWD_V1") != nullptr;       // A/B switch: plain-FMA fp32 kernels
   const bool aligned = !(lddq & 3) && !(lddk & 3) && !(lddv & 3);
   if (v1 || !amax_slot || !aligned) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
+    vnr_launch(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
+    vnr_launch(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
     return hipGetLastError();
   }
   hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  vnr_launch(attn_bwd_dkv_mfma_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   return hipGetLastError();
 }
 
@@ -638,7 +638,7 @@ hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, in
                          float* dbeta, hipStream_t s) {
   if (D > 512) return hipErrorInvalidValue;
   int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
+  vnr_launch(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
   return hipGetLastError();
 }
 
@@ -654,7 +654,7 @@ __global__ void act_bwd_kernel(float* d, const float* y, size_t n, int act) {
 hipError_t launch_act_bwd(float* d, const float* y, size_t n, int act, hipStream_t s) {
   if (act == ACT_IDENTITY) return hipSuccess;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, y, n, act);
+  vnr_launch(act_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, y, n, act);
   return hipGetLastError();
 }
 // y[i] = a * x[i] + (accumulate ? y[i] : 0)   (strided 2-D: rows x cols with leading dimensions)
@@ -671,7 +671,7 @@ hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, i
   const size_t n = (size_t)rows * cols;
   if (!n) return hipSuccess;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(axpby2d_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, a, y, ldy, rows, cols, accumulate);
+  vnr_launch(axpby2d_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, a, y, ldy, rows, cols, accumulate);
   return hipGetLastError();
 }
 // g[c] += (float) sum[c]   (column sums accumulated in float64 -> float32 gradient)
@@ -680,7 +680,7 @@ __global__ void add_d2f_kernel(float* g, const double* sum, int n, float a) {
   if (i < n) g[i] += a * (float)sum[i];
 }
 hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream_t s) {
-  hipLaunchKernelGGL(add_d2f_kernel, dim3((n + 127) / 128), dim3(128), 0, s, g, sum, n, a);
+  vnr_launch(add_d2f_kernel, dim3((n + 127) / 128), dim3(128), 0, s, g, sum, n, a);
   return hipGetLastError();
 }
 // column sums of two products in float64: s1[c] += sum_m d[m][c] ; s2[c] += sum_m d[m][c] * (x[m][c] - mean[c]) * rstd[c]
@@ -721,10 +721,10 @@ __global__ void bn_bwd_apply_kernel(const float* d, const float* x, const double
 hipError_t launch_bn_bwd(const float* d, const float* x, const double* mean, const double* sq, const float* gamma, int M, int C,
                          double* s1, double* s2, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
   int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, d, x, mean, sq, M, C, s1, s2);
+  vnr_launch(bn_bwd_sums_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, d, x, mean, sq, M, C, s1, s2);
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, d, x, mean, sq, s1, s2, gamma, M, C, dx, dgamma, dbeta);
+  vnr_launch(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, d, x, mean, sq, s1, s2, gamma, M, C, dx, dgamma, dbeta);
   return hipGetLastError();
 }
 // embedding gradient: dE[ids[m]][c] += d[m][c]
@@ -738,7 +738,7 @@ __global__ void embed_bwd_kernel(const float* d, const int32_t* ids, int M, int 
 hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s) {
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, ids, M, C, dE);
+  vnr_launch(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, ids, M, C, dE);
   return hipGetLastError();
 }
 // *out += sum_m sum_c d[m][c] * pe[m % T][c]     (gradient of the scalar pos_weight)
@@ -756,7 +756,7 @@ __global__ void pe_weight_bwd_kernel(const float* d, const float* pe, int M, int
   if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
 }
 hipError_t launch_pe_weight_bwd(const float* d, const float* pe, int M, int C, int T, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(pe_weight_bwd_kernel, dim3(64), dim3(256), 0, s, d, pe, M, C, T, out);
+  vnr_launch(pe_weight_bwd_kernel, dim3(64), dim3(256), 0, s, d, pe, M, C, T, out);
   return hipGetLastError();
 }
 
@@ -781,7 +781,7 @@ __global__ void coupling_inv_kernel(const float* heads, float* z, int M, int hal
   if (lane == 0) rowld[m] = acc;
 }
 hipError_t launch_coupling_inv(const float* heads, float* z, int M, int half, int zp_off, float* zp_in, float* rowld, hipStream_t s) {
-  hipLaunchKernelGGL(coupling_inv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half, zp_off, zp_in, rowld);
+  vnr_launch(coupling_inv_kernel, dim3((M + 3) / 4), dim3(256), 0, s, heads, z, M, half, zp_off, zp_in, rowld);
   return hipGetLastError();
 }
 // backward: given dz (gradient at the OUTPUT [M][2*half]) and g_b = d loss / d logdet_b:
@@ -811,7 +811,7 @@ hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float
                                    int T, int half, int zp_off, float* dheads, hipStream_t s) {
   const size_t n = (size_t)M * half;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(coupling_inv_bwd_kernel, dim3(blocks), dim3(256), 0, s, heads, zp_in, dz, g_b, len, M, T, half, zp_off, dheads);
+  vnr_launch(coupling_inv_bwd_kernel, dim3(blocks), dim3(256), 0, s, heads, zp_in, dz, g_b, len, M, T, half, zp_off, dheads);
   return hipGetLastError();
 }
 // ActNorm inverse (flow.py:177-187): y = (x - bias) / (exp(ls) + 1e-8).  Backward: dx = dy/den (in place on dy);
@@ -843,7 +843,7 @@ __global__ void actnorm_inv_bwd_kernel(const float* x, float* dy, const float* l
 hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b,
                                   double* s_ls, hipStream_t s) {
   int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-  hipLaunchKernelGGL(actnorm_inv_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, bias, M, C, s_b, s_ls);
+  vnr_launch(actnorm_inv_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, bias, M, C, s_b, s_ls);
   return hipGetLastError();
 }
 // d eps = -eps * mask * g_b  (gradient of sum_t mask * -0.5 (log 2pi + eps^2)); written (not accumulated)
@@ -857,7 +857,7 @@ __global__ void gauss_bwd_kernel(const float* eps, const float* g_b, const int32
 hipError_t launch_gauss_bwd(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d, hipStream_t s) {
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gauss_bwd_kernel, dim3(blocks), dim3(256), 0, s, eps, g_b, len, M, T, C, d);
+  vnr_launch(gauss_bwd_kernel, dim3(blocks), dim3(256), 0, s, eps, g_b, len, M, T, C, d);
   return hipGetLastError();
 }
 // reparameterisation z = eps * exp(logvar/2) + mu and posterior log-prob (posterior.py:21-72), backward:
@@ -876,7 +876,7 @@ hipError_t launch_reparam_bwd(const float* dz, const float* eps, const float* lo
                               int T, int C, float* dmu, float* dlogvar, hipStream_t s) {
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, s, dz, eps, logvar, gpost, len, M, T, C, dmu, dlogvar);
+  vnr_launch(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, s, dz, eps, logvar, gpost, len, M, T, C, dmu, dlogvar);
   return hipGetLastError();
 }
 
@@ -898,7 +898,7 @@ hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, con
                          hipStream_t s) {
   const size_t n = (size_t)B * Tr * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(l2_bwd_kernel, dim3(blocks), dim3(256), 0, s, rec, Tr, tgt, Tm, len, B, C, seed, d);
+  vnr_launch(l2_bwd_kernel, dim3(blocks), dim3(256), 0, s, rec, Tr, tgt, Tm, len, B, C, seed, d);
   return hipGetLastError();
 }
 // Length predictor (length_predictor.py:35-42, identity activation) and its loss (models.py:96-103), forward + backward in
@@ -942,7 +942,7 @@ length_loss_kernel(const float* x, const float* w, const float* bias, const int3
 hipError_t launch_length_loss(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len,
                               int B, int T, int D, float seed, float* pred, float* ll, float* dw, float* db, hipStream_t s) {
   if (T > 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(length_loss_kernel, dim3(B), dim3(256), 0, s, x, w, bias, text_len, mel_len, T, D, seed, pred, ll, dw, db);
+  vnr_launch(length_loss_kernel, dim3(B), dim3(256), 0, s, x, w, bias, text_len, mel_len, T, D, seed, pred, ll, dw, db);
   return hipGetLastError();
 }
 
@@ -964,7 +964,7 @@ __global__ void adam_kernel(float* const* w, const float* const* g, float* const
 }
 hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
                        float lr_t, float b1, float b2, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(adam_kernel, dim3(64, ntensors), dim3(256), 0, s, w, g, m, v, n, ntensors, lr_t, b1, b2, eps);
+  vnr_launch(adam_kernel, dim3(64, ntensors), dim3(256), 0, s, w, g, m, v, n, ntensors, lr_t, b1, b2, eps);
   return hipGetLastError();
 }
 
@@ -982,7 +982,7 @@ __global__ void conv_flip_kernel(const float* W, int k, int cin, int cout, float
 hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb, hipStream_t s) {
   const size_t n = (size_t)k * cin * cout;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(conv_flip_kernel, dim3(blocks), dim3(256), 0, s, W, k, cin, cout, Wb);
+  vnr_launch(conv_flip_kernel, dim3(blocks), dim3(256), 0, s, W, k, cin, cout, Wb);
   return hipGetLastError();
 }
 
@@ -1072,7 +1072,7 @@ hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float*
   const size_t lds = (size_t)C * C * sizeof(double);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8); attr = true; }
-  hipLaunchKernelGGL(invert_kernel, dim3(n), dim3(256), lds, s, b, C);
+  vnr_launch(invert_kernel, dim3(n), dim3(256), lds, s, b, C);
   return hipGetLastError();
 }
 hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s) {
@@ -1090,7 +1090,7 @@ __global__ void actnorm_inv_params_kernel(const float* ls, const float* bias, in
 }
 hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s) {
   if (C > 128) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(actnorm_inv_params_kernel, dim3(1), dim3(128), 0, s, ls, bias, C, sc, sh, lssum);
+  vnr_launch(actnorm_inv_params_kernel, dim3(1), dim3(128), 0, s, ls, bias, C, sc, sh, lssum);
   return hipGetLastError();
 }
 // y[b] += alpha[0] * len[b]   (alpha on the device)
@@ -1099,7 +1099,7 @@ __global__ void axpy_len_dev_kernel(float* y, const int32_t* len, const float* a
   if (b < B) y[b] += sign * alpha[0] * (float)len[b];
 }
 hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s) {
-  hipLaunchKernelGGL(axpy_len_dev_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, sign, B);
+  vnr_launch(axpy_len_dev_kernel, dim3((B + 63) / 64), dim3(64), 0, s, y, len, alpha, sign, B);
   return hipGetLastError();
 }
 // seeds of the backward pass (train.py:135, models.py:84-103): per-utterance losses -> batch means and
@@ -1126,7 +1126,7 @@ __global__ void train_seeds_kernel(const float* sum_out, const float* sum_init, 
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
                               const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
                               float* cg, float* scalars, hipStream_t s) {
-  hipLaunchKernelGGL(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, kw, lw,
+  vnr_launch(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, kw, lw,
                      g_post, g_prior, cg, scalars);
   return hipGetLastError();
 }
@@ -1136,7 +1136,7 @@ __global__ void axpy_dev_kernel(float* y, const float* x, const float* cg, float
   if (i < n) y[i] += alpha * (cg ? cg[0] : 1.f) * (x ? x[i] : 1.f);
 }
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s) {
-  hipLaunchKernelGGL(axpy_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, x, cg, alpha, n);
+  vnr_launch(axpy_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, x, cg, alpha, n);
   return hipGetLastError();
 }
 
@@ -1164,7 +1164,7 @@ transpose_batch_kernel(const TransposeJob* jobs) {
 }
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(transpose_batch_kernel, dim3(64, njobs), dim3(256), 0, s, static_cast<const TransposeJob*>(jobs_device));
+  vnr_launch(transpose_batch_kernel, dim3(64, njobs), dim3(256), 0, s, static_cast<const TransposeJob*>(jobs_device));
   return hipGetLastError();
 }
 
@@ -1190,7 +1190,7 @@ split_batch_kernel(const SplitJob* jobs, float scale) {
 }
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(split_batch_kernel, dim3(32, njobs), dim3(256), 0, s, static_cast<const SplitJob*>(jobs_device), scale);
+  vnr_launch(split_batch_kernel, dim3(32, njobs), dim3(256), 0, s, static_cast<const SplitJob*>(jobs_device), scale);
   return hipGetLastError();
 }
 

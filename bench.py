@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--exact-fp32", action="store_true", help="disable the split-fp16 GEMM path (exact fp32 MFMA everywhere)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B switches), repeatable")
     args = ap.parse_args()
 
     from vaenar_tts_amd import dist as vdist
@@ -65,6 +66,9 @@ def main():
     eng = model.engine
     if args.exact_fp32:
         eng.set_option("split_fp16", 0)
+    for kv in args.opt:                                  # A/B switches, e.g. --opt attn_presplit_self=0
+        name, val = kv.split("=")
+        eng.set_option(name, int(val))
 
     B, Tt, Tm, rf = S1["B"], S1["T_text"], S1["T_mel"], S1["rf"]
     batch = make_batch(B, Tt, Tm, ragged=False, seed=1234 + rank, temperature=1.0)

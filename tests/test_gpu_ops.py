@@ -169,6 +169,42 @@ def test_attention(eng, B, H, Tq, Tk, causal, want_ali, tau, ragged):
                 assert np.all(got[b, :, ql[b]:, :] == np.float32(1.0) / np.float32(Tk))
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,tau,ragged", [
+    (2, 2, 7, 7, 0, 1.0, True),           # tiny, padded queries -> uniform rows
+    (2, 2, 45, 45, 1, 1.0, True),         # causal, ragged, partial blocks
+    (3, 4, 400, 400, 1, 1.0, True),       # S1-shaped causal self attention: 13 key blocks over 4 waves, block skipping
+    (3, 4, 400, 400, 1, 1.0, False),      # ... full lengths (fast path everywhere below the diagonal)
+    (2, 4, 130, 200, 0, 1.0, True),       # Tk > 128, non-causal: two rounds for some waves
+    (2, 1, 33, 129, 0, 0.7, True),        # odd sizes, temperature != 1, a block holding one key
+    (2, 4, 128, 128, 0, 1.0, False),      # encoder-shaped, full lengths
+    (1, 2, 300, 520, 0, 1.0, True),       # 17 key blocks: up to five rounds per wave
+])
+def test_attention_presplit_general(eng, B, H, Tq, Tk, causal, tau, ragged):
+    """attention3.hip general kernel (any Tk, causal, online softmax over a wave's key blocks, O^T accumulation)."""
+    r = rng(Tq * 7 + Tk)
+    D = 64 * H
+    q, k, v = 1.5 * r.standard_normal((B, Tq, D)), r.standard_normal((B, Tk, D)), r.standard_normal((B, Tk, D))
+    if ragged:
+        ql = np.maximum(1, Tq - np.arange(B) * max(1, Tq // 3)).astype(np.int32)
+        kl = np.maximum(1, Tk - np.arange(B) * max(1, Tk // 4)).astype(np.int32)
+    else:
+        ql, kl = np.full(B, Tq, np.int32), np.full(B, Tk, np.int32)
+    if causal:
+        kl = ql.copy()
+    dq, dk, dv_ = (eng.to_device(t.astype(np.float32)) for t in (q, k, v))
+    dql, dkl = eng.to_device(ql), eng.to_device(kl)
+    ctx = eng.empty((B, Tq, D))
+    eng.set_option("op_attn_presplit", 1)
+    try:
+        _lib.check(eng.lib.vnr_op_attention(eng.handle, dq.ptr, D, dk.ptr, D, dv_.ptr, D, dql.ptr, dkl.ptr, B, H, Tq, Tk,
+                                            causal, tau, ctx.ptr, D, None), eng.handle)
+    finally:
+        eng.set_option("op_attn_presplit", 0)
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    rctx, _ = attention_ref(f(q), f(k), f(v), ql, kl, H, causal, np.float64(np.float32(tau)))
+    np.testing.assert_allclose(ctx.numpy(), rctx, atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,want_ali,tau,ragged", [
     (3, 4, 400, 128, 1, 1.0, True),       # S1-shaped decoder cross attention with alignments
     (3, 4, 400, 128, 0, 1.0, False),      # prior cross attention, nothing masked (fast path)

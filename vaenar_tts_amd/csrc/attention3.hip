@@ -22,6 +22,7 @@
 // rounding of t = s.log2(e) differs from the reference's exp(s - max) by <= 2^-24 . |t| relative -- below 3e-6 for |s| < 40.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace vnr {
 
@@ -220,6 +221,176 @@ attn3_kernel(const Attn3Args a, int nqt) {
   }
 }
 
+// ---- general kernel: any Tk, optional causal mask, online softmax over the key blocks of a wave ----------------------------
+// Same workgroup shape (4 waves = one 32-query tile); wave w walks key blocks w, w+4, w+8, ... with the usual running
+// (max, sum) rescaling.  The output is accumulated TRANSPOSED, O^T = V^T.P^T: the V image tile is the A operand as it is, P in
+// its S^T accumulator layout is the B operand as it is, and a lane owns one QUERY -- the per-block rescale and the final
+// normalisation are in-lane products (no cross-lane broadcast of alpha), and the partial tiles go to LDS as [query][64 d] rows
+// so that the merge pass stores 256-byte row pieces.  Blocks that cannot contribute are skipped when every query row of the
+// tile is valid (keys >= k_len have weight exactly 0; causal: keys beyond the tile's last row); tiles with padded query rows
+// walk every block (their rows are uniform over ALL Tk keys).  The next block's K tile is requested right after
+// the S^T MFMAs and its V tile right after the O^T MFMAs, so a block's loads fly under the previous block's softmax.
+__global__ void __launch_bounds__(256, 2)
+attn3g_kernel(const Attn3Args a, int nqt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* stats = reinterpret_cast<float*>(smem + 4 * kXchg);      // [4 waves][m | l][32]
+  const int npairs = a.B * a.H;
+  const int wg = blockIdx.x;
+  int pair, qidx;
+  if ((npairs & 7) == 0) {
+    const int xcd = wg & 7, j = wg >> 3, ppx = npairs >> 3;
+    qidx = j / ppx;
+    pair = (j - qidx * ppx) * 8 + xcd;
+  } else {
+    qidx = wg / npairs;
+    pair = wg - qidx * npairs;
+  }
+  if (a.causal) qidx = nqt - 1 - qidx;                 // heaviest tiles first
+  const int b = pair / a.H, hd = pair - b * a.H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q0 = qidx * 32;
+  const int ttq = (a.Tq + 31) >> 5, ttk = (a.Tk + 31) >> 5;
+  const char* kbase = a.Ki + (size_t)(b * a.H + hd) * ttk * kAoiTile + lane * 16;
+  const char* vbase = a.Vi + (size_t)(b * a.H + hd) * ttk * kAoiTile + lane * 16;
+
+  h8 qhi[4], qlo[4], khi[4], klo[4], vhi[2][2], vlo[2][2];
+  auto load_k = [&](int kb) {
+    const char* kp = kbase + (size_t)kb * kAoiTile;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { khi[t] = *reinterpret_cast<const h8*>(kp + 1024 * t); klo[t] = *reinterpret_cast<const h8*>(kp + 4096 + 1024 * t); }
+  };
+  auto load_v = [&](int kb) {
+    const char* vp = vbase + (size_t)kb * kAoiTile;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { vhi[x >> 1][x & 1] = *reinterpret_cast<const h8*>(vp + 1024 * x); vlo[x >> 1][x & 1] = *reinterpret_cast<const h8*>(vp + 4096 + 1024 * x); }
+  };
+  {
+    const char* qp = a.Qi + ((size_t)(b * a.H + hd) * ttq + qidx) * kAoiTile + lane * 16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { qhi[t] = *reinterpret_cast<const h8*>(qp + 1024 * t); qlo[t] = *reinterpret_cast<const h8*>(qp + 4096 + 1024 * t); }
+  }
+  // first block of this wave is requested before anything depends on the length arrays (block `wave` exists whenever
+  // wave < ttk; a block that turns out to be skippable costs one wasted tile read)
+  const bool any0 = wave < ttk;
+  load_k(any0 ? wave : 0);
+  load_v(any0 ? wave : 0);
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq;
+  const int klen = a.k_len ? a.k_len[b] : a.Tk;
+  int nkb = ttk;
+  {
+    int row_hi = q0 + 32; if (row_hi > a.Tq) row_hi = a.Tq;
+    if (row_hi <= qlen && klen > 0) {                  // every query row valid: masked keys have weight exactly 0
+      int kmax = klen;
+      if (a.causal && row_hi < kmax) kmax = row_hi;
+      nkb = (kmax + 31) >> 5;
+    }
+  }
+  const float c = (a.temperature != 1.0f) ? 0.125f * kLog2e / a.temperature : 0.125f * kLog2e;
+  const int iq = q0 + l31;
+  const bool qvalid = iq < qlen;
+
+  f32x16 O[2];                                         // O^T: lane = query l31, register r of block nb = channel 32 nb + frow3(r, half)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kb = wave; kb < nkb; kb += 4) {
+    const int kb0 = 32 * kb;
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
+    const bool more = kb + 4 < nkb;
+    if (more) load_k(kb + 4);                          // flies under this block's softmax and O^T MFMAs
+    const bool partial = kb0 + 32 > a.Tk;
+    if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen && (!a.causal || kb0 + 31 <= q0)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] *= c;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kb0 + frow3(r, half);
+        float s = st[r] * c;
+        s = (qvalid && j < klen && (!a.causal || j <= iq)) ? s : kMaskFill * kLog2e;   // attention.py:240
+        if (j >= a.Tk) s = -INFINITY;
+        st[r] = s;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(fmaxf(m_run, mt), -3.0e38f);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // 0 on the first block
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_new); st[r] = p; ps += p; }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    if (kb != wave && __any(m_new != m_run)) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nb][r] *= alpha;
+    }
+    m_run = m_new;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      if (partial) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (key >= a.Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+        }
+      }
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pv[e] = st[8 * tp + e];
+      h8 phi, plo;
+      split8x(pv, phi, plo);
+      O[0] = mfma3x(vhi[tp][0], vlo[tp][0], phi, plo, O[0]);
+      O[1] = mfma3x(vhi[tp][1], vlo[tp][1], phi, plo, O[1]);
+    }
+    if (more) load_v(kb + 4);
+  }
+
+  // ---- merge: partial tiles as [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row] + (m, l) per query ---------
+  char* xw = smem + wave * kXchg;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 o4 = {O[nb][4 * j], O[nb][4 * j + 1], O[nb][4 * j + 2], O[nb][4 * j + 3]};
+      *reinterpret_cast<f32x4*>(xw + l31 * 256 + (((nb * 8 + 2 * j + half) ^ (l31 & 15)) << 4)) = o4;
+    }
+  if (half == 0) { stats[wave * 64 + l31] = fmaxf(m_run, -3.0e38f); stats[wave * 64 + 32 + l31] = l_run; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
+    float mw[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + rr]; lw[w] = stats[w * 64 + 32 + rr]; }
+    const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+    float L = 0.f, f[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { f[w] = __builtin_amdgcn_exp2f(mw[w] - M); L += lw[w] * f[w]; }
+    const float linv = 1.0f / L;                       // softmax denominator, attention.py:242
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + rr * 256 + ((ch ^ (rr & 15)) << 4)) * (f[w] * linv);
+    const int row = q0 + rr;
+    if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
+  }
+}
+
 // fp32 [rows][cols] -> operand images, one thread per 4 columns
 __global__ void __launch_bounds__(256) aoi_convert_kernel(const float* src, int ld, int rows, int cols, const AoiDesc d) {
   const int q4 = cols >> 2;
@@ -239,12 +410,15 @@ hipError_t launch_aoi_convert(const float* src, int ld, int rows, int cols, cons
 }
 
 hipError_t launch_attention3(const Attn3Args& a, hipStream_t s) {
-  if (a.Tk <= 0 || a.Tk > 128 || a.Tq <= 0 || !a.Qi || !a.Ki || !a.Vi || !a.ctx) return hipErrorInvalidValue;
+  if (a.Tk <= 0 || a.Tq <= 0 || !a.Qi || !a.Ki || !a.Vi || !a.ctx || (a.ldo & 3)) return hipErrorInvalidValue;
+  if (a.ali && (a.Tk > 128 || a.causal)) return hipErrorInvalidValue;     // alignments: single-round kernel only
   const int nqt = (a.Tq + 31) / 32;
   const size_t lds = 4 * kXchg + 4 * 64 * sizeof(float);
   dim3 grid(nqt * a.H * a.B);
+  static const bool force_general = getenv("VNR_ATTN3_GENERAL") != nullptr;   // A/B switch: looped kernel even where the single-round one applies
   if (a.ali) vnr_launch(attn3_kernel<true>, grid, dim3(256), lds, s, a, nqt);
-  else vnr_launch(attn3_kernel<false>, grid, dim3(256), lds, s, a, nqt);
+  else if (!force_general && a.Tk <= 128 && !a.causal) vnr_launch(attn3_kernel<false>, grid, dim3(256), lds, s, a, nqt);   // 8.7 vs 9.4 us at 400x128
+  else vnr_launch(attn3g_kernel, grid, dim3(256), lds, s, a, nqt);
   return hipGetLastError();
 }
 

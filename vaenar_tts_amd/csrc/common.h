@@ -56,7 +56,8 @@ enum { ACT_IDENTITY = 0, ACT_RELU = 1, ACT_TANH = 2 };
 //               accumulator of attention3 already holds P, so the B operand of P.V needs no gather.
 // mode 0: plain fp32 output.  mode 1: every column is Q/K-type (image at `qk`).  mode 2: every column is V-type (image at
 // `vt`).  mode 3: a cross K|V panel -- column blocks of 2*D: the first D columns (K) go to image `qk` + blk * blk_bytes, the
-// last D columns (V) to `vt` + blk * blk_bytes, blk = column / (2*D).
+// last D columns (V) to `vt` + blk * blk_bytes, blk = column / (2*D).  mode 4: a self-attention Q|K|V panel of 3*D columns:
+// Q to `qk`, K to `qk` + blk_bytes, V to `vt`.
 struct AoiDesc {
   int mode = 0;
   int D = 0;                // H * 64
@@ -80,6 +81,10 @@ __device__ __forceinline__ void aoi_store4(const AoiDesc& a, int row, int col, c
     blk = col / (2 * a.D);
     c = col - blk * 2 * a.D;
     if (c >= a.D) { is_v = true; c -= a.D; }
+  } else if (a.mode == 4) {
+    blk = col / a.D;
+    c = col - blk * a.D;
+    if (blk == 2) { is_v = true; blk = 0; }
   }
   const int b = row / a.T, t = row - b * a.T, r = t & 31;
   const int head = c >> 6, d = c & 63, H = a.D >> 6;
@@ -172,8 +177,12 @@ struct ChainStage {
   const float* gamma; const float* beta;   // LayerNorm or null
   int acc_mode;             // 0: plain stage; 1/2/3: FFN second layer over hidden chunks (start / continue / finish+epilogue)
   float* out; int ldo;      // HBM output [M, n] or null
-  int out_fmt;              // 0: fp32; 1: `out` is a Q-type attention operand image (AoiDesc mode 1, D = n, n % 64 == 0)
-  int aoi_T;                // out_fmt 1: rows per batch element
+  int out_fmt;              // 0: fp32; 1: `out` is a Q-type attention operand image (AoiDesc mode 1, D = n, n % 64 == 0);
+                            // 4: this stage holds columns [aoi_c0, aoi_c0 + n) of a Q|K|V panel of 3*aoi_D columns whose three
+                            //    images (aoi_img_bytes each) start at `out` (AoiDesc mode 4)
+  int aoi_T;                // out_fmt 1/4: rows per batch element
+  int aoi_D, aoi_c0;
+  long long aoi_img_bytes;
   int dst;                  // destination panel or -1
   float scale;              // 2^-s of the pre-scaled weight image
 };
@@ -193,7 +202,7 @@ hipError_t launch_gemm2(const GemmArgs& g, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention2_supported(const AttnArgs& a);      // balanced DMA-fed kernel (attention2.hip) can take it
 hipError_t launch_attention2(const AttnArgs& a, hipStream_t s);
-// cross attention on pre-split operands, Tk <= 128 (attention3.hip)
+// attention core on producer-split operand images (attention3.hip); alignments only for non-causal calls with Tk <= 128
 struct Attn3Args {
   const char* Qi;                              // Q image [B][H][ceil(Tq/32)][8 KiB]
   const char* Ki; const char* Vi;              // K / V images [B][H][ceil(Tk/32)][8 KiB]
@@ -202,6 +211,7 @@ struct Attn3Args {
   float* ali;                                  // [B,H,Tq,Tk] or null
   int B, H, Tq, Tk;
   float temperature;
+  int causal = 0;
 };
 hipError_t launch_attention3(const Attn3Args& a, hipStream_t s);
 // fp32 [rows][cols] -> operand images (tests, op-level entry; the engine's producers write the images directly)

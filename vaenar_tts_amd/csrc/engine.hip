@@ -119,6 +119,7 @@ struct vnr_context {
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
   bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
   // cross K|V panels of the current call that were written as attention operand images (cleared with the workspace)
   struct KvAoi { const float* base; int n; int D; int B; int Tt; AoiDesc d; };
@@ -238,7 +239,7 @@ bool split_lookup(vnr_handle h, const float* Wt, int K, int N, SplitRef& out) {
   out.opm = ((off / sp.K) % 32 == 0) ? (const char*)sp.opm + (size_t)(off / sp.K / 32) * out.kt_total * 4096 : nullptr;
   return true;
 }
-struct Tail { const float* wt; int n; const float* bias; float* out; int ldo; };   // extra Dense(D -> n) on the block output
+struct Tail { const float* wt; int n; const float* bias; float* out; int ldo; int qkv_T = 0, qkv_B = 0; };   // qkv_T > 0: a Q|K|V panel written as operand images (rows per batch element, batch)   // extra Dense(D -> n) on the block output
 
 // The chain kernel reads the epilogue parameters (bias | gamma | beta, 256 floats each, per stage) of its whole program
 // as ONE contiguous block: it is assembled once per distinct program (device-to-device copies, stream ordered) and cached.
@@ -286,11 +287,11 @@ int run_attention(vnr_handle h, const AttnArgs& a, bool cross) {
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention launch: ") + hipGetErrorString(e));
   return VNR_OK;
 }
-int run_attention3(vnr_handle h, const Attn3Args& a) {
+int run_attention3(vnr_handle h, const Attn3Args& a, bool cross) {
   const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
                     (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
   const double fl = 4.0 * (double)a.B * a.H * a.Tq * (double)a.Tk * 64;
-  ProfScope ps(h, a.ali ? CLS_ATTN_CROSS_ALI : CLS_ATTN_CROSS, fl, io);
+  ProfScope ps(h, cross ? (a.ali ? CLS_ATTN_CROSS_ALI : CLS_ATTN_CROSS) : CLS_ATTN_SELF, fl, io);
   hipError_t e = launch_attention3(a, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention3 launch: ") + hipGetErrorString(e));
   return VNR_OK;
@@ -455,6 +456,17 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
   return VNR_OK;
 }
 
+// self-attention Q|K|V as attention operand images (three images of img_bytes each instead of the fp32 [M, 3D] panel)
+bool self_aoi_on(vnr_handle h, int D, int heads) {
+  static const bool v1 = getenv("VNR_GEMM_V1") != nullptr;
+  return h->aoi_enabled && h->aoi_self && !v1 && D > 0 && D == heads * 64;
+}
+long long aoi_img_bytes(int B, int T, int D) { return (long long)B * (D / 64) * ((T + 31) / 32) * kAoiTile; }
+size_t qkv_floats(bool aoi, int B, int T, int D) { return aoi ? (size_t)(3 * aoi_img_bytes(B, T, D) / 4) : (size_t)B * T * 3 * D; }
+void set_qkv_aoi(AoiDesc& d, float* base, int B, int T, int D) {
+  d.mode = 4; d.D = D; d.T = T; d.TT = (T + 31) / 32; d.blk_bytes = aoi_img_bytes(B, T, D);
+  d.qk = reinterpret_cast<char*>(base); d.vt = d.qk + 2 * d.blk_bytes;
+}
 // the operand images of the cross K|V that run_xblk is about to read at kv + col (null when that panel is plain fp32)
 const vnr_context::KvAoi* find_kv_aoi(vnr_handle h, const float* kv, int col, int D, int B, int Tt, int* blk) {
   for (const auto& r : h->kv_aoi) {
@@ -475,7 +487,7 @@ const vnr_context::KvAoi* find_kv_aoi(vnr_handle h, const float* kv, int col, in
 // block's Q|K|V, the flow heads, the decoder out-projection, the posterior heads).
 int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const float* kv, int kv_ld,
              const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau,
-             float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails) {
+             float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails, bool self_aoi) {
   const int M = B * Tq, D = k.D, F = k.F;
   // cross K|V written as attention operand images (run_kv): the query is produced as an image too and attention3 runs
   int kv_blk = 0;
@@ -485,14 +497,23 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   // self attention: fused Q|K|V projection (no bias, attention.py:154-159)
   if (!qkv_ready) {
     g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = k.qkv_wt; g.ldw = D; g.C = qkv; g.ldc = 3 * D; g.M = M; g.N = 3 * D;
+    if (self_aoi) set_qkv_aoi(g.aoi, qkv, B, Tq, D);
     TRY(run_gemm(h, g));
+  }
+  if (self_aoi) {                                        // Q|K|V arrived as operand images: attention3 general kernel
+    const long long ib = aoi_img_bytes(B, Tq, D);
+    Attn3Args t;
+    t.Qi = reinterpret_cast<const char*>(qkv); t.Ki = t.Qi + ib; t.Vi = t.Qi + 2 * ib;
+    t.q_len = q_len; t.k_len = q_len; t.ctx = sa; t.ldo = D; t.o_bs = (long long)Tq * D; t.ali = nullptr;
+    t.B = B; t.H = heads; t.Tq = Tq; t.Tk = Tq; t.temperature = tau; t.causal = 1;
+    TRY(run_attention3(h, t, false));
   }
   AttnArgs a;
   a.Q = qkv; a.ldq = 3 * D; a.K = qkv + D; a.ldk = 3 * D; a.V = qkv + 2 * D; a.ldv = 3 * D;
   a.q_len = q_len; a.k_len = q_len; a.ctx = sa; a.ldo = D; a.ali = nullptr; a.B = B; a.H = heads; a.Tq = Tq; a.Tk = Tq;
   a.causal = 1; a.temperature = tau;
   a.q_bs = (long long)Tq * 3 * D; a.k_bs = a.q_bs; a.v_bs = a.q_bs; a.o_bs = (long long)Tq * D;
-  TRY(run_attention(h, a, false));
+  if (!self_aoi) TRY(run_attention(h, a, false));
 
   // ---- fused row-panel chains (gemm3.hip) when the split images exist and the widths fit one 256-column panel --------
   SplitRef r_p1, r_q, r_p2, r_f1, r_f2;
@@ -537,7 +558,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     t.q_len = q_len; t.k_len = m_len; t.ctx = ca; t.ldo = D; t.o_bs = (long long)Tq * D; t.ali = ali;
     t.B = B; t.H = heads; t.Tq = Tq; t.Tk = Tt; t.temperature = tau;
     if (heads * 64 != D) return fail(h, VNR_ERR_ARG, "attention3: heads * 64 != attention width");
-    TRY(run_attention3(h, t));
+    TRY(run_attention3(h, t, true));
   } else {
   a.Q = q; a.ldq = D; a.K = kv + k.kv_col; a.ldk = kv_ld; a.V = kv + k.kv_col + D; a.ldv = kv_ld;
   a.q_len = q_len; a.k_len = m_len; a.ctx = ca; a.ldo = D; a.ali = ali; a.Tq = Tq; a.Tk = Tt; a.causal = 0;
@@ -574,6 +595,8 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
         s->w = r_t[i].opm + (size_t)(c0 / 32) * r_t[i].kt_total * 4096; s->kt_total = r_t[i].kt_total; s->kt0 = 0; s->nk = PT; s->n = w;
         s->a0 = 0; s->a1 = 0; s->asw = PT; s->bias = tails[i].bias ? tails[i].bias + c0 : nullptr; s->act = ACT_IDENTITY; s->res = -1; s->gamma = nullptr; s->beta = nullptr;
         s->acc_mode = 0; s->out = tails[i].out + c0; s->ldo = tails[i].ldo; s->dst = -1; s->scale = r_t[i].scale;
+        if (tails[i].qkv_T > 0) { s->out = tails[i].out; s->out_fmt = 4; s->aoi_T = tails[i].qkv_T; s->aoi_D = tails[i].n / 3; s->aoi_c0 = c0;
+                                  s->aoi_img_bytes = aoi_img_bytes(tails[i].qkv_B, tails[i].qkv_T, tails[i].n / 3); }
         fl += 2.0 * M * D * (double)w;
       }
     c.nstages = n;
@@ -596,6 +619,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   else TRY(run_gemm(h, g));
   for (const Tail& t : tails) {      // unfused tails
     g = GemmArgs(); g.A1 = out; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = t.wt; g.ldw = D; g.bias = t.bias; g.C = t.out; g.ldc = t.ldo; g.M = M; g.N = t.n;
+    if (t.qkv_T > 0) set_qkv_aoi(g.aoi, t.out, t.qkv_B, t.qkv_T, t.n / 3);
     TRY(run_gemm(h, g));
   }
   return VNR_OK;
@@ -606,7 +630,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
 // panel (optionally from a k-tile offset: a column window) and may write HBM and/or a panel; wide outputs are cut into
 // 256-column stages.  *done = false (nothing launched) when a split image is missing or a shape does not fit.
 struct PreStage { const float* wt; int K, N; int src, akt0; const float* bias; const float* pe; int pe_T; float pe_w;
-                  float* out; int ldo; int dst; };
+                  float* out; int ldo; int dst; int qkv_T = 0, qkv_B = 0; };
 int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const std::vector<PreStage>& stages, bool* done) {
   *done = false;
   static const bool off = getenv("VNR_NO_PRECHAIN") != nullptr;       // A/B switch
@@ -627,6 +651,7 @@ int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const
       s.bias = p.bias ? p.bias + c0 : nullptr; s.act = ACT_IDENTITY; s.res = -1; s.acc_mode = 0;
       s.pe = p.pe; s.pe_T = p.pe_T; s.pe_w = p.pe_w;
       s.out = p.out ? p.out + c0 : nullptr; s.ldo = p.ldo; s.dst = p.dst; s.scale = r.scale;
+      if (p.out && p.qkv_T > 0) { s.out = p.out; s.out_fmt = 4; s.aoi_T = p.qkv_T; s.aoi_D = p.N / 3; s.aoi_c0 = c0; s.aoi_img_bytes = aoi_img_bytes(p.qkv_B, p.qkv_T, p.N / 3); }
       fl += 2.0 * M * (double)p.K * s.n;
     }
   }
@@ -645,17 +670,19 @@ int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb
   float* xc = xa; float* xn = xb;
   if (blks.empty()) { *result = xc; return VNR_OK; }
   const int D = blks[0].D;
+  const bool saoi = self_aoi_on(h, D, heads);            // (the callers' pre-chains decide with the same predicate)
   float* qkv0 = qkv_pre;                                 // Q|K|V of the first block already computed by a pre-chain
-  if (!qkv0) { qkv0 = ws_alloc(h, (size_t)M * 3 * D); if (!qkv0) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed"); }
-  WS(qkv1, (size_t)M * 3 * D);
+  if (!qkv0) { qkv0 = ws_alloc(h, qkv_floats(saoi, B, Tq, D)); if (!qkv0) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed"); }
+  WS(qkv1, qkv_floats(saoi, B, Tq, D));
+  (void)M;
   float* qc = qkv0; float* qn = qkv1;
   bool ready = qkv_pre != nullptr;
   for (size_t b = 0; b < blks.size(); ++b) {
     std::vector<Tail> t;
-    if (b + 1 < blks.size()) t.push_back({blks[b + 1].qkv_wt, 3 * D, nullptr, qn, 3 * D});
+    if (b + 1 < blks.size()) t.push_back({blks[b + 1].qkv_wt, 3 * D, nullptr, qn, 3 * D, saoi ? Tq : 0, B});
     else t = tails;
     TRY(run_xblk(h, blks[b], xc, xn, kv, kv_ld, q_len, m_len, B, Tq, Tt, heads, tau,
-                 ali_base ? ali_base + b * ali_stride : nullptr, qc, ready, t));
+                 ali_base ? ali_base + b * ali_stride : nullptr, qc, ready, t, saoi));
     ready = b + 1 < blks.size();      // (also true on the unfused path: the tails loop computed it)
     std::swap(xc, xn); std::swap(qc, qn);
   }
@@ -802,12 +829,13 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
     bool fused = false;
     float* qkv_pre = nullptr;
     if (!f.blks.empty() && !(half & 31) && f.blks[0].D == D) {
-      qkv_pre = ws_alloc(h, (size_t)M * 3 * D);
+      const bool saoi = self_aoi_on(h, D, c.prior_attention_heads);
+      qkv_pre = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
       if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
       TRY(run_prechain(h, zc, C, C, M,
                        {PreStage{f.fold_wt, C, C, 0, 0, f.fold_b, nullptr, 1, 0.f, dst, C, 1},
                         PreStage{f.pre_wt, half, D, 1, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, 0},
-                        PreStage{f.blks[0].qkv_wt, D, 3 * D, 0, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1}}, &fused));
+                        PreStage{f.blks[0].qkv_wt, D, 3 * D, 0, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}}, &fused));
     }
     GemmArgs g;
     if (!fused) {
@@ -905,11 +933,12 @@ int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const
   bool fused = false;
   float* qkv_pre = nullptr;
   if (!h->dec_blks.empty() && h->dec_blks[0].D == D) {
-    qkv_pre = ws_alloc(h, (size_t)M * 3 * D);
+    const bool saoi = self_aoi_on(h, D, c.dec_attention_heads);
+    qkv_pre = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
     if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
     TRY(run_prechain(h, z, C, C, M,
                      {PreStage{h->dec_pre_wt, C, D, 0, 0, h->dec_pre_b, nullptr, 1, 0.f, xa, D, 1},
-                      PreStage{h->dec_blks[0].qkv_wt, D, 3 * D, 1, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1}}, &fused));
+                      PreStage{h->dec_blks[0].qkv_wt, D, 3 * D, 1, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}}, &fused));
   }
   if (!fused) {
     qkv_pre = nullptr;
@@ -1688,7 +1717,7 @@ int vnr_op_attention(vnr_handle h, const float* d_q, int ldq, const float* d_k, 
   a.Q = d_q; a.ldq = ldq; a.K = d_k; a.ldk = ldk; a.V = d_v; a.ldv = ldv; a.q_len = d_q_lengths; a.k_len = d_k_lengths;
   a.ctx = d_ctx; a.ldo = ldo; a.ali = d_alignments; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.temperature = temperature;
   a.q_bs = (long long)Tq * ldq; a.k_bs = (long long)Tk * ldk; a.v_bs = (long long)Tk * ldv; a.o_bs = (long long)Tq * ldo;
-  if (h->op_attn_presplit && !causal && Tk <= 128) {
+  if (h->op_attn_presplit && (!d_alignments || (!causal && Tk <= 128))) {
     // option "op_attn_presplit": the attention3 path -- fp32 operands are first rewritten as attention operand images
     // (inside the engine the producers write them directly)
     ws_reset(h);
@@ -1702,8 +1731,8 @@ int vnr_op_attention(vnr_handle h, const float* d_q, int ldq, const float* d_k, 
     RUN_MISC(h, launch_aoi_convert(d_v, ldv, B * Tk, D, dv, h->stream));
     Attn3Args t;
     t.Qi = dq.qk; t.Ki = dk.qk; t.Vi = dv.vt; t.q_len = d_q_lengths; t.k_len = d_k_lengths; t.ctx = d_ctx; t.ldo = ldo; t.o_bs = a.o_bs; t.ali = d_alignments;
-    t.B = B; t.H = H; t.Tq = Tq; t.Tk = Tk; t.temperature = temperature;
-    return run_attention3(h, t);
+    t.B = B; t.H = H; t.Tq = Tq; t.Tk = Tk; t.temperature = temperature; t.causal = causal;
+    return run_attention3(h, t, !causal);
   }
   return run_attention(h, a, !causal);
 }
@@ -1726,6 +1755,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit")) { h->aoi_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }

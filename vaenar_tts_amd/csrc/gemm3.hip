@@ -150,6 +150,12 @@ panel_chain_kernel(const ChainArgs g) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // A stage that holds only V columns of a Q|K|V panel (out_fmt 4) is computed UN-transposed (operands swapped: lane <->
+    // output column, registers <-> the 32 rows in k-slot order): 8 consecutive registers are then exactly one 16-byte unit of
+    // the V image (common.h), stored with fully coalesced 1 KiB wave writes instead of 2-byte scatters.  Needs the 16-row
+    // half panels to coincide with half tiles: rows per batch element % 16 == 0.
+    const bool vswap = st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) &&
+                       st.acc_mode == 0 && st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY;
     wstamp(si, 0);
     const int npad = (st.nk + PF - 1) / PF * PF;
     // activation operands are read ONE k-tile ahead (registers a[cur] / a[nxt]) so the LDS latency of tile kt+1 hides
@@ -173,11 +179,20 @@ panel_chain_kernel(const ChainArgs g) {
         const int kt = kb + u;
         read_a(kt + 1, (u + 1) & 1);
         if (wave_on && kt < st.nk) {
+          if (!vswap) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {                                   // D^T: lane <-> activation row
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][2 * t], acc, 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {                                 // D^T: lane <-> activation row
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t + 1], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][2 * t], acc, 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {                                 // D: lane <-> output column (V image stage)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t], wreg[u][2 * t], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t + 1], wreg[u][2 * t], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t], wreg[u][2 * t + 1], acc, 0, 0, 0);
+            }
           }
         }
         fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)
@@ -194,6 +209,28 @@ panel_chain_kernel(const ChainArgs g) {
       for (int r = 0; r < 16; ++r) accF[r] += acc[r];
     }
     if (st.acc_mode == 1 || st.acc_mode == 2) { lds_barrier(); stamp(3 + 2 * si); continue; }   // the hidden panel may be rewritten next
+    if (vswap) {
+      if (wave_on) {
+        const int cv = st.aoi_c0 - 2 * st.aoi_D + 32 * wave + l31;          // V column of this lane: head cv >> 6, channel cv & 63
+        const float bv = (prm + si * 768)[32 * wave + l31];                // (zero padded when the stage has no bias)
+        const int Hh = st.aoi_D >> 6, TT = (st.aoi_T + 31) >> 5;
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          const int R = m0 + 16 * tp;
+          if (R >= g.M) continue;
+          const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
+          h16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float x = acc[8 * tp + e] * st.scale + bv; const _Float16 hh = (_Float16)x; hi[e] = hh; lo[e] = (_Float16)(x - (float)hh); }
+          char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
+                       ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
+          *reinterpret_cast<h16x8*>(pdst) = hi;
+          *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
+        }
+      }
+      lds_barrier(); stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
     if (st.acc_mode == 3) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = accF[r];
@@ -287,14 +324,37 @@ panel_chain_kernel(const ChainArgs g) {
     }
     wstamp(si, 2);
     // ---- outputs: HBM (fp32, 16-byte row pieces) and/or destination panel (split fp16) -----------------------------------
+    // Attention operand images (common.h): a wave's 32 columns lie inside one head, so everything but (q, half) is either
+    // per-lane-per-stage (the row's tile) or wave-uniform (image, head, channel base).  Q/K-type columns take the fast
+    // path below; V-type columns of a stage that could not run un-transposed fall back to the generic scatter.
+    char* img_row = nullptr;                             // Q/K-type: address of this lane's 16-byte unit for t = 0, g = 0
+    bool img_generic = false;
+    if (st.out && st.out_fmt != 0 && wave_on && row < g.M) {
+      const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + 32 * wave;
+      const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
+      if (which == 2) img_generic = true;
+      else {
+        const int TT = (st.aoi_T + 31) >> 5, bb = row / st.aoi_T, tt = row - bb * st.aoi_T;
+        img_row = reinterpret_cast<char*>(st.out) + (size_t)which * st.aoi_img_bytes +
+                  ((size_t)(bb * (Dd >> 6) + (cw >> 6)) * TT + (tt >> 5)) * kAoiTile + ((cw & 63) >> 4) * 1024 + ((tt & 31) << 4) + half * 8;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = 32 * wave + 8 * q + 4 * half;
       if (!cok[q]) continue;
       if (st.out && row < g.M) {
-        if (st.out_fmt == 1) {                                               // attention operand image (common.h)
-          AoiDesc ad; ad.mode = 1; ad.D = st.n; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.qk = reinterpret_cast<char*>(st.out);
-          aoi_store4(ad, row, col, &v[4 * q]);
+        if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
+          h16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[4 * q + e] - (float)hh); }
+          char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
+          *reinterpret_cast<h16x4*>(pd) = hi;
+          *reinterpret_cast<h16x4*>(pd + 4096) = lo;
+        } else if (img_generic) {
+          AoiDesc ad; ad.mode = 4; ad.D = st.aoi_D; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.blk_bytes = st.aoi_img_bytes;
+          ad.qk = reinterpret_cast<char*>(st.out); ad.vt = ad.qk + 2 * st.aoi_img_bytes;
+          aoi_store4(ad, row, st.aoi_c0 + col, &v[4 * q]);
         }
         else out_store4(st.out + (size_t)row * st.ldo + col, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       }
@@ -320,6 +380,8 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
     if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.akt0 < 0 || st.akt0 + (st.asw < st.nk ? st.asw : st.nk) > 8 || (st.pe && st.pe_T <= 0) || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
     if (st.out && (st.ldo & 3)) return hipErrorInvalidValue;
     if (st.out && st.out_fmt == 1 && ((st.n & 63) || st.aoi_T <= 0)) return hipErrorInvalidValue;
+    if (st.out && st.out_fmt == 4 && ((st.aoi_D & 63) || st.aoi_T <= 0 || st.aoi_D <= 0 || (st.aoi_c0 & 3) || st.aoi_c0 + st.n > 3 * st.aoi_D)) return hipErrorInvalidValue;
+    if (st.out_fmt != 0 && st.out_fmt != 1 && st.out_fmt != 4) return hipErrorInvalidValue;
   }
   static bool attr_set = false;
   if (!attr_set) {

@@ -775,17 +775,27 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
   if (h->training && c.enc_pos_drop_rate > 0.f)              // pe_dropout (encoder.py:87)
     RUN_MISC(h, launch_rowop(nxt, M, Dm, nullptr, nullptr, nullptr, 1, 0.f, c.enc_pos_drop_rate, site_key(h->drop_seed, SITE_ENC_PE), nxt, h->stream));
   std::swap(cur, nxt);
-  WS(qkv, (size_t)M * 3 * A); WS(att, (size_t)M * A); WS(y, (size_t)M * Dm); WS(hid, (size_t)M * F);
+  const bool eaoi = self_aoi_on(h, A, c.enc_attention_heads);       // Q|K|V as attention operand images (attention3.hip)
+  WS(qkv, qkv_floats(eaoi, B, T, A)); WS(att, (size_t)M * A); WS(y, (size_t)M * Dm); WS(hid, (size_t)M * F);
   for (size_t i = 0; i < h->enc_blks.size(); ++i) {
     const SBlk& k = h->enc_blks[i];
     g = GemmArgs(); g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = k.qkv_wt; g.ldw = Dm; g.C = qkv; g.ldc = 3 * A; g.M = M; g.N = 3 * A;
+    if (eaoi) set_qkv_aoi(g.aoi, qkv, B, T, A);
     TRY(run_gemm(h, g));
+    if (eaoi) {
+      const long long ib = aoi_img_bytes(B, T, A);
+      Attn3Args t3;
+      t3.Qi = reinterpret_cast<const char*>(qkv); t3.Ki = t3.Qi + ib; t3.Vi = t3.Qi + 2 * ib;
+      t3.q_len = lens; t3.k_len = lens; t3.ctx = att; t3.ldo = A; t3.o_bs = (long long)T * A; t3.ali = nullptr;
+      t3.B = B; t3.H = c.enc_attention_heads; t3.Tq = T; t3.Tk = T; t3.temperature = c.enc_attention_temperature; t3.causal = 0;
+      TRY(run_attention3(h, t3, false));
+    }
     AttnArgs a;
     a.Q = qkv; a.ldq = 3 * A; a.K = qkv + A; a.ldk = 3 * A; a.V = qkv + 2 * A; a.ldv = 3 * A;
     a.q_len = lens; a.k_len = lens; a.ctx = att; a.ldo = A; a.ali = nullptr; a.B = B; a.H = c.enc_attention_heads;
     a.Tq = T; a.Tk = T; a.causal = 0; a.temperature = c.enc_attention_temperature;
     a.q_bs = (long long)T * 3 * A; a.k_bs = a.q_bs; a.v_bs = a.q_bs; a.o_bs = (long long)T * A;
-    TRY(run_attention(h, a, false));
+    if (!eaoi) TRY(run_attention(h, a, false));
     // LN(x + att_proj(concat(x, att)))  (attention.py:410-413)
     g = GemmArgs(); g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.A2 = att; g.lda2 = A; g.K = Dm + A; g.Wt = k.proj_wt; g.ldw = Dm + A;
     g.bias = k.proj_b; g.residual = cur; g.ldr = Dm; g.C = y; g.ldc = Dm; g.M = M; g.N = Dm;

@@ -1276,6 +1276,7 @@ int vnr_finalize_weights(vnr_handle h) {
     P.transpose_into(P.raw(p + "/attention/key_layer/kernel", {Dm, A}), Dm, A, qkv, A);
     P.transpose_into(P.raw(p + "/attention/value_layer/kernel", {Dm, A}), Dm, A, qkv, 2 * A);
     k.qkv_wt = qkv;
+    P.reg(qkv, 3 * A, Dm);
     k.proj_wt = P.wt(p + "/att_proj/kernel", Dm + A, Dm);
     k.proj_b = P.raw(p + "/att_proj/bias", {Dm});
     k.ln_g = P.raw(p + "/layer_norm/gamma", {Dm}); k.ln_b = P.raw(p + "/layer_norm/beta", {Dm});

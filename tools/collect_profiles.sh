@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profile artefacts on the GPU box (run through gpurun); summaries land in gpurun_out/final/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/final; mkdir -p $O
+O=${1:-gpurun_out/final}; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/kt -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train > $O/kt.log 2>&1
 python3 tools/rocpd_summary.py $(ls $O/kt/*.db $O/kt/*/*.db 2>/dev/null | head -1) > $O/kernel_stats.txt

@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--exact-fp32", action="store_true", help="disable the split-fp16 GEMM path (exact fp32 MFMA everywhere)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B switches), repeatable")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent B=16 batches kept in flight per GPU, one engine handle (= one HIP stream) each; the K timed "
+                         "steps are dealt round-robin to them.  One S1 batch leaves CUs idle (200 row panels on 256 CUs, single "
+                         "waves of attention workgroups); further streams fill them (measured 1: 4.86 M, 2: 6.11 M, 3: 6.63 M, 4: 6.03 M frames/s).  1 = the strictly sequential schedule")
     args = ap.parse_args()
 
     from vaenar_tts_amd import dist as vdist
@@ -62,36 +66,48 @@ def main():
         raise SystemExit("bench.py needs an AMD GPU (libvaenar_hip has no CPU fallback)")
     device = local_rank % ndev
     weights = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
-    model = VAENAR(hps, device=device, weights=weights)
-    eng = model.engine
-    if args.exact_fp32:
-        eng.set_option("split_fp16", 0)
-    for kv in args.opt:                                  # A/B switches, e.g. --opt attn_presplit_self=0
-        name, val = kv.split("=")
-        eng.set_option(name, int(val))
-
     B, Tt, Tm, rf = S1["B"], S1["T_text"], S1["T_mel"], S1["rf"]
-    batch = make_batch(B, Tt, Tm, ragged=False, seed=1234 + rank, temperature=1.0)
     Tz = (Tm + rf - 1) // rf
-    # inputs resident in HBM before the timed region
-    d_ids = eng.to_device(batch["ids"], np.int32)
-    d_tl = eng.to_device(batch["text_lengths"], np.int32)
-    d_ml = batch["mel_lengths"]                      # host: only its max decides the launch shapes
-    d_eps = eng.to_device(batch["eps"], np.float32)
+    nstreams = max(1, args.streams)
+    lanes = []                                           # one engine handle (own stream, workspace, weights copy) per batch in flight
+    for si in range(nstreams):
+        m = VAENAR(hps, device=device, weights=weights)
+        if args.exact_fp32:
+            m.engine.set_option("split_fp16", 0)
+        for kv in args.opt:                              # A/B switches, e.g. --opt attn_presplit_self=0
+            name, val = kv.split("=")
+            m.engine.set_option(name, int(val))
+        bt = make_batch(B, Tt, Tm, ragged=False, seed=1234 + rank + 1000 * si, temperature=1.0)
+        # inputs resident in HBM before the timed region (mel lengths stay on the host: only their max decides launch shapes)
+        lanes.append({"model": m, "batch": bt, "ids": m.engine.to_device(bt["ids"], np.int32),
+                      "tl": m.engine.to_device(bt["text_lengths"], np.int32), "eps": m.engine.to_device(bt["eps"], np.float32)})
+    model, eng, batch = lanes[0]["model"], lanes[0]["model"].engine, lanes[0]["batch"]
+    d_ids, d_tl, d_ml, d_eps = lanes[0]["ids"], lanes[0]["tl"], batch["mel_lengths"], lanes[0]["eps"]
 
-    def step():
-        return model.inference(d_ids, d_ml, d_tl, reduction_factor=rf, eps=d_eps, return_alignments=True)
+    def step(i=0):
+        ln = lanes[i % nstreams]
+        return ln["model"].inference(ln["ids"], ln["batch"]["mel_lengths"], ln["tl"], reduction_factor=rf, eps=ln["eps"],
+                                     return_alignments=True)
 
-    for _ in range(args.warmup):
-        mel, ali = step()
-    eng.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mel, ali = step()
-    eng.synchronize()
-    barrier()
-    dt = vdist.max_over_ranks(time.perf_counter() - t0)
+    def sync_all():
+        for ln in lanes:
+            ln["model"].engine.synchronize()
+
+    def timed(nsteps, use_lanes):
+        sync_all()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i if use_lanes else 0)
+        sync_all()
+        barrier()
+        return vdist.max_over_ranks(time.perf_counter() - t0)
+
+    for i in range(max(args.warmup, 1) * nstreams):
+        step(i)
+    mel, ali = step(0)
+    dt = timed(args.steps, True)                         # EXACTLY K steps, dealt round-robin to the streams
+    dt_single = timed(args.steps, False) if nstreams > 1 else dt   # the same K steps strictly one after another (reported beside)
 
     ms_per_step = 1e3 * dt / args.steps
     frames_per_step = B * Tm * world
@@ -107,7 +123,10 @@ def main():
         "config": {"workload": "S1 VAENAR.inference: B=16 per GPU, T_text=128, T_mel=800, 80-bin, rf=2, "
                                "LJHPS architecture, random-init weights, prior noise temperature 1.0, "
                                "decoder alignments returned", "global_batch": B * world,
-                   "parallelism": "batch-sharded x%d (no collective)" % world},
+                   "parallelism": "batch-sharded x%d (no collective)" % world,
+                   "batches_in_flight_per_gpu": nstreams},
+        "single_stream": {"ms_per_step": 1e3 * dt_single / args.steps, "value": frames_per_step / (dt_single / args.steps),
+                          "note": "the same K steps issued strictly one after another on one stream (batches_in_flight 1)"},
     }
 
     if rank == 0:

@@ -211,6 +211,23 @@ int vnr_op_layer_norm(vnr_handle h, const float *d_x, const float *d_gamma, cons
 /* PositionalEncoding.positional_encoding (modules/utils.py:333-355): d_out [T,dim]. */
 int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *d_out);
 
+/* ---- vocoder step after the path: reference audio/audio.py ---------------------------------
+ * Audio.inv_mel_spectrogram up to the Griffin-Lim input (audio.py:81-84): _denormalize (:206-216) -> + ref_level_db ->
+ * _db_to_amp (:189-191) -> _mel_to_linear (:166-174: pinv(mel basis) . mel, floored at 1e-10) -> ** power.
+ * d_mel [B,T,n_mels] (the path's mel output layout), d_inv_basis_t [n_mels, n_freq] = pinv(mel basis) transposed (the
+ * caller computes it once on the host), d_S [B,T,n_freq]. */
+int vnr_voc_mel_to_linear(vnr_handle h, const float *d_mel, const float *d_inv_basis_t, int B, int T,
+                          int n_mels, int n_freq, float min_level_db, float ref_level_db,
+                          float max_abs_value, int symmetric_specs, float power, float *d_S);
+/* Audio._griffin_lim (audio.py:95-102) with librosa 0.8.0 stft / istft semantics (window 'hann' of `win` samples padded
+ * to n_fft, center=True / reflect): y = istft(S e^{j phase0}); `iters` times: phase = angle(stft(y)), y = istft(S e^{j
+ * phase}).  d_S [B,T,n_fft/2+1] magnitudes; d_init_angles [B,T,n_fft/2+1] radians (the reference draws 2 pi rand(), unseeded)
+ * or NULL = drawn on the device from `seed`; d_frames [B] frames per utterance (<= T) or NULL = T;
+ * d_wav [B, hop*(T-1)] float (samples past an utterance's own hop*(frames-1) are 0).  n_fft must be 2048. */
+int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angles, uint64_t seed,
+                        const int32_t *d_frames, int B, int T, int n_fft, int hop, int win, int iters,
+                        float *d_wav);
+
 /* Engine options.  "split_fp16" (default 1): Dense/Conv GEMMs outside the text encoder evaluate every fp32
  * product as hi*hi + lo*hi + hi*lo on the fp16 matrix pipe (fp32 accumulate; 22 significant bits per operand,
  * measured mel error vs the float64 oracle ~3e-6, same as exact fp32 MFMA); 0 = exact fp32 MFMA everywhere.

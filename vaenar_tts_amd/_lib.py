@@ -90,6 +90,8 @@ PROTOTYPES = {
     "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
+    "vnr_voc_mel_to_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _f, _vp],
+    "vnr_voc_griffin_lim": [_vp, _vp, _vp, C.c_uint64, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vnr_set_option": [_vp, C.c_char_p, _i],
     "vnr_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "vnr_train_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],

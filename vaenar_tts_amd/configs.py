@@ -28,7 +28,15 @@ class _NS:
         return out
 
 
-def _base(vocab_size, mel_text_len_ratio):
+def _audio(sample_rate, frame_length_sample, frame_shift_sample, min_level_db):
+    # hparams.py:266-282 (LJSpeech) / :384-400 (DataBaker): read by audio/audio.py (the vocoder step after the path)
+    return _NS(num_mels=80, num_freq=1025, min_mel_freq=0., max_mel_freq=8000., sample_rate=sample_rate,
+               frame_length_sample=frame_length_sample, frame_shift_sample=frame_shift_sample, n_mfcc=13, preemphasize=0.97,
+               min_level_db=min_level_db, ref_level_db=20.0, max_abs_value=1, symmetric_specs=False, griffin_lim_iters=60,
+               power=1.5, center=True)
+
+
+def _base(vocab_size, mel_text_len_ratio, audio):
     return _NS(
         Train=_NS(
             random_seed=123456, epochs=2000, train_batch_size=32, test_batch_size=8,
@@ -37,7 +45,7 @@ def _base(vocab_size, mel_text_len_ratio):
             reduction_factors=[5, 4, 3, 2], reduce_interval=[0, 200, 400, 600],
             shuffle_buffer=128, shuffle=True, test_interval=50),
         Dataset=_NS(buffer_size=65536, num_parallel_reads=64, pad_factor=0),             # hparams.py:253-258
-        Audio=_NS(num_mels=80, sample_rate=22050, frame_shift_sample=256),
+        Audio=audio,
         Common=_NS(latent_dim=128, output_dim=80, final_reduction_factor=2,
                    max_reduction_factor=5, mel_text_len_ratio=mel_text_len_ratio),
         Encoder=_NS(Transformer=_NS(
@@ -61,9 +69,9 @@ def _base(vocab_size, mel_text_len_ratio):
 
 
 # /root/reference/configs/hparams.py:233-348
-LJHPS = _base(vocab_size=43, mel_text_len_ratio=5.59)
+LJHPS = _base(vocab_size=43, mel_text_len_ratio=5.59, audio=_audio(22050, 1024, 256, -100.0))
 # /root/reference/configs/hparams.py:351-474 (differs in vocab 39 :411, ratio 4.21 :407)
-DataBakerHPS = _base(vocab_size=39, mel_text_len_ratio=4.21)
+DataBakerHPS = _base(vocab_size=39, mel_text_len_ratio=4.21, audio=_audio(16000, 800, 200, -115.0))
 
 
 def tiny_hps():

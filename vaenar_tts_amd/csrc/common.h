@@ -216,6 +216,13 @@ struct Attn3Args {
 hipError_t launch_attention3(const Attn3Args& a, hipStream_t s);
 // fp32 [rows][cols] -> operand images (tests, op-level entry; the engine's producers write the images directly)
 hipError_t launch_aoi_convert(const float* src, int ld, int rows, int cols, const AoiDesc& d, hipStream_t s);
+// Griffin-Lim vocoder step after the path (vocoder.hip)
+hipError_t launch_mel_to_linear(const float* mel, const float* invT, int BT, int n_mels, int n_freq, float min_db, float ref_db, float max_abs,
+                                int symmetric, float power, float* S, hipStream_t s);
+hipError_t launch_uniform_angles(float* ang, size_t n, unsigned long long seed, hipStream_t s);
+hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_prev, float* fr_next, const int32_t* frames, const float* tw,
+                          const float* window, int B, int T, int hop, int win, hipStream_t s);
+hipError_t launch_gl_final(const float* fr, const float* window, const int32_t* frames, int B, int T, int hop, int win, float* wav, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);
 hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s);

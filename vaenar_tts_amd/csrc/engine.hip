@@ -136,6 +136,7 @@ struct vnr_context {
   std::vector<Chunk> chunks;
   // positional-encoding tables, keyed by (T, dim, step bits)
   std::map<std::tuple<int, int, uint32_t>, float*> pe_cache;
+  std::map<int, float*> voc_tables;     // win_length -> [twiddles 2048 floats | Hann window win floats] (vocoder.hip)
 
   // instrumentation
   bool profiling = false;
@@ -1155,6 +1156,7 @@ int vnr_destroy(vnr_handle h) {
   for (auto p : h->packed_allocs) hipFree(p);
   for (auto& c : h->chunks) hipFree(c.p);
   for (auto& kv : h->pe_cache) hipFree(kv.second);
+  for (auto& kv : h->voc_tables) hipFree(kv.second);
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
@@ -1758,6 +1760,56 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* 
   if (!h || !d_out) return fail(h, VNR_ERR_ARG, "null argument");
   HIP_TRY(h, hipSetDevice(h->device));
   RUN_MISC(h, launch_positional_encoding(T, dim, step, d_out, h->stream));
+  return VNR_OK;
+}
+
+// ---- vocoder step after the path (reference audio/audio.py:81-102; vocoder.hip) ---------------------------------------------
+namespace vnr { void voc_tables(int win, std::vector<float>& tw, std::vector<float>& window); }
+int vnr_voc_mel_to_linear(vnr_handle h, const float* d_mel, const float* d_inv_basis_t, int B, int T, int n_mels, int n_freq,
+                          float min_level_db, float ref_level_db, float max_abs_value, int symmetric_specs, float power, float* d_S) {
+  if (!h || !d_mel || !d_inv_basis_t || !d_S || B <= 0 || T <= 0 || n_mels <= 0 || n_freq <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  RUN_MISC(h, launch_mel_to_linear(d_mel, d_inv_basis_t, B * T, n_mels, n_freq, min_level_db, ref_level_db, max_abs_value, symmetric_specs,
+                                   power, d_S, h->stream));
+  return VNR_OK;
+}
+
+int vnr_voc_griffin_lim(vnr_handle h, const float* d_S, const float* d_init_angles, uint64_t seed, const int32_t* d_frames, int B, int T,
+                        int n_fft, int hop, int win, int iters, float* d_wav) {
+  if (!h || !d_S || !d_wav || B <= 0 || iters < 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  if (n_fft != 2048) return fail(h, VNR_ERR_ARG, "griffin_lim: the FFT kernel is built for n_fft = 2048 (num_freq 1025, hparams.py:268)");
+  if (win <= 0 || win > n_fft || hop <= 0 || hop > win) return fail(h, VNR_ERR_ARG, "griffin_lim: need 0 < hop <= win <= n_fft");
+  if ((long long)hop * (T - 1) <= n_fft / 2) return fail(h, VNR_ERR_ARG, "griffin_lim: hop * (frames - 1) must exceed n_fft / 2 (reflect padding)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  ws_reset(h);
+  float* tab = nullptr;
+  auto it = h->voc_tables.find(win);
+  if (it != h->voc_tables.end()) tab = it->second;
+  else {
+    std::vector<float> tw, window;
+    voc_tables(win, tw, window);
+    HIP_TRY(h, hipMalloc((void**)&tab, (tw.size() + window.size()) * sizeof(float)));
+    HIP_TRY(h, hipMemcpy(tab, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(tab + tw.size(), window.data(), window.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->voc_tables[win] = tab;
+  }
+  const float* tw = tab; const float* window = tab + 2048;
+  const size_t nfr = (size_t)B * T * win;
+  WS(fr0, nfr); WS(fr1, nfr);
+  const float* ang = d_init_angles;
+  if (!ang) {                                            // audio.py:96: 2 pi rand(*S.shape) (the reference does not seed it)
+    const size_t n = (size_t)B * T * (n_fft / 2 + 1);
+    WS(a0, n);
+    RUN_MISC(h, launch_uniform_angles(a0, n, seed, h->stream));
+    ang = a0;
+  }
+  RUN_MISC(h, launch_gl_pass(d_S, ang, nullptr, fr0, d_frames, tw, window, B, T, hop, win, h->stream));       // y = istft(S e^{j phase0})
+  float* cur = fr0; float* nxt = fr1;
+  for (int i = 0; i < iters; ++i) {                      // phase = angle(stft(y)); y = istft(S e^{j phase})  (audio.py:99-101)
+    RUN_MISC(h, launch_gl_pass(d_S, nullptr, cur, nxt, d_frames, tw, window, B, T, hop, win, h->stream));
+    std::swap(cur, nxt);
+  }
+  RUN_MISC(h, launch_gl_final(cur, window, d_frames, B, T, hop, win, d_wav, h->stream));
   return VNR_OK;
 }
 

@@ -35,7 +35,8 @@ def test_mel_to_linear(eng, hps):
     got = au.linear_from_mel_batch(mel).numpy()
     for b in range(3):
         ref = o.linear_from_mel(mel[b].T.astype(np.float64)).T
-        np.testing.assert_allclose(got[b], ref, rtol=2e-4, atol=1e-12)
+        # fp32 accumulation of 80 terms of mixed sign (pinv has negative entries): error relative to the frame's scale
+        np.testing.assert_allclose(got[b], ref, rtol=2e-4, atol=2e-6 * ref.max())
 
 
 @pytest.mark.parametrize("hps,T", [(LJHPS, 40), (DataBakerHPS, 33)], ids=["ljspeech", "databaker"])
@@ -95,7 +96,7 @@ def test_reference_call_surface_and_wav_files(eng, tmp_path):
     assert np.load(tmp_path / "prior-b-7.npy").shape == (22, 80)
     tu.synthesize_and_save_wavs(7, mels, [30, 22], [b"a", "b"], prefix="prior", seed=3)
     sr, w = wavfile.read(tmp_path / "prior-a-7.wav")
-    assert sr == 22050 and w.dtype == np.int16 and w.shape == (256 * 29,) and np.abs(w).max() == 32767
+    assert sr == 22050 and w.dtype == np.int16 and w.shape == (256 * 29,) and np.abs(w).max() in (32766, 32767)    # scaled to full range, truncated (audio.py:19-20)
     # the 2-D entry point of the reference (mel.T) with a given phase draw agrees with the oracle after the full chain
     au = tu.prcocessor
     ang = 2 * np.pi * r.random((1025, 22))

@@ -5,6 +5,7 @@
 
 #include <hip/hip_ext.h>
 #include <tuple>
+#include <vector>
 #include <utility>
 
 namespace vnr {
@@ -222,6 +223,7 @@ hipError_t launch_mel_to_linear(const float* mel, const float* invT, int BT, int
 hipError_t launch_uniform_angles(float* ang, size_t n, unsigned long long seed, hipStream_t s);
 hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_prev, float* fr_next, const int32_t* frames, const float* tw,
                           const float* window, int B, int T, int hop, int win, hipStream_t s);
+void voc_tables(int win, std::vector<float>& tw, std::vector<float>& window);     // host: twiddles exp(-2 pi j m / 2048) and periodic Hann, from float64
 hipError_t launch_gl_final(const float* fr, const float* window, const int32_t* frames, int B, int T, int hop, int win, float* wav, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);

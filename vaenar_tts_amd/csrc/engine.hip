@@ -1764,7 +1764,6 @@ int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* 
 }
 
 // ---- vocoder step after the path (reference audio/audio.py:81-102; vocoder.hip) ---------------------------------------------
-namespace vnr { void voc_tables(int win, std::vector<float>& tw, std::vector<float>& window); }
 int vnr_voc_mel_to_linear(vnr_handle h, const float* d_mel, const float* d_inv_basis_t, int B, int T, int n_mels, int n_freq,
                           float min_level_db, float ref_level_db, float max_abs_value, int symmetric_specs, float power, float* d_S) {
   if (!h || !d_mel || !d_inv_basis_t || !d_S || B <= 0 || T <= 0 || n_mels <= 0 || n_freq <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
@@ -1779,6 +1778,7 @@ int vnr_voc_griffin_lim(vnr_handle h, const float* d_S, const float* d_init_angl
   if (!h || !d_S || !d_wav || B <= 0 || iters < 0) return fail(h, VNR_ERR_ARG, "bad argument");
   if (n_fft != 2048) return fail(h, VNR_ERR_ARG, "griffin_lim: the FFT kernel is built for n_fft = 2048 (num_freq 1025, hparams.py:268)");
   if (win <= 0 || win > n_fft || hop <= 0 || hop > win) return fail(h, VNR_ERR_ARG, "griffin_lim: need 0 < hop <= win <= n_fft");
+  if ((win + hop - 1) / hop > 8) return fail(h, VNR_ERR_ARG, "griffin_lim: more than 8 overlapping frames per sample (win / hop > 8)");
   if ((long long)hop * (T - 1) <= n_fft / 2) return fail(h, VNR_ERR_ARG, "griffin_lim: hop * (frames - 1) must exceed n_fft / 2 (reflect padding)");
   HIP_TRY(h, hipSetDevice(h->device));
   ws_reset(h);

@@ -61,20 +61,23 @@ __device__ float2* fft2048(float2* x, float2* y, const float2* tw, int tid) {
   return x;
 }
 
-// sample n of the overlap-added, normalised signal in istft coordinates (0 <= n < n_fft + hop (nf - 1)), rebuilt from the frames
-__device__ __forceinline__ float ola_sample(const float* fr, const float* window, int n, int nf, int hop, int win, int lpad) {
-  // frames t with lpad <= n - t hop < lpad + win
-  int t_hi = (n - lpad) / hop;                       // n - lpad >= 0 for every n we are asked for
-  if (t_hi > nf - 1) t_hi = nf - 1;
-  int t_lo = (n - lpad - win) / hop + 1; if (n - lpad - win < 0) t_lo = 0;
-  float num = 0.f, den = 0.f;
-  for (int t = t_lo; t <= t_hi; ++t) {
-    const int i = n - t * hop - lpad;
-    if (i < 0 || i >= win) continue;
-    const float w = window[i];
-    num += fr[(size_t)t * win + i];
-    den += w * w;
+// sample n of the overlap-added, normalised signal in istft coordinates (0 <= n < n_fft + hop (nf - 1)), rebuilt from the frames.
+// At most kMaxOv frames overlap a sample (host checks ceil(win / hop) <= kMaxOv); the loop has a fixed trip count and predicated
+// loads so that all of a sample's reads are in flight together (a data-dependent loop serialised ~5 L2 round trips per sample).
+constexpr int kMaxOv = 8;
+__device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, int n, int nf, int hop, int win, int lpad) {
+  const int t_hi = (n - lpad) / hop;                 // newest frame whose window support starts at or before n (n >= lpad always)
+  float v[kMaxOv], w2[kMaxOv];
+#pragma unroll
+  for (int j = 0; j < kMaxOv; ++j) {
+    const int t = t_hi - j, i = n - t * hop - lpad;  // i >= 0 by construction
+    const bool ok = t >= 0 && t < nf && i < win;
+    v[j] = ok ? fr[(size_t)t * win + i] : 0.f;
+    w2[j] = ok ? wsq[i] : 0.f;
   }
+  float num = 0.f, den = 0.f;
+#pragma unroll
+  for (int j = kMaxOv - 1; j >= 0; --j) { num += v[j]; den += w2[j]; }     // frame order (oldest first), like the overlap-add loop
   return den > 1.17549435e-38f ? num / den : num;   // librosa.istft: divide where window_sumsquare > tiny(float32)
 }
 
@@ -83,25 +86,31 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
   __shared__ float2 bufA[kNfft];
   __shared__ float2 bufB[kNfft];
   __shared__ float2 tws[kHalf];
+  __shared__ float wins[kNfft], wsqs[kNfft];          // window and its square (win <= n_fft entries used)
   const int tid = threadIdx.x;
   const int f = blockIdx.x, b = blockIdx.y;
   const int nf = a.frames ? a.frames[b] : a.T;
   if (f >= nf) return;
   const int lpad = (kNfft - a.win) / 2;
   for (int i = tid; i < kHalf; i += 256) tws[i] = a.tw[i];
+  for (int i = tid; i < a.win; i += 256) { const float w = a.window[i]; wins[i] = w; wsqs[i] = w * w; }
+  if (!FIRST) __syncthreads();
   float2* X;
   if (!FIRST) {
     // analysis frame: padded[f hop + i], i in the window's support; padded = reflect-pad(y, n_fft/2), y = istft signal cropped by n_fft/2
     const int L = a.hop * (nf - 1);
     const float* frp = a.fr_prev + (size_t)b * a.T * a.win;
-    for (int i = tid; i < kNfft; i += 256) {
+#pragma unroll
+    for (int u = 0; u < kNfft / 256; ++u) {
+      const int i = tid + 256 * u;
       float v = 0.f;
       const int iw = i - lpad;
       if (iw >= 0 && iw < a.win) {
         int q = f * a.hop + i - kHalf;               // index into y
         if (q < 0) q = -q;
         if (q >= L) q = 2 * (L - 1) - q;
-        v = a.window[iw] * ola_sample(frp, a.window, q + kHalf, nf, a.hop, a.win, lpad);
+        q = q < 0 ? 0 : q;
+        v = wins[iw] * ola_sample(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
       }
       bufA[i] = make_float2(v, 0.f);
     }
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
   float2* other = (Y == bufA) ? bufB : bufA;
   const float2* R = fft2048<true>(Y, other, tws, tid);
   float* frn = a.fr_next + ((size_t)b * a.T + f) * a.win;
-  for (int i = tid; i < a.win; i += 256) frn[i] = a.window[i] * (R[i + lpad].x * (1.0f / kNfft));
+  for (int i = tid; i < a.win; i += 256) frn[i] = wins[i] * (R[i + lpad].x * (1.0f / kNfft));
 }
 
 // final signal: wav[b][q] = overlap-added, normalised signal cropped by n_fft/2 (istft center=True), q < hop (nf - 1); 0 beyond
@@ -148,7 +157,7 @@ __global__ void __launch_bounds__(256) gl_final_kernel(const float* fr, const fl
   const int nf = frames ? frames[b] : T;
   const int L = hop * (nf - 1);
   float v = 0.f;
-  if (q < L) v = ola_sample(fr + (size_t)b * T * win, window, q + kHalf, nf, hop, win, (kNfft - win) / 2);
+  if (q < L) v = ola_sample(fr + (size_t)b * T * win, window + win, q + kHalf, nf, hop, win, (kNfft - win) / 2);   // window | window^2
   wav[(size_t)b * Lmax + q] = v;
 }
 
@@ -198,9 +207,9 @@ hipError_t launch_uniform_angles(float* ang, size_t n, unsigned long long seed, 
 
 // twiddle table exp(-2 pi j m / 2048), m < 1024, and the periodic Hann window: computed in float64 on the host
 void voc_tables(int win, std::vector<float>& tw, std::vector<float>& window) {
-  tw.resize(2 * kHalf); window.resize(win);
+  tw.resize(2 * kHalf); window.resize(2 * win);      // window | window^2 (as the kernels square it: in fp32)
   for (int m = 0; m < kHalf; ++m) { const double th = -2.0 * M_PI * m / kNfft; tw[2 * m] = (float)cos(th); tw[2 * m + 1] = (float)sin(th); }
-  for (int n = 0; n < win; ++n) window[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / win));
+  for (int n = 0; n < win; ++n) { window[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / win)); window[win + n] = window[n] * window[n]; }
 }
 
 hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_prev, float* fr_next, const int32_t* frames, const float* tw,

@@ -12,10 +12,11 @@
 //     frame t of the next iteration rebuilds the win_length samples it needs by GATHERING the <= ceil(win/hop)+1 overlapping
 //     frames of the previous iteration, summing them in frame order (deterministic: no float atomics) and dividing by the window
 //     sum of squares computed in the same loop; center=True's reflect padding is an index reflection in that gather;
-//   * forward FFT (n_fft = 2048, radix-2 Stockham in LDS, fp32, twiddles from a table computed in float64), phase
+//   * forward FFT (n_fft = 2048 = 8.8.8.4: Stockham passes with 8 points per thread in registers, 4 LDS round trips; fp32,
+//     twiddles from a table computed in float64), phase
 //     normalisation X/|X| (angle(0) = 0 -> 1), scaling by the target magnitude, Hermitian extension, inverse FFT, window -> fr.
 // HBM traffic per iteration: S once (4.1 KB per frame) + the frame buffers (4 KB written, ~5 x 4 KB gathered, mostly L2 hits):
-// bound by LDS / barrier latency of the 22 butterfly stages, not by HBM.
+// bound by the LDS round trips and barriers of the two FFTs, not by HBM.
 #include "common.h"
 #include <math.h>
 #include <vector>
@@ -35,30 +36,91 @@ struct VocArgs {
   int B, T, hop, win;
 };
 
+// LDS index padding: one float2 of padding per 32 (256 bytes).  The autosort writes of the first two radix-8 passes stride by
+// 8 p float2 across lanes (p = 1, 8): unpadded that is an 8-way bank conflict on every store.
+__device__ __forceinline__ int pidx(int i) { return i + (i >> 5); }
+constexpr int kPadded = kNfft + kNfft / 32;
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// in-LDS Stockham radix-2 FFT of kNfft complex points by 256 threads; data in `x`, scratch `y`; returns the buffer holding the
-// result (natural order).  INV: conjugate twiddles (unnormalised inverse).
+// twiddle exp(-/+ 2 pi j idx / kNfft) for idx in [0, kNfft) from the half-circle table (idx >= kNfft/2: negate)
 template <bool INV>
-__device__ float2* fft2048(float2* x, float2* y, const float2* tw, int tid) {
-#pragma unroll 1
-  for (int s = 0; s < kLog; ++s) {
-    const int p = 1 << s;
+__device__ __forceinline__ float2 twid(const float2* tw, int idx) {
+  float2 w = tw[idx & (kHalf - 1)];
+  if (idx & kHalf) { w.x = -w.x; w.y = -w.y; }
+  if (INV) w.y = -w.y;
+  return w;
+}
+#define VNR_BF(a, b) { const float2 t_ = a; a = make_float2(t_.x + b.x, t_.y + b.y); b = make_float2(t_.x - b.x, t_.y - b.y); }
+// multiply by -j (forward) / +j (inverse)
+template <bool INV> __device__ __forceinline__ float2 mul_mj(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+// 8-point DFT in registers (decimation in frequency); results leave in bit-reversed order: X[k] = u[rev3(k)]
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 (&u)[8]) {
+  const float h = 0.70710678118654752440f;
+  VNR_BF(u[0], u[4]); VNR_BF(u[1], u[5]); VNR_BF(u[2], u[6]); VNR_BF(u[3], u[7]);
+  // twiddles w8^1, w8^2, w8^3 on the lower half
+  { const float2 a = u[5]; u[5] = INV ? make_float2(h * (a.x - a.y), h * (a.x + a.y)) : make_float2(h * (a.x + a.y), h * (a.y - a.x)); }
+  u[6] = mul_mj<INV>(u[6]);
+  { const float2 a = u[7]; u[7] = INV ? make_float2(-h * (a.x + a.y), h * (a.x - a.y)) : make_float2(h * (a.y - a.x), -h * (a.x + a.y)); }
+  VNR_BF(u[0], u[2]); VNR_BF(u[1], u[3]); VNR_BF(u[4], u[6]); VNR_BF(u[5], u[7]);
+  u[3] = mul_mj<INV>(u[3]); u[7] = mul_mj<INV>(u[7]);
+  VNR_BF(u[0], u[1]); VNR_BF(u[2], u[3]); VNR_BF(u[4], u[5]); VNR_BF(u[6], u[7]);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(float2 (&u)[4]) {   // bit-reversed outputs: X[0] = u0, X[2] = u1, X[1] = u2, X[3] = u3
+  VNR_BF(u[0], u[2]); VNR_BF(u[1], u[3]);
+  u[3] = mul_mj<INV>(u[3]);
+  VNR_BF(u[0], u[1]); VNR_BF(u[2], u[3]);
+}
+
+// in-LDS Stockham FFT of kNfft = 8.8.8.4 complex points by 256 threads: three radix-8 passes (8 points per thread in registers)
+// and one radix-4 pass (two butterflies per thread): 4 LDS round trips and barriers instead of the 11 of a radix-2 schedule.
+// Pass with radix R after sub-transforms of length p: thread i (< N/R): k = i mod p; inputs x[i + r N/R] times w^(r k) with
+// w = exp(-2 pi j / (p R)); outputs y[(i - k) R + k + r' p].  Data in `x`, scratch `y`; returns the buffer holding the result
+// (natural order).  INV: conjugate twiddles (unnormalised inverse).
+template <bool INV>
+__device__ void fft2048(float2* x, const float2* tw, int tid) {
+  // in place: every pass reads its points into registers, the workgroup synchronises, then the results are written to their
+  // autosort positions of the SAME buffer (16 KB instead of a ping-pong pair: 5 instead of 2 workgroups per CU)
+  int p = 1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = tid + 256 * u;
-      const int k = i & (p - 1);
-      const int j = ((i - k) << 1) + k;
-      float2 w = tw[k << (kLog - 1 - s)];
-      if (INV) w.y = -w.y;
-      const float2 u0 = x[i], u1 = cmul(x[i + kHalf], w);
-      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+  for (int pass = 0; pass < 3; ++pass) {
+    const int i = tid, k = i & (p - 1), j = ((i - k) << 3) + k;
+    float2 u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = x[pidx(i + r * (kNfft / 8))];
+    if (pass > 0) {
+      const int step = k * (kNfft / 8 / p);            // r k N / (p R)
+#pragma unroll
+      for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], twid<INV>(tw, r * step));
     }
+    dft8<INV>(u);
     __syncthreads();
-    float2* t = x; x = y; y = t;
+    const int rev[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[pidx(j + r * p)] = u[rev[r]];
+    __syncthreads();
+    p <<= 3;
   }
-  return x;
+  // p = 512: radix-4 pass, 512 butterflies (two per thread)
+  float2 v[2][4];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int i = tid + 256 * h2, k = i & (p - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[h2][r] = x[pidx(i + r * (kNfft / 4))];
+    const int step = k * (kNfft / 4 / p);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) v[h2][r] = cmul(v[h2][r], twid<INV>(tw, r * step));
+    dft4<INV>(v[h2]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int i = tid + 256 * h2, k = i & (p - 1), j = ((i - k) << 2) + k;
+    x[pidx(j)] = v[h2][0]; x[pidx(j + p)] = v[h2][2]; x[pidx(j + 2 * p)] = v[h2][1]; x[pidx(j + 3 * p)] = v[h2][3];
+  }
+  __syncthreads();
 }
 
 // sample n of the overlap-added, normalised signal in istft coordinates (0 <= n < n_fft + hop (nf - 1)), rebuilt from the frames.
@@ -83,20 +145,31 @@ __device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, i
 
 template <bool FIRST>
 __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
-  __shared__ float2 bufA[kNfft];
-  __shared__ float2 bufB[kNfft];
+  __shared__ float2 buf[kPadded];                      // padded indexing: pidx()
   __shared__ float2 tws[kHalf];
-  __shared__ float wins[kNfft], wsqs[kNfft];          // window and its square (win <= n_fft entries used)
+  extern __shared__ float wins[];                     // window [win] | window^2 [win]
+  float* wsqs = wins + a.win;
   const int tid = threadIdx.x;
   const int f = blockIdx.x, b = blockIdx.y;
   const int nf = a.frames ? a.frames[b] : a.T;
   if (f >= nf) return;
   const int lpad = (kNfft - a.win) / 2;
+  // the target magnitudes (and the initial phases) are requested first: their HBM round trip overlaps everything up to the
+  // phase step.  Thread tid owns bins tid + 256 u, u < 5 (bin 1024 = Nyquist: thread 0, u = 4)
+  float sm[5], th0[5];
+  {
+    const float* Sp = a.S + ((size_t)b * a.T + f) * kBins;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int k = tid + 256 * u;
+      sm[u] = k < kBins ? fabsf(Sp[k]) : 0.f;
+      th0[u] = (FIRST && k < kBins) ? a.ang0[((size_t)b * a.T + f) * kBins + k] : 0.f;
+    }
+  }
   for (int i = tid; i < kHalf; i += 256) tws[i] = a.tw[i];
-  for (int i = tid; i < a.win; i += 256) { const float w = a.window[i]; wins[i] = w; wsqs[i] = w * w; }
-  if (!FIRST) __syncthreads();
-  float2* X;
+  for (int i = tid; i < 2 * a.win; i += 256) wins[i] = a.window[i];
   if (!FIRST) {
+    __syncthreads();
     // analysis frame: padded[f hop + i], i in the window's support; padded = reflect-pad(y, n_fft/2), y = istft signal cropped by n_fft/2
     const int L = a.hop * (nf - 1);
     const float* frp = a.fr_prev + (size_t)b * a.T * a.win;
@@ -112,40 +185,44 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
         q = q < 0 ? 0 : q;
         v = wins[iw] * ola_sample(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
       }
-      bufA[i] = make_float2(v, 0.f);
+      buf[pidx(i)] = make_float2(v, 0.f);
     }
     __syncthreads();
-    X = fft2048<false>(bufA, bufB, tws, tid);
-  } else {
-    __syncthreads();
-    X = bufA;
+    fft2048<false>(buf, tws, tid);
   }
-  float2* Y = (X == bufA) ? bufB : bufA;
   // phase: unit = X / |X| (angle(0) = 0 -> 1); spectrum of the next signal = S . unit, Hermitian; DC and Nyquist are real (irfft
-  // ignores their imaginary parts)
-  const float* Sp = a.S + ((size_t)b * a.T + f) * kBins;
-  for (int k = tid; k < kBins; k += 256) {
-    float2 unit;
-    if (FIRST) {
-      const float th = a.ang0[((size_t)b * a.T + f) * kBins + k];
-      float sn, cs; sincosf(th, &sn, &cs);
-      unit = make_float2(cs, sn);
-    } else {
-      const float2 x = X[k];
-      const float mag = sqrtf(x.x * x.x + x.y * x.y);
-      unit = mag > 0.f ? make_float2(x.x / mag, x.y / mag) : make_float2(1.f, 0.f);
+  // ignores their imaginary parts).  Bin k and its mirror N - k are both owned by the thread that owns k: read, synchronise, write.
+  float2 yk[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int k = tid + 256 * u;
+    float2 unit = make_float2(1.f, 0.f);
+    if (k < kBins) {
+      if (FIRST) {
+        float sn, cs; sincosf(th0[u], &sn, &cs);
+        unit = make_float2(cs, sn);
+      } else {
+        const float2 x = buf[pidx(k)];
+        const float mag = sqrtf(x.x * x.x + x.y * x.y);
+        if (mag > 0.f) unit = make_float2(x.x / mag, x.y / mag);
+      }
     }
-    const float s = fabsf(Sp[k]);
-    float2 y = make_float2(s * unit.x, s * unit.y);
-    if (k == 0 || k == kHalf) y.y = 0.f;
-    Y[k] = y;
-    if (k > 0 && k < kHalf) Y[kNfft - k] = make_float2(y.x, -y.y);
+    yk[u] = make_float2(sm[u] * unit.x, sm[u] * unit.y);
+    if (k == 0 || k == kHalf) yk[u].y = 0.f;
   }
   __syncthreads();
-  float2* other = (Y == bufA) ? bufB : bufA;
-  const float2* R = fft2048<true>(Y, other, tws, tid);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int k = tid + 256 * u;
+    if (k < kBins) {
+      buf[pidx(k)] = yk[u];
+      if (k > 0 && k < kHalf) buf[pidx(kNfft - k)] = make_float2(yk[u].x, -yk[u].y);
+    }
+  }
+  __syncthreads();
+  fft2048<true>(buf, tws, tid);
   float* frn = a.fr_next + ((size_t)b * a.T + f) * a.win;
-  for (int i = tid; i < a.win; i += 256) frn[i] = wins[i] * (R[i + lpad].x * (1.0f / kNfft));
+  for (int i = tid; i < a.win; i += 256) frn[i] = wins[i] * (buf[pidx(i + lpad)].x * (1.0f / kNfft));
 }
 
 // final signal: wav[b][q] = overlap-added, normalised signal cropped by n_fft/2 (istft center=True), q < hop (nf - 1); 0 beyond
@@ -217,8 +294,9 @@ hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_pre
   VocArgs a;
   a.S = S; a.ang0 = ang0; a.fr_prev = fr_prev; a.fr_next = fr_next; a.frames = frames; a.tw = reinterpret_cast<const float2*>(tw); a.window = window;
   a.B = B; a.T = T; a.hop = hop; a.win = win;
-  if (ang0) vnr_launch(gl_frame_kernel<true>, dim3(T, B), dim3(256), 0, s, a);
-  else vnr_launch(gl_frame_kernel<false>, dim3(T, B), dim3(256), 0, s, a);
+  const unsigned lds = (unsigned)(2 * win * sizeof(float));
+  if (ang0) vnr_launch(gl_frame_kernel<true>, dim3(T, B), dim3(256), lds, s, a);
+  else vnr_launch(gl_frame_kernel<false>, dim3(T, B), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -34,6 +34,8 @@ def inference_test():
     parser.add_argument('--batch_size', type=int, default=1)
     parser.add_argument('--temperature', type=float, default=0.)
     parser.add_argument('--write_mels', type=int, default=1)
+    parser.add_argument('--write_wavs', type=int, default=0,
+                        help='also run the Griffin-Lim vocoder step on the GPU (audio/utils.py:24-40) and write prior-{fid}-{step}.wav')
     parser.add_argument('--num_utterances', type=int, default=8, help='synthetic data only')
     parser.add_argument('--seed', type=int, default=1234)
     args = parser.parse_args()
@@ -59,6 +61,10 @@ def inference_test():
     else:
         model.load_weights(args.ckpt_path)                                        # replaces Checkpoint.restore :122-123
     rng = np.random.Generator(np.random.PCG64(args.seed + rank))
+    tester = None
+    if args.write_wavs:
+        from vaenar_tts_amd.audio import TestUtils
+        tester = TestUtils(hparams, args.test_dir, engine=model.engine)          # inference.py:112
 
     def test_step(t, t_l):                                                        # inference.py:128-143
         text_pos_step = np.float32(model.mel_text_len_ratio) / np.float32(rf)
@@ -97,6 +103,9 @@ def inference_test():
             for i, fid in enumerate(ids):
                 np.save(os.path.join(args.test_dir, 'prior-{}-{}.npy'.format(fid, ckpt_step)),
                         outs[i, :pred_m_lens[i]].astype(np.float32))
+        if tester is not None:                                                    # audio/utils.py:24-40
+            tester.synthesize_and_save_wavs(ckpt_step, outs, np.minimum(pred_m_lens, outs.shape[1]), list(ids), prefix='prior',
+                                            seed=args.seed)
     time_consumed = vdist.max_over_ranks(time_consumed)
     durations = float(np.sum(vdist.gather_to_rank0(np.array([durations])))) if world > 1 else durations
     if rank == 0:

@@ -162,6 +162,8 @@ def main():
             "frac_f16_peak": (gemm_tflops * (1.0 if args.exact_fp32 else 3.0)) / PEAK_F16_MFMA_TFLOPS,
             "traffic": traffic.get("gemm_bytes_per_launch"),
             "traffic_source": traffic.get("source"),
+            "measured": "one batch in flight (the profiled pass after the timed region runs on a single stream); same as "
+                        "`rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1 ...` in profiles/",
             "launches_per_step": g["launches"] // max(1, args.profile_steps),
             "avg_launch_us": 1e3 * g["ms"] / max(1, g["launches"]),
             "flops_per_step": g["flops"] / max(1, args.profile_steps),

@@ -119,6 +119,7 @@ struct vnr_context {
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
   bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
   // cross K|V panels of the current call that were written as attention operand images (cleared with the workspace)
@@ -1490,11 +1491,21 @@ int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_leng
   float* text_embd = d_text_embd_out;
   if (!text_embd) { WS(t, (size_t)B * Tt * Dm); text_embd = t; }
   TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
+  WS(z, (size_t)B * Tz * C);
+  if (h->late_dec_kv) {
+    // the decoder's cross K|V are produced right before the decoder instead of ~2 ms earlier with the prior's: the decoder
+    // cross-attention (the HBM-bound kernel of the path) then finds them in L2 / Infinity Cache (12.5 -> ? us per launch)
+    WS(kvp, (size_t)B * Tt * h->prior_kv_n);
+    TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n, kvp, h->cfg.prior_attention_dim));
+    TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kvp, h->prior_kv_n, B, Tz, Tt, d_eps, z, nullptr));
+    WS(kvd, (size_t)B * Tt * h->dec_kv_n);
+    TRY(run_kv(h, text_embd, B, Tt, Dm, h->dec_kv_wt, h->dec_kv_n, kvd, h->cfg.dec_attention_dim));
+    return decoder_body(h, z, kvd, h->dec_kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, nullptr, d_mel, d_alignments);
+  }
   // every cross-attention K|V of the memory (all prior blocks + decoder blocks) in one GEMM
   const int kv_n = h->prior_kv_n + h->dec_kv_n;
   WS(kv, (size_t)B * Tt * kv_n);
   TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, kv_n, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
-  WS(z, (size_t)B * Tz * C);
   TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kv, kv_n, B, Tz, Tt, d_eps, z, nullptr));
   return decoder_body(h, z, kv + h->prior_kv_n, kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor,
                       nullptr, d_mel, d_alignments);
@@ -1818,6 +1829,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit")) { h->aoi_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }

@@ -6,7 +6,7 @@
 // (periodic Hann of win_length zero-padded symmetrically to n_fft, center=True reflect padding, overlap-add divided by the window
 // sum of squares where it exceeds float32 tiny, n_fft/2 samples cropped at both ends) -- restated in oracle/audio_numpy.py.
 //
-// One fused kernel per Griffin-Lim iteration, one workgroup per (utterance, frame):
+// One fused kernel per Griffin-Lim iteration, one workgroup per (utterance, pair of frames):
 //   * the time signal is never materialised between iterations.  An iteration keeps only the windowed inverse-FFT frames
 //     fr[b][t][win_length] (the padded window is zero outside its middle win_length samples, so a frame touches only those);
 //     frame t of the next iteration rebuilds the win_length samples it needs by GATHERING the <= ceil(win/hop)+1 overlapping
@@ -143,6 +143,10 @@ __device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, i
   return den > 1.17549435e-38f ? num / den : num;   // librosa.istft: divide where window_sumsquare > tiny(float32)
 }
 
+// One workgroup = TWO consecutive frames (2f, 2f+1) of one utterance, carried through ONE complex FFT pair: z = x0 + j x1 has
+// Z[k] = X0[k] + j X1[k], so X0[k] = (Z[k] + conj Z[N-k]) / 2 and X1[k] = (Z[k] - conj Z[N-k]) / (2j); after the phase step the
+// two Hermitian spectra are packed as W = Y0 + j Y1 and one inverse transform returns y0 in the real and y1 in the imaginary part.
+// Halves the butterfly work per frame (the kernel is bound by vector issue).
 template <bool FIRST>
 __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
   __shared__ float2 buf[kPadded];                      // padded indexing: pidx()
@@ -150,79 +154,96 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
   extern __shared__ float wins[];                     // window [win] | window^2 [win]
   float* wsqs = wins + a.win;
   const int tid = threadIdx.x;
-  const int f = blockIdx.x, b = blockIdx.y;
+  const int f0 = 2 * blockIdx.x, b = blockIdx.y;
   const int nf = a.frames ? a.frames[b] : a.T;
-  if (f >= nf) return;
+  if (f0 >= nf) return;
+  const bool two = f0 + 1 < nf;                        // the second frame of the pair exists
   const int lpad = (kNfft - a.win) / 2;
   // the target magnitudes (and the initial phases) are requested first: their HBM round trip overlaps everything up to the
   // phase step.  Thread tid owns bins tid + 256 u, u < 5 (bin 1024 = Nyquist: thread 0, u = 4)
-  float sm[5], th0[5];
-  {
-    const float* Sp = a.S + ((size_t)b * a.T + f) * kBins;
+  float sm[2][5], th0[2][5];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const size_t row = ((size_t)b * a.T + f0 + g) * kBins;
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       const int k = tid + 256 * u;
-      sm[u] = k < kBins ? fabsf(Sp[k]) : 0.f;
-      th0[u] = (FIRST && k < kBins) ? a.ang0[((size_t)b * a.T + f) * kBins + k] : 0.f;
+      const bool ok = k < kBins && (g == 0 || two);
+      sm[g][u] = ok ? fabsf(a.S[row + k]) : 0.f;
+      th0[g][u] = (FIRST && ok) ? a.ang0[row + k] : 0.f;
     }
   }
   for (int i = tid; i < kHalf; i += 256) tws[i] = a.tw[i];
   for (int i = tid; i < 2 * a.win; i += 256) wins[i] = a.window[i];
   if (!FIRST) {
     __syncthreads();
-    // analysis frame: padded[f hop + i], i in the window's support; padded = reflect-pad(y, n_fft/2), y = istft signal cropped by n_fft/2
+    // analysis frames: padded[f hop + i], i in the window's support; padded = reflect-pad(y, n_fft/2), y = istft signal cropped by n_fft/2
     const int L = a.hop * (nf - 1);
     const float* frp = a.fr_prev + (size_t)b * a.T * a.win;
 #pragma unroll
     for (int u = 0; u < kNfft / 256; ++u) {
       const int i = tid + 256 * u;
-      float v = 0.f;
+      float v[2] = {0.f, 0.f};
       const int iw = i - lpad;
       if (iw >= 0 && iw < a.win) {
-        int q = f * a.hop + i - kHalf;               // index into y
-        if (q < 0) q = -q;
-        if (q >= L) q = 2 * (L - 1) - q;
-        q = q < 0 ? 0 : q;
-        v = wins[iw] * ola_sample(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (g == 1 && !two) continue;
+          int q = (f0 + g) * a.hop + i - kHalf;      // index into y
+          if (q < 0) q = -q;
+          if (q >= L) q = 2 * (L - 1) - q;
+          q = q < 0 ? 0 : q;
+          v[g] = wins[iw] * ola_sample(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
+        }
       }
-      buf[pidx(i)] = make_float2(v, 0.f);
+      buf[pidx(i)] = make_float2(v[0], v[1]);
     }
     __syncthreads();
     fft2048<false>(buf, tws, tid);
   }
   // phase: unit = X / |X| (angle(0) = 0 -> 1); spectrum of the next signal = S . unit, Hermitian; DC and Nyquist are real (irfft
   // ignores their imaginary parts).  Bin k and its mirror N - k are both owned by the thread that owns k: read, synchronise, write.
-  float2 yk[5];
+  float2 wk[5], wm[5];
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int k = tid + 256 * u;
-    float2 unit = make_float2(1.f, 0.f);
+    float2 u0 = make_float2(1.f, 0.f), u1 = make_float2(1.f, 0.f);
     if (k < kBins) {
       if (FIRST) {
-        float sn, cs; sincosf(th0[u], &sn, &cs);
-        unit = make_float2(cs, sn);
+        float sn, cs;
+        sincosf(th0[0][u], &sn, &cs); u0 = make_float2(cs, sn);
+        sincosf(th0[1][u], &sn, &cs); u1 = make_float2(cs, sn);
       } else {
-        const float2 x = buf[pidx(k)];
-        const float mag = sqrtf(x.x * x.x + x.y * x.y);
-        if (mag > 0.f) unit = make_float2(x.x / mag, x.y / mag);
+        const float2 zk = buf[pidx(k)], zm = buf[pidx((kNfft - k) & (kNfft - 1))];
+        const float2 x0 = make_float2(zk.x + zm.x, zk.y - zm.y);          // 2 X0[k]
+        const float2 x1 = make_float2(zk.y + zm.y, zm.x - zk.x);          // 2 X1[k] = -j (Z[k] - conj Z[N-k])
+        const float m0 = sqrtf(x0.x * x0.x + x0.y * x0.y), m1 = sqrtf(x1.x * x1.x + x1.y * x1.y);
+        if (m0 > 0.f) u0 = make_float2(x0.x / m0, x0.y / m0);
+        if (m1 > 0.f) u1 = make_float2(x1.x / m1, x1.y / m1);
       }
     }
-    yk[u] = make_float2(sm[u] * unit.x, sm[u] * unit.y);
-    if (k == 0 || k == kHalf) yk[u].y = 0.f;
+    float2 y0 = make_float2(sm[0][u] * u0.x, sm[0][u] * u0.y), y1 = make_float2(sm[1][u] * u1.x, sm[1][u] * u1.y);
+    if (k == 0 || k == kHalf) { y0.y = 0.f; y1.y = 0.f; }
+    wk[u] = make_float2(y0.x - y1.y, y0.y + y1.x);                         // W[k]   = Y0[k] + j Y1[k]
+    wm[u] = make_float2(y0.x + y1.y, y1.x - y0.y);                         // W[N-k] = conj Y0[k] + j conj Y1[k]
   }
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int k = tid + 256 * u;
     if (k < kBins) {
-      buf[pidx(k)] = yk[u];
-      if (k > 0 && k < kHalf) buf[pidx(kNfft - k)] = make_float2(yk[u].x, -yk[u].y);
+      buf[pidx(k)] = wk[u];
+      if (k > 0 && k < kHalf) buf[pidx(kNfft - k)] = wm[u];
     }
   }
   __syncthreads();
   fft2048<true>(buf, tws, tid);
-  float* frn = a.fr_next + ((size_t)b * a.T + f) * a.win;
-  for (int i = tid; i < a.win; i += 256) frn[i] = wins[i] * (buf[pidx(i + lpad)].x * (1.0f / kNfft));
+  float* frn = a.fr_next + ((size_t)b * a.T + f0) * a.win;
+  for (int i = tid; i < a.win; i += 256) {
+    const float2 y = buf[pidx(i + lpad)];
+    frn[i] = wins[i] * (y.x * (1.0f / kNfft));
+    if (two) frn[a.win + i] = wins[i] * (y.y * (1.0f / kNfft));
+  }
 }
 
 // final signal: wav[b][q] = overlap-added, normalised signal cropped by n_fft/2 (istft center=True), q < hop (nf - 1); 0 beyond
@@ -295,8 +316,8 @@ hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_pre
   a.S = S; a.ang0 = ang0; a.fr_prev = fr_prev; a.fr_next = fr_next; a.frames = frames; a.tw = reinterpret_cast<const float2*>(tw); a.window = window;
   a.B = B; a.T = T; a.hop = hop; a.win = win;
   const unsigned lds = (unsigned)(2 * win * sizeof(float));
-  if (ang0) vnr_launch(gl_frame_kernel<true>, dim3(T, B), dim3(256), lds, s, a);
-  else vnr_launch(gl_frame_kernel<false>, dim3(T, B), dim3(256), lds, s, a);
+  if (ang0) vnr_launch(gl_frame_kernel<true>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
+  else vnr_launch(gl_frame_kernel<false>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

@@ -186,6 +186,18 @@ def main():
             "kernel_ms_per_step": {c: p["ms"] / max(1, args.profile_steps) for c, p in prof.items()},
         }
         out["device"] = eng.device_info()
+        # ---- host-to-host latency of ONE call (ids on the host -> mel on the host), one batch in flight ----
+        lat = []
+        for _ in range(20):
+            t1 = time.perf_counter()
+            m1, _a1 = model.inference(batch["ids"], batch["mel_lengths"], batch["text_lengths"], reduction_factor=rf, eps=d_eps,
+                                      return_alignments=False)
+            m1.numpy()                                       # device -> host copy ends the call
+            lat.append(1e3 * (time.perf_counter() - t1))
+        lat.sort()
+        out["latency_host_to_host_ms"] = {"min": lat[0], "median": lat[len(lat) // 2], "p95": lat[int(0.95 * (len(lat) - 1))],
+                                          "note": "one S1 batch: token ids and lengths uploaded, 4.1 MB of mels downloaded, alignments not "
+                                                  "requested; PCIe-inclusive, never `value`"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the NumPy oracle (fp32) on the same S1 batch, host cores of this box ----

@@ -1,4 +1,5 @@
-// Cross-attention core on pre-split operands (gfx950, split-fp16 MFMA 32x32x16), Tk <= 128.
+// Attention core on producer-split operand images (gfx950, split-fp16 MFMA 32x32x16): attn3_kernel<ALI> for non-causal calls with
+// Tk <= 128 (cross-attention over the text, alignments optional), attn3g_kernel for any Tk and the causal mask (further below).
 //
 // Same contract as attention.hip / attention2.hip (reference modules/attention.py:221-246: scale, key ^ query mask with the
 // -2**32+1 fill, softmax, . V, optional alignments) for the cross-attention of a CrossAttentionBLK (attention.py:445-447),

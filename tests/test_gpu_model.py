@@ -120,6 +120,35 @@ def test_inference_matches_oracle(setup, fused, temperature):
         np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("opts", [{}, {"attn_presplit": 0}, {"attn_presplit_self": 0}, {"late_dec_kv": 0}, {"chain": 0}],
+                         ids=["default", "cross-fp32", "self-fp32", "kv-early", "no-chain"])
+def test_inference_long_text_and_ab_switches(opts):
+    """T_text = 150 > 128: the cross-attention leaves the operand-image kernel (attention3, Tk <= 128) for the fp32-operand
+    kernels (attention2, and the first-generation kernel for the alignments); T_z = 45 is not a multiple of 16, so the V stage
+    of the chain tails takes the generic image scatter.  Every A/B switch of the attention path gives the same mels."""
+    hps, model, oracle = _setup("tiny")
+    try:
+        for k, v in opts.items():
+            model.engine.set_option(k, v)
+        b = make_batch(2, 150, 90, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, temperature=1.0, text_step=21, mel_step=17)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        rmel, rali = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+        assert np.abs(mel.numpy() - rmel).max() < MEL_TOL
+        for k in rali:
+            np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+        # ... and a short text (images everywhere) on the same handle
+        b = make_batch(3, 40, 64, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, temperature=1.0, text_step=7, mel_step=9)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        rmel, rali = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+        assert np.abs(mel.numpy() - rmel).max() < MEL_TOL
+        for k in rali:
+            np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+    finally:
+        model.engine.close()
+
+
 def test_test_step_frame_counts(setup):
     """inference.py:128-143: length predictor -> int32 trunc -> +80 -> ceil(/2) -> prior -> decoder."""
     name, hps, model, oracle = setup

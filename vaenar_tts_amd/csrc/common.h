@@ -186,11 +186,13 @@ struct ChainStage {
   long long aoi_img_bytes;
   int dst;                  // destination panel or -1
   float scale;              // 2^-s of the pre-scaled weight image
+  int lds_ln;               // (set by launch_panel_chain) LDS slot of gamma | beta for a LayerNorm stage, -1 otherwise
 };
 struct ChainArgs {
   const float* in0; int ld0;   // panel 0 <- in0[M, D]
   const float* in1; int ld1;   // panel 1 <- in1[M, D] (or null)
   int M, D, nstages;
+  int rows64;                  // 1: 64-row panels (M/64 workgroups), 0: 32-row panels -- see gemm3.hip
   const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded
   unsigned long long* dbg_ts;   // measurement only: [wgs][64] s_memtime stamps (start, panels, then loop/epilogue per stage)
   ChainStage st[kMaxChainStages];

@@ -119,6 +119,7 @@ struct vnr_context {
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
   bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
@@ -274,6 +275,7 @@ int chain_params(vnr_handle h, ChainArgs& g) {
 
 int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   TRY(chain_params(h, g));
+  g.rows64 = h->chain_rows64 ? 1 : 0;
   ProfScope ps(h, CLS_GEMM, flops, 0.0);
   hipError_t e = launch_panel_chain(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("panel chain launch: ") + hipGetErrorString(e));
@@ -1139,6 +1141,7 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
   vnr_handle h = new vnr_context();
   h->cfg = *cfg;
   h->device = device;
+  if (const char* e = getenv("VNR_CHAIN_ROWS64")) h->chain_rows64 = atoi(e) != 0;      // test / measurement override of the option's default
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return fail(nullptr, VNR_ERR_HIP, "hipSetDevice / hipStreamCreate failed");
@@ -1829,6 +1832,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit")) { h->aoi_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "chain_rows64")) { h->chain_rows64 = value != 0; return VNR_OK; }
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }

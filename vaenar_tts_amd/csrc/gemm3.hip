@@ -22,11 +22,16 @@ typedef __attribute__((address_space(3))) void* lds3_t;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PANEL_BYTES = 32 * 1024;          // 32 rows x 8 k-tiles x 128 B
-constexpr int P_OFF = 2048;                     // [0, 2 KB): LayerNorm exchange scratch [2][32][8]
-constexpr int PRM_OFF = P_OFF + 2 * PANEL_BYTES;     // epilogue parameters [kMaxChainStages][3][256] fp32
-constexpr int CHAIN_LDS = PRM_OFF + kMaxChainStages * 768 * 4;
-constexpr int PF = 4;                           // weight k-tiles kept in flight per wave (register prefetch depth)
+// LDS map of a workgroup with RT row tiles (ROWS = 32 RT activation rows):
+//   [0, 2048 RT)                LayerNorm exchange scratch [2][ROWS][8] fp32
+//   [.., + 2 x ROWS KiB)        two activation panels: ROWS rows x 8 k-tiles x 128 B
+//   then                        bias of every stage [nstages][256] fp32, then (gamma | beta) [256 + 256] fp32 of every LayerNorm stage
+template <int RT> struct ChainLds {
+  static constexpr int ROWS = 32 * RT;
+  static constexpr int PANEL_BYTES = ROWS * 1024;
+  static constexpr int P_OFF = 2048 * RT;
+  static constexpr int PRM_OFF = P_OFF + 2 * PANEL_BYTES;
+};
 
 __device__ __forceinline__ float act3(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -44,16 +49,26 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ int panel_off(int r, int kt, int c) { return r * 1024 + ((((kt << 3) + c) ^ (r & 15)) << 4); }
 }  // namespace
 
+// RT = 1: 32-row panels (M/32 workgroups).  RT = 2: 64-row panels (M/64 workgroups): every weight operand fetched from L2 feeds
+// two MFMA sets, which halves the weight stream per row -- the stream through the CU's vector-memory return path (64 B/clk) is
+// what bounds this kernel -- at the price of half as many workgroups: the same launch time when one batch owns the GPU, but
+// half the CUs stay free for the kernels of other batches in flight (bench.py --streams).
+template <int RT>
 __global__ void __launch_bounds__(512)
 panel_chain_kernel(const ChainArgs g) {
+  using L = ChainLds<RT>;
+  constexpr int ROWS = L::ROWS, PANEL_BYTES = L::PANEL_BYTES, P_OFF = L::P_OFF, PRM_OFF = L::PRM_OFF;
+  // weight k-tiles kept in flight per wave (register prefetch depth): a k-tile of the 64-row variant carries twice the MFMAs, so
+  // half the depth covers the same time (and the accumulators need the registers)
+  constexpr int PF = RT == 2 ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = blockIdx.x * ROWS;
   auto panel_ptr = [&](int i) -> char* { return smem + P_OFF + i * PANEL_BYTES; };
   float* scratch = reinterpret_cast<float*>(smem);
-  float* prm = reinterpret_cast<float*>(smem + PRM_OFF);       // [stage][bias | gamma | beta][256]
+  float* prm = reinterpret_cast<float*>(smem + PRM_OFF);       // [stage][256] bias, then the LayerNorm (gamma | beta) slots
   unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 64 : nullptr;
   auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   auto wstamp = [&](int si, int i) { if (ts && si == 1 && lane == 0) ts[32 + wave * 4 + i] = __builtin_amdgcn_s_memtime(); };
@@ -93,36 +108,42 @@ panel_chain_kernel(const ChainArgs g) {
 #pragma unroll
   for (int u = 0; u < PF; ++u) fetch(u);
 
-  // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (one contiguous block, no registers; read back with
-  //      ds_read at the epilogues, so no vector-memory wait is ever needed there)
+  // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (no registers; read back with ds_read at the epilogues, so
+  //      no vector-memory wait is ever needed there): stage s is copied by wave s mod 8 -- its bias (1 KiB) and, for a
+  //      LayerNorm stage, gamma | beta (2 KiB, contiguous in the packed block) into the slot the host assigned (lds_ln)
   {
-    const int chunks = g.nstages * 768 / 4;                          // 16-byte chunks; 64 per wave instruction
-    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)chunks * 16u, 0x00020000);
-    for (int c0 = wave * 64; c0 < chunks; c0 += 512)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + c0 * 16), 16, (unsigned)(c0 + lane) * 16u, 0, 0, 0);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
+    for (int s_ = wave; s_ < g.nstages; s_ += 8) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + s_ * 1024), 16, (unsigned)(s_ * 3072 + lane * 16), 0, 0, 0);
+      const int lo = g.st[s_].lds_ln;
+      if (lo >= 0) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + lo * 4), 16, (unsigned)(s_ * 3072 + 1024 + lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + lo * 4 + 1024), 16, (unsigned)(s_ * 3072 + 2048 + lane * 16), 0, 0, 0);
+      }
+    }
   }
   // ---- input panels (fp32 rows in HBM -> split fp16 panel): all reads issued first, rows beyond M read as zeros --------
   {
     const int q4 = g.D >> 2;                                       // float4 per row (<= 64)
-    float4 x[2][4];
+    float4 x[2][4 * RT];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       const float* src = pi == 0 ? g.in0 : g.in1;
       const int ld = pi == 0 ? g.ld0 : g.ld1;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 4 * RT; ++it) {
         const int e = tid + 512 * it, r = e / q4, j = e - r * q4;
-        x[pi][it] = (src && r < 32 && m0 + r < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + 4 * j)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[pi][it] = (src && r < ROWS && m0 + r < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + 4 * j)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       if (!(pi == 0 ? g.in0 : g.in1)) continue;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
+      for (int it = 0; it < 4 * RT; ++it) {
         const int e = tid + 512 * it, r = e / q4, j = e - r * q4;
-        if (r >= 32) continue;
+        if (r >= ROWS) continue;
         const int kt = j >> 3, p = (j & 7) * 4;                    // position inside the 32-k tile
         h16x4 hi, lo;
         const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
@@ -137,9 +158,11 @@ panel_chain_kernel(const ChainArgs g) {
   lds_barrier();
   stamp(1);
 
-  f32x16 accF;                                          // persistent accumulator of the FFN second layer
+  f32x16 accF[RT];                                      // persistent accumulators of the FFN second layer
 #pragma unroll
-  for (int r = 0; r < 16; ++r) accF[r] = 0.f;
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accF[rt][r] = 0.f;
 
 #pragma unroll 1
   for (int si = 0; si < g.nstages; ++si) {
@@ -147,9 +170,11 @@ panel_chain_kernel(const ChainArgs g) {
     const bool wave_on = 32 * wave < st.n;               // this wave owns output columns 32w .. 32w+31
     const char* const Ap0 = panel_ptr(st.a0);
     const char* const Ap1 = panel_ptr(st.a1);
-    f32x16 acc;
+    f32x16 acc[RT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
     // A stage that holds only V columns of a Q|K|V panel (out_fmt 4) is computed UN-transposed (operands swapped: lane <->
     // output column, registers <-> the 32 rows in k-slot order): 8 consecutive registers are then exactly one 16-byte unit of
     // the V image (common.h), stored with fully coalesced 1 KiB wave writes instead of 2-byte scatters.  Needs the 16-row
@@ -159,17 +184,19 @@ panel_chain_kernel(const ChainArgs g) {
     wstamp(si, 0);
     const int npad = (st.nk + PF - 1) / PF * PF;
     // activation operands are read ONE k-tile ahead (registers a[cur] / a[nxt]) so the LDS latency of tile kt+1 hides
-    // under the six MFMAs of tile kt; reads past the stage's last tile are clamped (harmless re-read)
-    h16x8 afr[2][4];
+    // under the MFMAs of tile kt; reads past the stage's last tile are clamped (harmless re-read)
+    h16x8 afr[2][RT][4];
     auto read_a = [&](int kt, int set) {
       const int kc = kt < st.nk ? kt : st.nk - 1;
       const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
       const int akt = (kc < st.asw) ? kc + st.akt0 : kc - st.asw;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        afr[set][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 2 * t + half));
-        afr[set][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off(l31, akt, 4 + 2 * t + half));
-      }
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          afr[set][rt][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off(32 * rt + l31, akt, 2 * t + half));
+          afr[set][rt][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off(32 * rt + l31, akt, 4 + 2 * t + half));
+        }
     };
     read_a(0, 0);
 #pragma unroll 1
@@ -181,18 +208,22 @@ panel_chain_kernel(const ChainArgs g) {
         if (wave_on && kt < st.nk) {
           if (!vswap) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {                                 // D^T: lane <-> activation row
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][2 * t + 1], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][2 * t], acc, 0, 0, 0);
-            }
+            for (int t = 0; t < 2; ++t)                                   // D^T: lane <-> activation row
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t + 1], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
+              }
           } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {                                 // D: lane <-> output column (V image stage)
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t], wreg[u][2 * t], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t + 1], wreg[u][2 * t], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][2 * t], wreg[u][2 * t + 1], acc, 0, 0, 0);
-            }
+            for (int t = 0; t < 2; ++t)                                   // D: lane <-> output column (V image stage)
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t + 1], wreg[u][2 * t], acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t + 1], acc[rt], 0, 0, 0);
+              }
           }
         }
         fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)
@@ -201,123 +232,152 @@ panel_chain_kernel(const ChainArgs g) {
     stamp(2 + 2 * si);
     wstamp(si, 1);
     // ---- FFN second layer: accumulate over hidden chunks (modes 1,2: no epilogue yet) ----------------------------------
-    if (st.acc_mode == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accF[r] = acc[r];
-    } else if (st.acc_mode >= 2) {
+    for (int rt = 0; rt < RT; ++rt) {
+      if (st.acc_mode == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accF[r] += acc[r];
+        for (int r = 0; r < 16; ++r) accF[rt][r] = acc[rt][r];
+      } else if (st.acc_mode >= 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accF[rt][r] += acc[rt][r];
+      }
     }
     if (st.acc_mode == 1 || st.acc_mode == 2) { lds_barrier(); stamp(3 + 2 * si); continue; }   // the hidden panel may be rewritten next
     if (vswap) {
       if (wave_on) {
         const int cv = st.aoi_c0 - 2 * st.aoi_D + 32 * wave + l31;          // V column of this lane: head cv >> 6, channel cv & 63
-        const float bv = (prm + si * 768)[32 * wave + l31];                // (zero padded when the stage has no bias)
+        const float bv = (prm + si * 256)[32 * wave + l31];                // (zero padded when the stage has no bias)
         const int Hh = st.aoi_D >> 6, TT = (st.aoi_T + 31) >> 5;
 #pragma unroll
-        for (int tp = 0; tp < 2; ++tp) {
-          const int R = m0 + 16 * tp;
-          if (R >= g.M) continue;
-          const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
-          h16x8 hi, lo;
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float x = acc[8 * tp + e] * st.scale + bv; const _Float16 hh = (_Float16)x; hi[e] = hh; lo[e] = (_Float16)(x - (float)hh); }
-          char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
-                       ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
-          *reinterpret_cast<h16x8*>(pdst) = hi;
-          *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
-        }
+          for (int tp = 0; tp < 2; ++tp) {
+            const int R = m0 + 32 * rt + 16 * tp;
+            if (R >= g.M) continue;
+            const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
+            h16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float x = acc[rt][8 * tp + e] * st.scale + bv; const _Float16 hh = (_Float16)x; hi[e] = hh; lo[e] = (_Float16)(x - (float)hh); }
+            char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
+                         ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
+            *reinterpret_cast<h16x8*>(pdst) = hi;
+            *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
+          }
       }
       lds_barrier(); stamp(3 + 2 * si); wstamp(si, 3);
       continue;
     }
     if (st.acc_mode == 3) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = accF[r];
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = accF[rt][r];
     }
 
     // ---- epilogue: v = act(acc*scale + bias) (+ residual panel) ; optional LayerNorm over the row ------------------------
-    // lane (row l31, half) holds columns n = 32*wave + 8q + 4*half + e  (register 4q + e)
-    float v[16];
-    const int row = m0 + l31;
-    const float* sp = prm + si * 768;
+    // lane (row 32 rt + l31, half) holds columns n = 32*wave + 8q + 4*half + e  (register 4q + e)
+    float v[RT][16];
+    const float* sp = prm + si * 256;
     bool cok[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = 32 * wave + 8 * q + 4 * half;
       cok[q] = wave_on && col < st.n;                                   // (n is a multiple of 4)
       const float4 bi = *reinterpret_cast<const float4*>(sp + col);
-      v[4 * q + 0] = acc[4 * q + 0] * st.scale + bi.x;
-      v[4 * q + 1] = acc[4 * q + 1] * st.scale + bi.y;
-      v[4 * q + 2] = acc[4 * q + 2] * st.scale + bi.z;
-      v[4 * q + 3] = acc[4 * q + 3] * st.scale + bi.w;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        v[rt][4 * q + 0] = acc[rt][4 * q + 0] * st.scale + bi.x;
+        v[rt][4 * q + 1] = acc[rt][4 * q + 1] * st.scale + bi.y;
+        v[rt][4 * q + 2] = acc[rt][4 * q + 2] * st.scale + bi.z;
+        v[rt][4 * q + 3] = acc[rt][4 * q + 3] * st.scale + bi.w;
+      }
     }
     if (st.act == ACT_RELU) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[rt][r] = fmaxf(v[rt][r], 0.f);
     } else if (st.act == ACT_TANH) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = tanhf(v[r]);
-    }
-    if (st.pe) {                                                        // + pos_weight * PE[t] (encoder.py:85, transform.py:51)
-      const float* pr = st.pe + (size_t)(row % st.pe_T) * st.n;
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = 32 * wave + 8 * q + 4 * half;
-        if (cok[q] && row < g.M) {
-          const float4 p4 = *reinterpret_cast<const float4*>(pr + col);
-          v[4 * q] += st.pe_w * p4.x; v[4 * q + 1] += st.pe_w * p4.y; v[4 * q + 2] += st.pe_w * p4.z; v[4 * q + 3] += st.pe_w * p4.w;
+        for (int r = 0; r < 16; ++r) v[rt][r] = tanhf(v[rt][r]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = m0 + 32 * rt + l31, prow = 32 * rt + l31;
+      if (st.pe) {                                                      // + pos_weight * PE[t] (encoder.py:85, transform.py:51)
+        const float* pr = st.pe + (size_t)(row % st.pe_T) * st.n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * wave + 8 * q + 4 * half;
+          if (cok[q] && row < g.M) {
+            const float4 p4 = *reinterpret_cast<const float4*>(pr + col);
+            v[rt][4 * q] += st.pe_w * p4.x; v[rt][4 * q + 1] += st.pe_w * p4.y; v[rt][4 * q + 2] += st.pe_w * p4.z; v[rt][4 * q + 3] += st.pe_w * p4.w;
+          }
         }
       }
-    }
-    if (st.res >= 0) {                                                  // residual = hi + lo of the panel entry (22 bits)
-      const char* Rp = panel_ptr(st.res);
+      if (st.res >= 0) {                                                // residual = hi + lo of the panel entry (22 bits)
+        const char* Rp = panel_ptr(st.res);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = 32 * wave + 8 * q + 4 * half, kt = col >> 5, p = col & 31;
-        const h16x4 rh = *reinterpret_cast<const h16x4*>(Rp + panel_off(l31, kt, p >> 3) + (p & 4) * 2);
-        const h16x4 rl = *reinterpret_cast<const h16x4*>(Rp + panel_off(l31, kt, 4 + (p >> 3)) + (p & 4) * 2);
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * wave + 8 * q + 4 * half, kt = col >> 5, p = col & 31;
+          const h16x4 rh = *reinterpret_cast<const h16x4*>(Rp + panel_off(prow, kt, p >> 3) + (p & 4) * 2);
+          const h16x4 rl = *reinterpret_cast<const h16x4*>(Rp + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * q + e] += (float)rh[e] + (float)rl[e];
+          for (int e = 0; e < 4; ++e) v[rt][4 * q + e] += (float)rh[e] + (float)rl[e];
+        }
       }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (!cok[q]) v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0.f;
-    if (st.gamma) {                                                      // LayerNormalization (eps 1e-3), two-pass statistics
-      float s1 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s1 += v[r];
-      s1 += __shfl_xor(s1, 32, 64);
-      if (half == 0) scratch[l31 * 8 + wave] = s1;
-      lds_barrier();
-      float mean = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) mean += scratch[l31 * 8 + w];
-      mean *= 1.f / (float)st.n;
-      float s2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
+        if (!cok[q]) v[rt][4 * q] = v[rt][4 * q + 1] = v[rt][4 * q + 2] = v[rt][4 * q + 3] = 0.f;
+    }
+    if (st.gamma) {                                                      // LayerNormalization (eps 1e-3), two-pass statistics
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float d = cok[q] ? v[4 * q + e] - mean : 0.f;
-          s2 += d * d;
-        }
-      s2 += __shfl_xor(s2, 32, 64);
-      if (half == 0) scratch[256 + l31 * 8 + wave] = s2;
+      for (int rt = 0; rt < RT; ++rt) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += v[rt][r];
+        s1 += __shfl_xor(s1, 32, 64);
+        if (half == 0) scratch[(32 * rt + l31) * 8 + wave] = s1;
+      }
       lds_barrier();
-      float var = 0.f;
+      float mean[RT];
 #pragma unroll
-      for (int w = 0; w < 8; ++w) var += scratch[256 + l31 * 8 + w];
-      const float rstd = 1.0f / sqrtf(var * (1.f / (float)st.n) + kLnEps);
+      for (int rt = 0; rt < RT; ++rt) {
+        float mu = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = 32 * wave + 8 * q + 4 * half;
-        const float4 ga = *reinterpret_cast<const float4*>(sp + 256 + col), be = *reinterpret_cast<const float4*>(sp + 512 + col);
-        v[4 * q + 0] = (v[4 * q + 0] - mean) * rstd * ga.x + be.x;
-        v[4 * q + 1] = (v[4 * q + 1] - mean) * rstd * ga.y + be.y;
-        v[4 * q + 2] = (v[4 * q + 2] - mean) * rstd * ga.z + be.z;
-        v[4 * q + 3] = (v[4 * q + 3] - mean) * rstd * ga.w + be.w;
+        for (int w = 0; w < 8; ++w) mu += scratch[(32 * rt + l31) * 8 + w];
+        mu *= 1.f / (float)st.n;
+        mean[rt] = mu;
+        float s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = cok[q] ? v[rt][4 * q + e] - mu : 0.f;
+            s2 += d * d;
+          }
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0) scratch[ROWS * 8 + (32 * rt + l31) * 8 + wave] = s2;
+      }
+      lds_barrier();
+      const float* lnp = prm + st.lds_ln;                               // gamma [256] | beta [256]
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) var += scratch[ROWS * 8 + (32 * rt + l31) * 8 + w];
+        const float rstd = 1.0f / sqrtf(var * (1.f / (float)st.n) + kLnEps);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * wave + 8 * q + 4 * half;
+          const float4 ga = *reinterpret_cast<const float4*>(lnp + col), be = *reinterpret_cast<const float4*>(lnp + 256 + col);
+          v[rt][4 * q + 0] = (v[rt][4 * q + 0] - mean[rt]) * rstd * ga.x + be.x;
+          v[rt][4 * q + 1] = (v[rt][4 * q + 1] - mean[rt]) * rstd * ga.y + be.y;
+          v[rt][4 * q + 2] = (v[rt][4 * q + 2] - mean[rt]) * rstd * ga.z + be.z;
+          v[rt][4 * q + 3] = (v[rt][4 * q + 3] - mean[rt]) * rstd * ga.w + be.w;
+        }
       }
     } else if (st.dst >= 0 && (st.dst == st.a0 || (st.asw < st.nk && st.dst == st.a1))) {
       lds_barrier();                                                  // in-place stage: every wave is done reading the source panel
@@ -327,44 +387,48 @@ panel_chain_kernel(const ChainArgs g) {
     // Attention operand images (common.h): a wave's 32 columns lie inside one head, so everything but (q, half) is either
     // per-lane-per-stage (the row's tile) or wave-uniform (image, head, channel base).  Q/K-type columns take the fast
     // path below; V-type columns of a stage that could not run un-transposed fall back to the generic scatter.
-    char* img_row = nullptr;                             // Q/K-type: address of this lane's 16-byte unit for t = 0, g = 0
-    bool img_generic = false;
-    if (st.out && st.out_fmt != 0 && wave_on && row < g.M) {
-      const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + 32 * wave;
-      const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
-      if (which == 2) img_generic = true;
-      else {
-        const int TT = (st.aoi_T + 31) >> 5, bb = row / st.aoi_T, tt = row - bb * st.aoi_T;
-        img_row = reinterpret_cast<char*>(st.out) + (size_t)which * st.aoi_img_bytes +
-                  ((size_t)(bb * (Dd >> 6) + (cw >> 6)) * TT + (tt >> 5)) * kAoiTile + ((cw & 63) >> 4) * 1024 + ((tt & 31) << 4) + half * 8;
-      }
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = 32 * wave + 8 * q + 4 * half;
-      if (!cok[q]) continue;
-      if (st.out && row < g.M) {
-        if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
+    for (int rt = 0; rt < RT; ++rt) {
+      const int row = m0 + 32 * rt + l31, prow = 32 * rt + l31;
+      char* img_row = nullptr;                           // Q/K-type: address of this lane's 16-byte unit for t = 0, g = 0
+      bool img_generic = false;
+      if (st.out && st.out_fmt != 0 && wave_on && row < g.M) {
+        const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + 32 * wave;
+        const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
+        if (which == 2) img_generic = true;
+        else {
+          const int TT = (st.aoi_T + 31) >> 5, bb = row / st.aoi_T, tt = row - bb * st.aoi_T;
+          img_row = reinterpret_cast<char*>(st.out) + (size_t)which * st.aoi_img_bytes +
+                    ((size_t)(bb * (Dd >> 6) + (cw >> 6)) * TT + (tt >> 5)) * kAoiTile + ((cw & 63) >> 4) * 1024 + ((tt & 31) << 4) + half * 8;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * wave + 8 * q + 4 * half;
+        if (!cok[q]) continue;
+        if (st.out && row < g.M) {
+          if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
+            h16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[rt][4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[rt][4 * q + e] - (float)hh); }
+            char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
+            *reinterpret_cast<h16x4*>(pd) = hi;
+            *reinterpret_cast<h16x4*>(pd + 4096) = lo;
+          } else if (img_generic) {
+            AoiDesc ad; ad.mode = 4; ad.D = st.aoi_D; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.blk_bytes = st.aoi_img_bytes;
+            ad.qk = reinterpret_cast<char*>(st.out); ad.vt = ad.qk + 2 * st.aoi_img_bytes;
+            aoi_store4(ad, row, st.aoi_c0 + col, &v[rt][4 * q]);
+          }
+          else out_store4(st.out + (size_t)row * st.ldo + col, v[rt][4 * q], v[rt][4 * q + 1], v[rt][4 * q + 2], v[rt][4 * q + 3]);
+        }
+        if (st.dst >= 0) {
           h16x4 hi, lo;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[4 * q + e] - (float)hh); }
-          char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
-          *reinterpret_cast<h16x4*>(pd) = hi;
-          *reinterpret_cast<h16x4*>(pd + 4096) = lo;
-        } else if (img_generic) {
-          AoiDesc ad; ad.mode = 4; ad.D = st.aoi_D; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.blk_bytes = st.aoi_img_bytes;
-          ad.qk = reinterpret_cast<char*>(st.out); ad.vt = ad.qk + 2 * st.aoi_img_bytes;
-          aoi_store4(ad, row, st.aoi_c0 + col, &v[4 * q]);
+          for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[rt][4 * q + e]; hi[e] = h; lo[e] = (_Float16)(v[rt][4 * q + e] - (float)h); }
+          const int kt = col >> 5, p = col & 31;
+          *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
+          *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
         }
-        else out_store4(st.out + (size_t)row * st.ldo + col, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-      }
-      if (st.dst >= 0) {
-        h16x4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[4 * q + e]; hi[e] = h; lo[e] = (_Float16)(v[4 * q + e] - (float)h); }
-        const int kt = col >> 5, p = col & 31;
-        *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(l31, kt, p >> 3) + (p & 4) * 2) = hi;
-        *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(l31, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
       }
     }
     lds_barrier();                                                    // panels are complete / free before the next stage
@@ -373,30 +437,24 @@ panel_chain_kernel(const ChainArgs g) {
   }
 }
 
-hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
-  if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
-  for (int i = 0; i < g.nstages; ++i) {
-    const ChainStage& st = g.st[i];
-    if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.akt0 < 0 || st.akt0 + (st.asw < st.nk ? st.asw : st.nk) > 8 || (st.pe && st.pe_T <= 0) || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
-    if (st.out && (st.ldo & 3)) return hipErrorInvalidValue;
-    if (st.out && st.out_fmt == 1 && ((st.n & 63) || st.aoi_T <= 0)) return hipErrorInvalidValue;
-    if (st.out && st.out_fmt == 4 && ((st.aoi_D & 63) || st.aoi_T <= 0 || st.aoi_D <= 0 || (st.aoi_c0 & 3) || st.aoi_c0 + st.n > 3 * st.aoi_D)) return hipErrorInvalidValue;
-    if (st.out_fmt != 0 && st.out_fmt != 1 && st.out_fmt != 4) return hipErrorInvalidValue;
+template <int RT>
+static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
+  static int attr_set = 0;
+  if (attr_set < lds) {
+    (void)hipFuncSetAttribute((const void*)panel_chain_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = lds;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)panel_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS);
-    attr_set = true;
-  }
+  constexpr int ROWS = 32 * RT;
+  const int wgs = (g.M + ROWS - 1) / ROWS;
   static const char* ts_path = getenv("VNR_CHAIN_TS");
   if (ts_path) {
     ChainArgs gg = g;
-    const size_t n = (size_t)((g.M + 31) / 32) * 64;
+    const size_t n = (size_t)wgs * 64;
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
-    vnr_launch(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, gg);
+    vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, gg);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hbuf(n);
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -405,8 +463,27 @@ hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s) {
     if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 64)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
-  vnr_launch(panel_chain_kernel, dim3((g.M + 31) / 32), dim3(512), CHAIN_LDS, s, g);
+  vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, g);
   return hipGetLastError();
+}
+
+hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
+  ChainArgs g = g_in;
+  if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
+  int nln = 0;
+  for (int i = 0; i < g.nstages; ++i) {
+    ChainStage& st = g.st[i];
+    if (st.n <= 0 || st.n > 256 || (st.n & 3) || st.nk <= 0 || st.nk > 16 || st.akt0 < 0 || st.akt0 + (st.asw < st.nk ? st.asw : st.nk) > 8 || (st.pe && st.pe_T <= 0) || st.asw <= 0 || (st.asw < st.nk && st.nk - st.asw > 8) || (st.asw < st.nk ? st.asw : st.nk) > 8 || !st.w) return hipErrorInvalidValue;
+    if (st.out && st.out_fmt == 0 && (st.ldo & 3)) return hipErrorInvalidValue;
+    if (st.out && st.out_fmt == 1 && ((st.n & 63) || st.aoi_T <= 0)) return hipErrorInvalidValue;
+    if (st.out && st.out_fmt == 4 && ((st.aoi_D & 63) || st.aoi_T <= 0 || st.aoi_D <= 0 || (st.aoi_c0 & 3) || st.aoi_c0 + st.n > 3 * st.aoi_D)) return hipErrorInvalidValue;
+    if (st.out_fmt != 0 && st.out_fmt != 1 && st.out_fmt != 4) return hipErrorInvalidValue;
+    // LDS slot (float offset from the parameter area) of this stage's gamma | beta: behind the bias table
+    st.lds_ln = (st.gamma && st.acc_mode != 1 && st.acc_mode != 2) ? g.nstages * 256 + 512 * nln++ : -1;
+  }
+  const int prm_bytes = (g.nstages * 256 + nln * 512) * 4;
+  if (g.rows64) return launch_chain_rt<2>(g, ChainLds<2>::PRM_OFF + prm_bytes, s);
+  return launch_chain_rt<1>(g, ChainLds<1>::PRM_OFF + prm_bytes, s);
 }
 
 }  // namespace vnr

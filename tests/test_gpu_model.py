@@ -314,6 +314,27 @@ def test_model_init_actnorm(name):
         model.engine.close()
 
 
+@pytest.mark.parametrize("rows64", [0, 1], ids=["rows32", "rows64"])
+def test_s1_against_fp32_oracle(rows64):
+    """The bench workload itself (B=16, T_text=128, T_mel=800, full lengths) against the fp32 NumPy oracle (seconds at this
+    size), with the chain kernel's 32- and 64-row panels (the latter is what bench.py runs with several batches in flight)."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    b = make_batch(16, 128, 800, ragged=False, seed=1234, temperature=1.0)
+    ref, rali = Oracle(hps, w, np.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+    model = VAENAR(hps, weights=w)
+    try:
+        model.engine.set_option("chain_rows64", rows64)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        err = np.abs(mel.numpy() - ref).max()
+        print(f"S1 rows64={rows64}: max-abs mel err vs fp32 oracle {err:.3e}")
+        assert err < MEL_TOL
+        for k in rali:
+            np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+    finally:
+        model.engine.close()
+
+
 def test_full_size_s1_properties():
     """BASELINE.json's full configuration (B=16, T_text=128, T_mel=800, rf=2) through size-independent properties (the
     float64 oracle takes minutes at this size): utterances are independent, so (i) a sub-batch run alone reproduces its rows

@@ -60,7 +60,8 @@ panel_chain_kernel(const ChainArgs g) {
   constexpr int ROWS = L::ROWS, PANEL_BYTES = L::PANEL_BYTES, P_OFF = L::P_OFF, PRM_OFF = L::PRM_OFF;
   // weight k-tiles kept in flight per wave (register prefetch depth): a k-tile of the 64-row variant carries twice the MFMAs, so
   // half the depth covers the same time (and the accumulators need the registers)
-  constexpr int PF = RT == 2 ? 3 : 4;
+  constexpr int PF = RT == 2 ? 2 : 4;
+  static_assert(PF % 2 == 0, "the activation operand double buffer alternates with the slot index: the depth must be even");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

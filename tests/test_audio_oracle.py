@@ -119,3 +119,16 @@ def test_deemphasis_and_int16():
     w = o.to_int16(np.array([0.0, 0.5, -1.0, 0.25]))
     assert w.dtype == np.int16 and list(w) == [0, 16383, -32767, 8191]
     assert list(o.to_int16(np.array([0.001, -0.002]))) == [3276, -6553]       # the 0.01 floor of audio.py:19
+
+
+def test_oracle_reproduces_the_committed_fixture():
+    """tests/golden/audio_lj.npz (oracle/make_audio_golden.py): the restatement is frozen against its own committed outputs."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "audio_lj.npz"))
+    o = A.AudioOracle(LJHPS.Audio)
+    for b, n in enumerate(z["lengths"]):
+        S = o.linear_from_mel(z["mels"][b, :n].T.astype(np.float64))
+        np.testing.assert_allclose([S.sum(), (S ** 2).sum()], z["S_sum_%d" % b], rtol=1e-12)
+        a = z["init_angles"][b, :n].T.astype(np.float64)
+        for it in (0, 2, 5):
+            np.testing.assert_allclose(o.griffin_lim(S, a, it), z["wav%d_it%d" % (b, it)], atol=1e-5 * np.abs(z["wav%d_it%d" % (b, it)]).max())

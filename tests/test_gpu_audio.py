@@ -110,6 +110,24 @@ def test_reference_call_surface_and_wav_files(eng, tmp_path):
     assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+def test_against_the_committed_fixture(eng):
+    """tests/golden/audio_lj.npz: ragged batch, given phase draw; waveforms after 0 / 2 / 5 iterations and after de-emphasis."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "audio_lj.npz"))
+    au = Audio(LJHPS.Audio, engine=eng)
+    lens = [int(x) for x in z["lengths"]]
+    for it, tol in ((0, 2e-6), (2, 5e-5), (5, 3e-4)):
+        wavs = au.inv_mel_spectrogram_batch(z["mels"], lens, init_angles=z["init_angles"], n_iters=it)
+        for b in range(len(lens)):
+            ref = z["wav%d_it%d" % (b, it)]
+            assert wavs[b].shape == ref.shape
+            assert np.abs(wavs[b] - ref).max() <= tol * np.abs(ref).max(), (it, b, np.abs(wavs[b] - ref).max() / np.abs(ref).max())
+        if it == 5:
+            for b in range(len(lens)):
+                ref = z["wav%d_deemph" % b]
+                assert np.abs(au.inv_preemphasize(wavs[b]) - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
 def test_bad_arguments_fail_loudly(eng):
     S = eng.zeros((1, 8, 513))
     wav = eng.empty((1, 128 * 7))

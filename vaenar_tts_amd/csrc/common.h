@@ -5,6 +5,7 @@
 
 #include <hip/hip_ext.h>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 #include <utility>
 

@@ -152,3 +152,43 @@ def test_checkpoint_round_trip_and_model_mapping(tmp_path):
     with pytest.raises(KeyError):
         ck.load_model_weights(str(tmp_path / "partial"), hps)
     assert "posterior/pos_weight" not in ck.load_model_weights(str(tmp_path / "partial"), hps, include_posterior=False)
+
+
+def test_object_graph_of_saved_model_weights(tmp_path):
+    """save_model_weights writes the _CHECKPOINTABLE_OBJECT_GRAPH entry object-based restore walks: every variable is reachable
+    from node 0 through children whose local names spell its attribute path, and carries its checkpoint key."""
+    from vaenar_tts_amd import tf_checkpoint as ck
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.weights import init_weights
+    hps = tiny_hps()
+    w = init_weights(hps, seed=3, mode="synthetic")
+    prefix = str(tmp_path / "ckpt-7")
+    ck.save_model_weights(prefix, w)
+    got = ck.read_checkpoint(prefix, with_strings=True)
+    nodes = ck.parse_object_graph(got[ck.OBJECT_GRAPH_KEY])
+    assert nodes[0][0] == [(1, "model")] and nodes[0][1] == []
+    for path in w:
+        nid = 0
+        for part in ["model"] + path.split("/"):
+            nxt = [c for c, name in nodes[nid][0] if name == part]
+            assert len(nxt) == 1, (path, part)
+            nid = nxt[0]
+        assert nodes[nid][1] == [("VARIABLE_VALUE", "model/" + path, "model/" + path + ck.SUFFIX)]
+        np.testing.assert_array_equal(got["model/" + path + ck.SUFFIX], w[path])
+    assert sum(len(a) for _, a in nodes) == len(w)                       # exactly one attribute per variable
+    # known answer of the proto encoding for a two-variable tree: node0{child 1 'model'}, node1{child 2 'a', child 4 'b'},
+    # node2{child 3 '0'}, node3{attr}, node4{attr}
+    g = ck.object_graph_proto(["a/0", "b"], root="model")
+    n = ck.parse_object_graph(g)
+    assert [c for c, _ in n] == [[(1, "model")], [(2, "a"), (4, "b")], [(3, "0")], [], []]
+    assert g[:11] == bytes([0x0a, 0x0b, 0x0a, 0x09, 0x08, 0x01, 0x12, 0x05]) + b"mod"
+    # the string tensor's on-disk layout: varint length, masked CRC-32C of the uint32 length, bytes
+    raw = open(prefix + ".data-00000-of-00001", "rb").read()
+    e = ck._parse_entry(ck.read_index(prefix + ".index")[ck.OBJECT_GRAPH_KEY.encode()])
+    blob = raw[e["offset"]:e["offset"] + e["size"]]
+    ln, pos = ck._read_varint(blob, 0)
+    assert ln == len(got[ck.OBJECT_GRAPH_KEY]) and blob[pos + 4:] == got[ck.OBJECT_GRAPH_KEY]
+    assert blob[pos:pos + 4] == struct.pack("<I", ck._mask(ck.crc32c(struct.pack("<I", ln))))
+    # and load_model_weights is unaffected by the extra entry
+    w2 = ck.load_model_weights(prefix, hps)
+    assert set(w2) == set(w)

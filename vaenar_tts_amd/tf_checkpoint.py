@@ -19,9 +19,14 @@ Object-based (TF2 / Keras) checkpoints name a variable by its attribute path fro
 (``optimizer/...`` and ``.../.OPTIMIZER_SLOT/...``), the ``step`` counter and the ``_CHECKPOINTABLE_OBJECT_GRAPH`` string are
 skipped by ``load_model_weights``.
 
-``write_checkpoint`` produces well-formed bundles (readable by ``tf.train.load_checkpoint`` / ``list_variables``); it does
-NOT emit the ``_CHECKPOINTABLE_OBJECT_GRAPH`` proto, so TensorFlow's object-based ``restore`` cannot consume them -- it exists
-for tests and for exporting trained variables to name-based readers.
+``write_checkpoint`` produces well-formed bundles (readable by ``tf.train.load_checkpoint`` / ``list_variables``).
+``save_model_weights`` adds the ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry that object-based ``restore`` walks: a serialized
+``TrackableObjectGraph`` (tensorflow/core/protobuf/trackable_object_graph.proto: ``nodes`` = repeated ``TrackableObject{1:
+children{1: node_id, 2: local_name}, 2: attributes{1: name, 2: full_name, 3: checkpoint_key}}``), node 0 = the Checkpoint
+root, one node per attribute-path prefix (list elements by index, like Keras' list wrappers), a variable node carrying the
+attribute ``VARIABLE_VALUE`` with its checkpoint key -- stored as a DT_STRING scalar in the bundle's string layout (varint64
+lengths, fixed32 masked CRC-32C of the lengths as uint32, then the bytes; the entry CRC runs over lengths-as-uint32, that
+checksum and the bytes).  Optimizer slot variables are not written (``expect_partial()`` in the reference, inference.py:123).
 
 PARITY UNPINNED against bundles written by real TensorFlow (none exist in this environment; the published checkpoints of
 the reference are behind a Google-Drive link, README.md:4): the format statements above are the published ones, pinned by
@@ -122,8 +127,9 @@ def list_variables(prefix):
     return out
 
 
-def read_checkpoint(prefix, verify=True, keys=None):
-    """{key: ndarray} of every numeric tensor of the bundle (string tensors and sliced entries are skipped)."""
+def read_checkpoint(prefix, verify=True, keys=None, with_strings=False):
+    """{key: ndarray} of every numeric tensor of the bundle (sliced entries are skipped; ``with_strings``: scalar string tensors
+    such as the object graph are returned as bytes)."""
     index = read_index(prefix + ".index", verify)
     header = dict(num_shards=1, endianness=0)
     for num, _, val in _parse(index.get(b"", b"")):
@@ -139,6 +145,20 @@ def read_checkpoint(prefix, verify=True, keys=None):
         if k == b"" or (keys is not None and k.decode() not in keys):
             continue
         e = _parse_entry(v)
+        if e["dtype"] == DT_STRING and not e["shape"] and not e["sliced"] and with_strings:
+            sid = e["shard_id"]
+            if sid not in shards:
+                shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"]), "rb")
+            shards[sid].seek(e["offset"])
+            raw = shards[sid].read(e["size"])
+            n, pos = _read_varint(raw, 0)
+            cksum, val = raw[pos:pos + 4], raw[pos + 4:pos + 4 + n]
+            crc = crc32c(struct.pack("<I", n))
+            if verify and (cksum != struct.pack("<I", _mask(crc)) or len(val) != n or
+                           (e["crc32c"] is not None and e["crc32c"] != _mask(crc32c(val, crc32c(cksum, crc))))):
+                raise IOError("checkpoint data: checksum mismatch for string tensor %s" % k.decode())
+            out[k.decode()] = val
+            continue
         if e["dtype"] not in _NP_OF_DT or e["sliced"]:
             continue
         sid = e["shard_id"]
@@ -231,6 +251,20 @@ def write_checkpoint(prefix, tensors):
     off = 0
     with open(prefix + ".data-00000-of-00001", "wb") as f:
         for key in sorted(tensors, key=lambda s: s.encode()):
+            if isinstance(tensors[key], (bytes, bytearray)):       # DT_STRING scalar: [varint64 length][masked crc of the length][bytes]
+                val = bytes(tensors[key])
+                crc = crc32c(struct.pack("<I", len(val)))           # lengths enter the checksum as uint32, not as varints
+                cksum = struct.pack("<I", _mask(crc))
+                raw = _varint(len(val)) + cksum + val
+                crc = crc32c(val, crc32c(cksum, crc))
+                f.write(raw)
+                entry = _field(1, 0, _varint(DT_STRING)) + _ld(2, b"")
+                if off:
+                    entry += _field(4, 0, _varint(off))
+                entry += _field(5, 0, _varint(len(raw))) + _field(6, 5, struct.pack("<I", _mask(crc)))
+                items.append((key.encode(), entry))
+                off += len(raw)
+                continue
             a = np.asarray(tensors[key], order="C")          # (ascontiguousarray would promote 0-d to 1-d)
             raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
             f.write(raw)
@@ -244,6 +278,50 @@ def write_checkpoint(prefix, tensors):
     _write_table(prefix + ".index", items)
 
 
+OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+
+
+def object_graph_proto(paths, root="model"):
+    """Serialized TrackableObjectGraph for variables at the attribute paths ``root/<path>`` (see the module docstring)."""
+    nodes = [{"children": [], "attr": None}]                      # node 0: the tf.train.Checkpoint object
+    index = {(): 0}
+    for p in sorted(paths):
+        parts = tuple([root] + p.split("/"))
+        for d in range(1, len(parts) + 1):
+            if parts[:d] not in index:
+                index[parts[:d]] = len(nodes)
+                nodes.append({"children": [], "attr": None})
+                nodes[index[parts[:d - 1]]]["children"].append((index[parts[:d]], parts[d - 1]))
+        nodes[index[parts]]["attr"] = "/".join(parts) + SUFFIX
+    out = b""
+    for n in nodes:
+        body = b"".join(_ld(1, _field(1, 0, _varint(cid)) + _ld(2, name.encode())) for cid, name in n["children"])
+        if n["attr"]:
+            key = n["attr"]
+            body += _ld(2, _ld(1, b"VARIABLE_VALUE") + _ld(2, key[:-len(SUFFIX)].encode()) + _ld(3, key.encode()))
+        out += _ld(1, body)
+    return out
+
+
+def parse_object_graph(buf):
+    """[(children [(node_id, local_name)], attributes [(name, full_name, checkpoint_key)])] of a TrackableObjectGraph."""
+    nodes = []
+    for num, _, node in _parse(buf):
+        if num != 1:
+            continue
+        children, attrs = [], []
+        for n2, _, val in _parse(node):
+            f = {k: v for k, _, v in _parse(val)}
+            if n2 == 1:
+                children.append((int(f.get(1, 0)), f.get(2, b"").decode()))
+            elif n2 == 2:
+                attrs.append((f.get(1, b"").decode(), f.get(2, b"").decode(), f.get(3, b"").decode()))
+        nodes.append((children, attrs))
+    return nodes
+
+
 def save_model_weights(prefix, weights, root="model"):
-    """{weights.py path: ndarray} -> bundle with the object-based key names (no object-graph proto: see module docstring)."""
-    write_checkpoint(prefix, {"%s/%s%s" % (root, p, SUFFIX): np.asarray(a, np.float32) for p, a in weights.items()})
+    """{weights.py path: ndarray} -> object-based checkpoint: the variables under their attribute-path keys plus the object graph."""
+    tensors = {"%s/%s%s" % (root, p, SUFFIX): np.asarray(a, np.float32) for p, a in weights.items()}
+    tensors[OBJECT_GRAPH_KEY] = object_graph_proto(weights.keys(), root)          # bytes -> DT_STRING scalar
+    write_checkpoint(prefix, tensors)

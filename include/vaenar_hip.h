@@ -232,7 +232,14 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * product as hi*hi + lo*hi + hi*lo on the fp16 matrix pipe (fp32 accumulate; 22 significant bits per operand,
  * measured mel error vs the float64 oracle ~3e-6, same as exact fp32 MFMA); 0 = exact fp32 MFMA everywhere.
  * "split_encoder" (default 1): the text encoder (which feeds the integer frame-count predictor) uses the split path as
- * well; 0 keeps that chain on exact fp32 MFMA.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel. */
+ * well; 0 keeps that chain on exact fp32 MFMA.  "op_dense_split" (default 0): vnr_op_dense uses the split kernel.
+ * "chain" (default 1): fused row-panel chains of the attention blocks.  "attn_presplit" / "attn_presplit_self" (default 1):
+ * the producers of Q, K, V write fp16 hi/lo operand-major image tiles and the attention core loads them directly
+ * (cross-attention with T_text <= 128 / every self-attention); 0 = fp32 Q, K, V and the in-kernel split.
+ * "op_attn_presplit" (default 0): vnr_op_attention converts its fp32 operands to images and takes that kernel (tests).
+ * "late_dec_kv" (default 1): vnr_inference computes the decoder's cross K|V right before the decoder.
+ * "chain_rows64" (default 0): 64-row panels in the chain kernel -- half the workgroups, half the weight stream per row; slower
+ * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams). */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,

@@ -736,7 +736,8 @@ int refresh_bn_affine(vnr_handle h) {
 int run_kv(vnr_handle h, const float* text_embd, int B, int Tt, int mem, const float* panel, int n, float* out, int D) {
   GemmArgs g;
   g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = B * Tt; g.N = n;
-  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g) && !getenv("VNR_GEMM_V1")) {
+  static const bool gemm_v1 = getenv("VNR_GEMM_V1") != nullptr;     // (the operand-image epilogue exists in gemm2 only)
+  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g) && !gemm_v1) {
     const int nblk = n / (2 * D), TT = (Tt + 31) / 32;
     const size_t blk_bytes = (size_t)B * (D / 64) * TT * kAoiTile;
     WS(img, 2 * nblk * blk_bytes / 4);

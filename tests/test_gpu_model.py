@@ -335,6 +335,32 @@ def test_s1_against_fp32_oracle(rows64):
         model.engine.close()
 
 
+def test_handles_in_flight_are_independent():
+    """bench.py keeps several batches in flight on one GPU, one engine handle (= one HIP stream, workspace, weight copy) each,
+    issued round-robin from one host thread without synchronising: every handle must return exactly what it returns alone."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    batches = [make_batch(4, 60 + 9 * i, 200 + 40 * i, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                          ragged=True, seed=50 + i, temperature=1.0, text_step=5, mel_step=13) for i in range(3)]
+    models = [VAENAR(hps, weights=w) for _ in range(3)]
+    try:
+        for m in models:
+            m.engine.set_option("chain_rows64", 1)
+        alone = []
+        for m, b in zip(models, batches):
+            mel, _ = m.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+            alone.append(mel.numpy())                      # .numpy() synchronises: strictly one after another
+        outs = []
+        for rep in range(4):                               # 12 asynchronous calls dealt to the three handles
+            for m, b in zip(models, batches):
+                outs.append(m.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])[0])
+        for i, o in enumerate(outs):
+            np.testing.assert_array_equal(o.numpy(), alone[i % 3])
+    finally:
+        for m in models:
+            m.engine.close()
+
+
 def test_full_size_s1_properties():
     """BASELINE.json's full configuration (B=16, T_text=128, T_mel=800, rf=2) through size-independent properties (the
     float64 oracle takes minutes at this size): utterances are independent, so (i) a sub-batch run alone reproduces its rows

@@ -2,6 +2,7 @@
 // flow coupling, length predictor, masked reductions and weight preparation.
 // Wavefront = 64 lanes everywhere; row reductions use wave shuffles.
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace vnr {
@@ -498,16 +499,66 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
     else atomicAdd(&out[c], t);
   }
 }
-hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
+// Same sums with 16-byte loads: a lane owns 4 consecutive columns (C, ld multiples of 4, x 16-byte aligned), a wave covers 256
+// columns of a row, the block's 4 waves take rows m, m+1, m+2, m+3 of a stride-(4 gridDim.y) walk with two loads in flight.
+__global__ void col_sum4_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout) {
+  const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+  const int rg = threadIdx.x >> 6;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  float mx = 0.f;
+  if (c < C) {
+    double mu[4] = {0.0, 0.0, 0.0, 0.0};
+    if (mean) { mu[0] = mean[c]; mu[1] = mean[c + 1]; mu[2] = mean[c + 2]; mu[3] = mean[c + 3]; }
+    const int step = gridDim.y * 4;
+    int m = blockIdx.y * 4 + rg;
+    auto add = [&](const float4& v) {
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mx = fmaxf(mx, fabsf(xv[e]));
+        const double d = (double)xv[e] - mu[e];
+        acc[e] += mean ? d * d : (double)xv[e];
+      }
+    };
+    for (; m + step < M; m += 2 * step) {
+      const float4 v0 = *reinterpret_cast<const float4*>(x + (size_t)m * ld + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(x + (size_t)(m + step) * ld + c);
+      add(v0); add(v1);
+    }
+    for (; m < M; m += step) add(*reinterpret_cast<const float4*>(x + (size_t)m * ld + c));
+  }
+  __shared__ double part[4][256];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[rg][(threadIdx.x & 63) * 4 + e] = acc[e];
+  if (amax) {
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+  }
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (fout) atomicAdd(&fout[cc], (float)t);
+    else atomicAdd(&out[cc], t);
+  }
+}
+static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, hipStream_t s) {
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
-  vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, (float*)nullptr);
+  static const bool v1 = getenv("VNR_COLSUM_V1") != nullptr;           // A/B switch
+  if (!v1 && !(C & 3) && !(ld & 3) && !((size_t)x & 15)) {
+    int rb4 = (M + 31) / 32; if (rb4 > 256) rb4 = 256; if (rb4 < 1) rb4 = 1;
+    vnr_launch(col_sum4_kernel, dim3((C + 255) / 256, rb4), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
+  } else {
+    vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
+  }
   return hipGetLastError();
+}
+hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s) {
+  return launch_col_sum_any(x, M, C, ld, mean, out, amax, nullptr, s);
 }
 // grad[c] += sum_m x[m][c]  (bias gradients), optional abs-max by-product
 hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s) {
-  int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
-  vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, (const double*)nullptr, (double*)nullptr, amax, grad);
-  return hipGetLastError();
+  return launch_col_sum_any(x, M, C, ld, nullptr, nullptr, amax, grad, s);
 }
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
   return launch_col_sum_amax(x, M, C, ld, mean, out, nullptr, s);

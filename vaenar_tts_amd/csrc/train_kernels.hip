@@ -190,6 +190,18 @@ __global__ void absmax2d_kernel(const float* x, int ld, int rows, int cols, unsi
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s) {
   static const bool skip = getenv("VNR_SKIP_ABSMAX") != nullptr;      // measurement knob (gradients of tiny magnitude lose accuracy)
   if (skip) return hipSuccess;
+  if (ld == cols && rows > 1) {                          // contiguous block: one long row (every thread busy whatever `cols` is)
+    const size_t n = (size_t)rows * cols;
+    const int chunk = 1 << 16;                           // columns per pseudo-row
+    if (!(n & 3) && n >= (size_t)chunk && n / chunk < (1u << 30)) {
+      const int r2 = (int)(n / chunk);
+      int blocks = r2 < 1024 ? r2 : 1024;
+      vnr_launch(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, chunk, r2, chunk, out);
+      const size_t rest = n - (size_t)r2 * chunk;
+      if (rest) vnr_launch(absmax2d_kernel, dim3(1), dim3(256), 0, s, x + (size_t)r2 * chunk, (int)rest, 1, (int)rest, out);
+      return hipGetLastError();
+    }
+  }
   int blocks = rows < 512 ? rows : 512; if (blocks < 1) blocks = 1;
   vnr_launch(absmax2d_kernel, dim3(blocks), dim3(256), 0, s, x, ld, rows, cols, out);
   return hipGetLastError();

@@ -113,5 +113,54 @@ def inference_test():
             time_consumed, durations, time_consumed / max(durations, 1e-9)))
 
 
+def synthesize_from_text(argv):
+    """Counterpart of reference inference.py:14-83: a text file (one sentence per line) -> character ids (english cleaners /
+    pinyin syllables) -> test_step -> Griffin-Lim -> ``test-{i}-{step}.wav`` (alignment plots are not drawn)."""
+    from vaenar_tts_amd import texts as vtexts
+    from vaenar_tts_amd.audio import TestUtils
+    parser = argparse.ArgumentParser('Synthesis parameters parser')
+    parser.add_argument('--dataset', type=str, choices=['ljspeech', 'databaker'], default='ljspeech')
+    parser.add_argument('--text', type=str, required=True, help='text file with one sentence per line (databaker: TONE3 pinyin syllables)')
+    parser.add_argument('--ckpt_path', type=str, default='synthetic-0')
+    parser.add_argument('--test_dir', type=str, default='gpurun_out/test_dir')
+    parser.add_argument('--temperature', type=float, default=0.)
+    parser.add_argument('--seed', type=int, default=1234)
+    args = parser.parse_args(argv)
+    ckpt_step = args.ckpt_path.split('-')[-1]
+    os.makedirs(args.test_dir, exist_ok=True)
+    hparams = {'ljspeech': LJHPS, 'databaker': DataBakerHPS}[args.dataset]
+    rf = hparams.Common.final_reduction_factor
+    to_array = vtexts.text_to_array if args.dataset == 'ljspeech' else vtexts.pinyin_to_array
+    with open(args.text, 'r') as f:
+        arrays = [to_array(line.strip(), hparams) for line in f if line.strip()]
+    text_batch, text_lens = vtexts.pad_batch(arrays)                              # inference.py:43-53
+    model = VAENAR(hparams, device=0)
+    if args.ckpt_path.startswith('synthetic'):
+        model.load_weights(init_weights(hparams, seed=args.seed, mode='synthetic', include_posterior=False))
+    else:
+        model.load_weights(args.ckpt_path)
+    tester = TestUtils(hparams, args.test_dir, engine=model.engine)
+    text_pos_step = np.float32(model.mel_text_len_ratio) / np.float32(rf)         # inference.py:58-72
+    text_embd = model.text_encoder(text_batch, text_lens, pos_step=text_pos_step, training=False)
+    predicted_m_l = model.length_predictor(text_embd, text_lens, training=False).numpy().astype(np.int32)
+    reduced_pred_ml = (predicted_m_l + 80 + rf - 1) // rf
+    eps = None
+    if args.temperature:
+        rng = np.random.Generator(np.random.PCG64(args.seed))
+        eps = (np.float32(args.temperature) * rng.standard_normal(
+            (len(text_lens), int(reduced_pred_ml.max()), hparams.Common.latent_dim))).astype(np.float32)
+    prior_latents, _ = model.prior.sample(reduced_pred_ml, text_embd, text_lens, training=False, temperature=args.temperature,
+                                          eps=eps, return_logprobs=False)
+    _, prediction, _ = model.decoder(prior_latents, text_embd, reduced_pred_ml, text_lens, training=False)
+    pred_lens = predicted_m_l + 80
+    outs = prediction.numpy()
+    ids = [str(i) for i in range(len(text_lens))]
+    tester.synthesize_and_save_wavs(ckpt_step, outs, np.minimum(pred_lens, outs.shape[1]), ids, prefix='test', seed=args.seed)
+
+
 if __name__ == '__main__':
-    inference_test()
+    import sys
+    if '--text' in sys.argv:
+        synthesize_from_text(sys.argv[1:])
+    else:
+        inference_test()

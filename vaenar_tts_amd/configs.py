@@ -36,8 +36,9 @@ def _audio(sample_rate, frame_length_sample, frame_shift_sample, min_level_db):
                power=1.5, center=True)
 
 
-def _base(vocab_size, mel_text_len_ratio, audio):
+def _base(vocab_size, mel_text_len_ratio, audio, characters):
     return _NS(
+        Texts=_NS(pad='_', bos='^', eos='~', characters=characters),              # hparams.py:260-264 / :378-382
         Train=_NS(
             random_seed=123456, epochs=2000, train_batch_size=32, test_batch_size=8,
             num_samples=1, length_weight=1.0, kl_weight=1.0, kl_weight_init=1e-5,
@@ -69,9 +70,11 @@ def _base(vocab_size, mel_text_len_ratio, audio):
 
 
 # /root/reference/configs/hparams.py:233-348
-LJHPS = _base(vocab_size=43, mel_text_len_ratio=5.59, audio=_audio(22050, 1024, 256, -100.0))
+LJHPS = _base(vocab_size=43, mel_text_len_ratio=5.59, audio=_audio(22050, 1024, 256, -100.0),
+              characters='_^~abcdefghijklmnopqrstuvwxyz!\'\"(),-.:;? []')
 # /root/reference/configs/hparams.py:351-474 (differs in vocab 39 :411, ratio 4.21 :407)
-DataBakerHPS = _base(vocab_size=39, mel_text_len_ratio=4.21, audio=_audio(16000, 800, 200, -115.0))
+DataBakerHPS = _base(vocab_size=39, mel_text_len_ratio=4.21, audio=_audio(16000, 800, 200, -115.0),
+                    characters='_^~abcdefghijklmnopqrstuvwxyz12345,./- ')
 
 
 def tiny_hps():

@@ -132,3 +132,24 @@ def test_oracle_reproduces_the_committed_fixture():
         a = z["init_angles"][b, :n].T.astype(np.float64)
         for it in (0, 2, 5):
             np.testing.assert_allclose(o.griffin_lim(S, a, it), z["wav%d_it%d" % (b, it)], atol=1e-5 * np.abs(z["wav%d_it%d" % (b, it)]).max())
+
+
+@pytest.mark.parametrize("n_fft,hop,win", [(2048, 256, 1024), (2048, 200, 800)])
+def test_stft_istft_against_torch(n_fft, hop, win):
+    """torch.stft / torch.istft implement librosa's conventions (centred zero-padded window, reflect padding, window-envelope
+    normalisation) independently of this repository: a third implementation next to scipy's."""
+    import torch
+    y = rng(hop + win).standard_normal(hop * 41)
+    w = torch.hann_window(win, periodic=True, dtype=torch.float64)
+    Z = torch.stft(torch.from_numpy(y), n_fft, hop_length=hop, win_length=win, window=w, center=True, pad_mode="reflect",
+                   return_complex=True)
+    D = A.stft(y, n_fft, hop, win)
+    np.testing.assert_allclose(D, Z.numpy(), atol=1e-10)
+    # inverse of an arbitrary (inconsistent) spectrogram: the quantity Griffin-Lim needs
+    r = rng(7)
+    X = np.abs(D) * np.exp(2j * np.pi * r.random(D.shape))
+    X[0] = X[0].real; X[-1] = X[-1].real                      # (both drop the imaginary part of DC / Nyquist)
+    ref = torch.istft(torch.from_numpy(X), n_fft, hop_length=hop, win_length=win, window=w, center=True).numpy()
+    got = A.istft(X, hop, win)
+    assert got.shape == ref.shape == (hop * (D.shape[1] - 1),)
+    np.testing.assert_allclose(got, ref, atol=1e-10)

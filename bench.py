@@ -78,6 +78,7 @@ def main():
             # 64-row panels in the chain kernel: half the workgroups, half the weight stream per row.  One batch alone is 10 %
             # slower with them (2.92 vs 2.63 ms) but the CUs they leave free take the other batches' kernels: 7.5 vs 6.6 M frames/s
             m.engine.set_option("chain_rows64", 1)
+            m.engine.set_option("gemm_wide_tiles", 1)       # same idea for the GEMM kernel: 64x128 tiles (+4 % with 3 streams)
         for kv in args.opt:                              # A/B switches, e.g. --opt attn_presplit_self=0
             name, val = kv.split("=")
             m.engine.set_option(name, int(val))

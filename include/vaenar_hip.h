@@ -239,7 +239,8 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * "op_attn_presplit" (default 0): vnr_op_attention converts its fp32 operands to images and takes that kernel (tests).
  * "late_dec_kv" (default 1): vnr_inference computes the decoder's cross K|V right before the decoder.
  * "chain_rows64" (default 0): 64-row panels in the chain kernel -- half the workgroups, half the weight stream per row; slower
- * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams). */
+ * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams).
+ * "gemm_wide_tiles" (default 0): the same trade for the tiled GEMM kernel (64x128 workgroup tiles wherever N >= 128). */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,

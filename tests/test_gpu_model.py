@@ -120,8 +120,9 @@ def test_inference_matches_oracle(setup, fused, temperature):
         np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
 
 
-@pytest.mark.parametrize("opts", [{}, {"attn_presplit": 0}, {"attn_presplit_self": 0}, {"late_dec_kv": 0}, {"chain": 0}],
-                         ids=["default", "cross-fp32", "self-fp32", "kv-early", "no-chain"])
+@pytest.mark.parametrize("opts", [{}, {"attn_presplit": 0}, {"attn_presplit_self": 0}, {"late_dec_kv": 0}, {"chain": 0},
+                                  {"chain_rows64": 1, "gemm_wide_tiles": 1}],
+                         ids=["default", "cross-fp32", "self-fp32", "kv-early", "no-chain", "throughput-tiles"])
 def test_inference_long_text_and_ab_switches(opts):
     """T_text = 150 > 128: the cross-attention leaves the operand-image kernel (attention3, Tk <= 128) for the fp32-operand
     kernels (attention2, and the first-generation kernel for the alignments); T_z = 45 is not a multiple of 16, so the V stage
@@ -325,6 +326,7 @@ def test_s1_against_fp32_oracle(rows64):
     model = VAENAR(hps, weights=w)
     try:
         model.engine.set_option("chain_rows64", rows64)
+        model.engine.set_option("gemm_wide_tiles", rows64)
         mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
         err = np.abs(mel.numpy() - ref).max()
         print(f"S1 rows64={rows64}: max-abs mel err vs fp32 oracle {err:.3e}")

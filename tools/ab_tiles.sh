@@ -1,4 +1,6 @@
-for t in "" "VNR_SPLIT_TILE=1" "VNR_SPLIT_TILE=0" "VNR_SPLIT_TILE=1 VNR_SPLIT_STAGES=4" "VNR_SPLIT_TILE=0 VNR_SPLIT_STAGES=4"; do
-env $t python bench.py --no-cpu-baseline --no-train --streams 3 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$t', round(d['ms_per_step'],4), round(d['value']), {k:round(v,4) for k,v in d['end_to_end']['kernel_ms_per_step'].items()})"
-done
+python tools/parity_s1.py 2>&1 | tail -5
+for i in 1 2; do
+for t in "--opt gemm_wide_tiles=0" ""; do
+python bench.py --no-cpu-baseline --no-train --streams 3 --steps 40 $t 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$t', round(d['ms_per_step'],4), round(d['value']))"
+done; done

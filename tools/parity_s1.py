@@ -13,7 +13,7 @@ from vaenar_tts_amd.weights import init_weights
 w = init_weights(LJHPS, seed=1234, mode="synthetic", include_posterior=False)
 b = make_batch(16, 128, 800, ragged=False, seed=1234, temperature=1.0)
 ref, _ = Oracle(LJHPS, w, np.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
-for opts in ({}, {"chain_rows64": 1}, {"chain_rows64": 1, "late_dec_kv": 0}):
+for opts in ({}, {"chain_rows64": 1}, {"chain_rows64": 1, "gemm_wide_tiles": 1}, {"chain_rows64": 1, "late_dec_kv": 0}):
     m = VAENAR(LJHPS, device=0, weights=w)
     for k, v in opts.items():
         m.engine.set_option(k, v)
@@ -23,6 +23,7 @@ for opts in ({}, {"chain_rows64": 1}, {"chain_rows64": 1, "late_dec_kv": 0}):
 ms = [VAENAR(LJHPS, device=0, weights=w) for _ in range(3)]
 for m in ms:
     m.engine.set_option("chain_rows64", 1)
+    m.engine.set_option("gemm_wide_tiles", 1)
 outs = []
 for i in range(9):
     outs.append(ms[i % 3].inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])[0])

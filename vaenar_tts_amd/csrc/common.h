@@ -136,6 +136,7 @@ struct GemmArgs {
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]
   AoiDesc aoi;                      // mode != 0: C is written as an attention operand image (attention3.hip) instead of fp32
+  int wide_tiles = 0;               // split path: prefer 64x128 workgroup tiles (fewer, denser workgroups; engine option "gemm_wide_tiles")
 };
 
 struct AttnArgs {

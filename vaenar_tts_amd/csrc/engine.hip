@@ -119,6 +119,7 @@ struct vnr_context {
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
@@ -221,6 +222,7 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
       }
     }
   }
+  g.wide_tiles = h->gemm_wide_tiles ? 1 : 0;
   ProfScope ps(h, CLS_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e) +
@@ -1833,6 +1835,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_fp16")) { h->split_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain")) { h->chain_enabled = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit")) { h->aoi_enabled = value != 0; return VNR_OK; }
+  if (!strcmp(name, "gemm_wide_tiles")) { h->gemm_wide_tiles = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_rows64")) { h->chain_rows64 = value != 0; return VNR_OK; }
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }

@@ -656,8 +656,9 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     static const int sstages = getenv("VNR_SPLIT_STAGES") ? atoi(getenv("VNR_SPLIT_STAGES")) : -1;   // measurement knob
     int t = stile, ns = sstages;
     // 64x64 tiles (3 workgroups per CU) are fastest or tied on every S1 shape except the long-K PostNet convolutions
-    // (M = 12800, K = 5*256): there the 64x128 tile halves the activation re-reads (53 -> 40 us per layer, tools/sweep_split_tiles.sh)
-    if (t < 0) t = (g.taps > 0 && g.M >= 8192 && g.N >= 128) ? 1 : 2;
+    // (M = 12800, K = 5*256): there the 64x128 tile halves the activation re-reads (53 -> 40 us per layer, tools/sweep_split_tiles.sh).
+    // With several batches in flight (wide_tiles) the 64x128 tile wins everywhere: +4 % aggregate throughput (tools/ab_tiles.sh)
+    if (t < 0) t = ((g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128)) ? 1 : 2;
     if (ns < 0) ns = 3;
     if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, true>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, true>(g, s) : launch2<128, 128, 2, 2, 3, false, true>(g, s);
     if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, true>(g, s) : launch2<64, 128, 2, 2, 3, false, true>(g, s);

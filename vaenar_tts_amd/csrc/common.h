@@ -22,8 +22,8 @@ inline thread_local ProfSlot g_prof_slot;
 template <typename... KArgs, typename Tuple, size_t... I>
 inline void vnr_launch_ext(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, Tuple& t, std::index_sequence<I...>) {
   void* ptrs[] = {static_cast<void*>(&std::get<I>(t))..., nullptr};
-  g_prof_slot.used = true;
-  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s, g_prof_slot.e0, g_prof_slot.e1, 0);
+  // a failed launch leaves its error for the caller's hipGetLastError(), like the plain launch
+  g_prof_slot.used = hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s, g_prof_slot.e0, g_prof_slot.e1, 0) == hipSuccess;
 }
 template <typename... KArgs, typename... Args>
 inline void vnr_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, Args&&... args) {

@@ -150,6 +150,28 @@ def test_inference_long_text_and_ab_switches(opts):
         model.engine.close()
 
 
+@pytest.mark.parametrize("B,Tt,Tm,rows64", [
+    (1, 32, 64, 0), (2, 33, 62, 1), (3, 127, 66, 0), (2, 128, 128, 1), (2, 129, 130, 0), (5, 5, 32, 1), (1, 64, 96, 1), (4, 31, 34, 0),
+])
+def test_tile_boundaries_of_the_operand_images(B, Tt, Tm, rows64):
+    """Lengths that sit on, just below and just above the 32-row image tiles, the 16-row half tiles of the un-transposed V stage
+    and the Tk <= 128 limit of the cross-attention image kernel; ragged and full; both chain panel heights."""
+    hps, model, oracle = _setup("tiny")
+    try:
+        model.engine.set_option("chain_rows64", rows64)
+        model.engine.set_option("gemm_wide_tiles", rows64)
+        for ragged in (False, True):
+            b = make_batch(B, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                           ragged=ragged, temperature=1.0, text_step=max(1, Tt // 7), mel_step=max(2, Tm // 9), seed=Tt * 1000 + Tm)
+            mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+            rmel, rali = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+            assert np.abs(mel.numpy() - rmel).max() < MEL_TOL, (B, Tt, Tm, ragged)
+            for k in rali:
+                np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+    finally:
+        model.engine.close()
+
+
 def test_test_step_frame_counts(setup):
     """inference.py:128-143: length predictor -> int32 trunc -> +80 -> ceil(/2) -> prior -> decoder."""
     name, hps, model, oracle = setup

@@ -18,7 +18,8 @@
 //   S^T = K.Q^T (lane = query: softmax statistics are in-lane + one cross-half shuffle, P is already the A operand of P.V);
 //   the four waves exchange (row max, row sum) once through LDS: p = 2^(t - m_w) locally, then one factor 2^(m_w - M) / L;
 //   alignments leave as 128-byte row pieces after a wave-private 32x32 LDS transpose (16-byte lanes, XOR-swizzled chunks);
-//   the four partial O = P.V tiles are summed through LDS, each wave finishing 8 of the 32 accumulator registers.
+//   the partial O^T = V^T.P^T tiles (a lane owns a query; computed from the unnormalised p BEFORE the statistics barrier, scaled
+//   afterwards) are summed through LDS as [query][64 d] rows, each wave storing 8 rows as 256-byte pieces.
 // Logits are kept in the log2 domain (scale 1/8 . log2(e) / temperature folded into one multiply, exp = v_exp_f32): one
 // rounding of t = s.log2(e) differs from the reference's exp(s - max) by <= 2^-24 . |t| relative -- below 3e-6 for |s| < 40.
 #include "common.h"
@@ -132,46 +133,10 @@ attn3_kernel(const Attn3Args a, int nqt) {
   for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_w); st[r] = p; ls += p; }
   ls += __shfl_xor(ls, 32, 64);
   if (half == 0) { stats[wave * 64 + l31] = m_w; stats[wave * 64 + 32 + l31] = ls; }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  {
-    float mw[4], lw[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
-    const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
-    float L = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) L += lw[w] * __builtin_amdgcn_exp2f(mw[w] - M);
-    const float f = __builtin_amdgcn_exp2f(m_w - M) * (1.0f / L);  // softmax, attention.py:242 (one division per row)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] *= f;
-  }
 
-  float* xw = reinterpret_cast<float*>(smem + wave * kXchg);       // this wave's exchange space
-  if (ALI && active) {
-    // alignment rows: 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 p4 = {st[4 * j], st[4 * j + 1], st[4 * j + 2], st[4 * j + 3]};
-      *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int rr = 8 * x + (lane >> 3), kc = lane & 7;
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
-      const int qrow = q0 + rr, key = kb0 + 4 * kc;
-      if (qrow < a.Tq) {
-        float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
-        if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
-      }
-    }
-  }
-
-  // ---- O partial = P.V over this wave's 32 keys ----------------------------------------------------------------------------
+  // ---- O^T partial = V^T.P^T over this wave's 32 keys, from the UNNORMALISED p (relative to this wave's maximum): issued before
+  //      the statistics barrier so that the exchange latency hides under the MFMAs.  Transposed accumulation (as in
+  //      attn3g_kernel): a lane owns one query, so the factor 2^(m_w - M) / L is an in-lane product afterwards.
   f32x16 O[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -192,33 +157,67 @@ attn3_kernel(const Attn3Args a, int nqt) {
       for (int e = 0; e < 8; ++e) pv[e] = st[8 * tp + e];
       h8 phi, plo;
       split8x(pv, phi, plo);
-      O[0] = mfma3x(phi, plo, vhi[tp][0], vlo[tp][0], O[0]);
-      O[1] = mfma3x(phi, plo, vhi[tp][1], vlo[tp][1], O[1]);
+      O[0] = mfma3x(vhi[tp][0], vlo[tp][0], phi, plo, O[0]);
+      O[1] = mfma3x(vhi[tp][1], vlo[tp][1], phi, plo, O[1]);
     }
   }
-  // ---- sum the four partial tiles: [wave][j = 4 nb + (r>>2)][lane][4] ------------------------------------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float f;
+  {
+    float mw[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
+    const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) L += lw[w] * __builtin_amdgcn_exp2f(mw[w] - M);
+    f = __builtin_amdgcn_exp2f(m_w - M) * (1.0f / L);              // softmax, attention.py:242 (one division per row)
+  }
+
+  char* xb = smem + wave * kXchg;                                  // this wave's exchange space
+  if (ALI && active) {
+    // alignment rows: normalise, 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
+    float* xw = reinterpret_cast<float*>(xb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 p4 = {st[4 * j] * f, st[4 * j + 1] * f, st[4 * j + 2] * f, st[4 * j + 3] * f};
+      *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int rr = 8 * x + (lane >> 3), kc = lane & 7;
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
+      const int qrow = q0 + rr, key = kb0 + 4 * kc;
+      if (qrow < a.Tq) {
+        float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
+        if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
+      }
+    }
+  }
+  // ---- sum the four partial tiles: rows [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row], already scaled -----
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const f32x4 o4 = {O[nb][4 * jj], O[nb][4 * jj + 1], O[nb][4 * jj + 2], O[nb][4 * jj + 3]};
-      *reinterpret_cast<f32x4*>(xw + (((nb * 4 + jj) * 64 + lane) << 2)) = o4;
+      const f32x4 o4 = {O[nb][4 * jj] * f, O[nb][4 * jj + 1] * f, O[nb][4 * jj + 2] * f, O[nb][4 * jj + 3] * f};
+      *reinterpret_cast<f32x4*>(xb + l31 * 256 + (((nb * 8 + 2 * jj + half) ^ (l31 & 15)) << 4)) = o4;
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int jx = 2 * wave + u, nb = jx >> 2, rb = 4 * (jx & 3);
+    const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + ((jx * 64 + lane) << 4));
-    float* ob = a.ctx + (size_t)b * a.o_bs + hd * 64 + nb * 32 + l31;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = q0 + frow3(rb + e, half);
-      if (row < a.Tq) __builtin_nontemporal_store(acc[e], ob + (size_t)row * a.ldo);
-    }
+    for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + rr * 256 + ((ch ^ (rr & 15)) << 4));
+    const int row = q0 + rr;
+    if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
   }
 }
 

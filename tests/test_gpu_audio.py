@@ -55,6 +55,25 @@ def test_first_istft_and_few_iterations(eng, hps, T):
         assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (iters, np.abs(got - ref).max() / np.abs(ref).max())
 
 
+def test_eight_fold_overlap(eng):
+    """hop = win / 8: the general gather (up to 8 overlapping frames per sample) instead of the 4-frame one of the two reference
+    configurations."""
+    import copy
+    hps = copy.deepcopy(LJHPS.Audio)
+    hps.frame_shift_sample = 128
+    au = Audio(hps, engine=eng)
+    o = A.AudioOracle(hps)
+    r = rng(21)
+    T = 45
+    S = o.linear_from_mel(r.uniform(0.0, 1.0, (80, T)))
+    ang = 2 * np.pi * r.random((1025, T))
+    ref = o.griffin_lim(S, ang, 2)
+    d_S = eng.to_device(np.ascontiguousarray(S.T)[None], np.float32)
+    got = au._griffin_lim_batch(d_S, None, np.ascontiguousarray(ang.T)[None], n_iters=2).numpy()[0]
+    assert got.shape == ref.shape == (128 * (T - 1),)
+    assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max()
+
+
 def test_ragged_batch_matches_single_utterances(eng):
     au = Audio(LJHPS.Audio, engine=eng)
     r = rng(5)

@@ -127,11 +127,12 @@ __device__ void fft2048(float2* x, const float2* tw, int tid) {
 // At most kMaxOv frames overlap a sample (host checks ceil(win / hop) <= kMaxOv); the loop has a fixed trip count and predicated
 // loads so that all of a sample's reads are in flight together (a data-dependent loop serialised ~5 L2 round trips per sample).
 constexpr int kMaxOv = 8;
+template <int NOV>                                   // NOV >= ceil(win / hop): 4 for both reference configurations (1024/256, 800/200)
 __device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, int n, int nf, int hop, int win, int lpad) {
   const int t_hi = (n - lpad) / hop;                 // newest frame whose window support starts at or before n (n >= lpad always)
-  float v[kMaxOv], w2[kMaxOv];
+  float v[NOV], w2[NOV];
 #pragma unroll
-  for (int j = 0; j < kMaxOv; ++j) {
+  for (int j = 0; j < NOV; ++j) {
     const int t = t_hi - j, i = n - t * hop - lpad;  // i >= 0 by construction
     const bool ok = t >= 0 && t < nf && i < win;
     v[j] = ok ? fr[(size_t)t * win + i] : 0.f;
@@ -139,7 +140,7 @@ __device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, i
   }
   float num = 0.f, den = 0.f;
 #pragma unroll
-  for (int j = kMaxOv - 1; j >= 0; --j) { num += v[j]; den += w2[j]; }     // frame order (oldest first), like the overlap-add loop
+  for (int j = NOV - 1; j >= 0; --j) { num += v[j]; den += w2[j]; }     // frame order (oldest first), like the overlap-add loop
   return den > 1.17549435e-38f ? num / den : num;   // librosa.istft: divide where window_sumsquare > tiny(float32)
 }
 
@@ -147,7 +148,7 @@ __device__ __forceinline__ float ola_sample(const float* fr, const float* wsq, i
 // Z[k] = X0[k] + j X1[k], so X0[k] = (Z[k] + conj Z[N-k]) / 2 and X1[k] = (Z[k] - conj Z[N-k]) / (2j); after the phase step the
 // two Hermitian spectra are packed as W = Y0 + j Y1 and one inverse transform returns y0 in the real and y1 in the imaginary part.
 // Halves the butterfly work per frame (the kernel is bound by vector issue).
-template <bool FIRST>
+template <bool FIRST, int NOV>
 __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
   __shared__ float2 buf[kPadded];                      // padded indexing: pidx()
   __shared__ float2 tws[kHalf];
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
           if (q < 0) q = -q;
           if (q >= L) q = 2 * (L - 1) - q;
           q = q < 0 ? 0 : q;
-          v[g] = wins[iw] * ola_sample(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
+          v[g] = wins[iw] * ola_sample<NOV>(frp, wsqs, q + kHalf, nf, a.hop, a.win, lpad);
         }
       }
       buf[pidx(i)] = make_float2(v[0], v[1]);
@@ -247,6 +248,7 @@ __global__ void __launch_bounds__(256) gl_frame_kernel(const VocArgs a) {
 }
 
 // final signal: wav[b][q] = overlap-added, normalised signal cropped by n_fft/2 (istft center=True), q < hop (nf - 1); 0 beyond
+template <int NOV>
 __global__ void __launch_bounds__(256) gl_final_kernel(const float* fr, const float* window, const int32_t* frames, int T, int hop, int win,
                                                          int Lmax, float* wav) {
   const int b = blockIdx.y;
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(256) gl_final_kernel(const float* fr, const fl
   const int nf = frames ? frames[b] : T;
   const int L = hop * (nf - 1);
   float v = 0.f;
-  if (q < L) v = ola_sample(fr + (size_t)b * T * win, window + win, q + kHalf, nf, hop, win, (kNfft - win) / 2);   // window | window^2
+  if (q < L) v = ola_sample<NOV>(fr + (size_t)b * T * win, window + win, q + kHalf, nf, hop, win, (kNfft - win) / 2);   // window | window^2
   wav[(size_t)b * Lmax + q] = v;
 }
 
@@ -316,15 +318,18 @@ hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_pre
   a.S = S; a.ang0 = ang0; a.fr_prev = fr_prev; a.fr_next = fr_next; a.frames = frames; a.tw = reinterpret_cast<const float2*>(tw); a.window = window;
   a.B = B; a.T = T; a.hop = hop; a.win = win;
   const unsigned lds = (unsigned)(2 * win * sizeof(float));
-  if (ang0) vnr_launch(gl_frame_kernel<true>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
-  else vnr_launch(gl_frame_kernel<false>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
+  const bool ov4 = (win + hop - 1) / hop <= 4;
+  if (ang0) vnr_launch(gl_frame_kernel<true, 4>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);      // (the first pass gathers nothing)
+  else if (ov4) vnr_launch(gl_frame_kernel<false, 4>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
+  else vnr_launch(gl_frame_kernel<false, kMaxOv>, dim3((T + 1) / 2, B), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_gl_final(const float* fr, const float* window, const int32_t* frames, int B, int T, int hop, int win, float* wav, hipStream_t s) {
   const int Lmax = hop * (T - 1);
   if (Lmax <= 0) return hipErrorInvalidValue;
-  vnr_launch(gl_final_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, s, fr, window, frames, T, hop, win, Lmax, wav);
+  if ((win + hop - 1) / hop <= 4) vnr_launch(gl_final_kernel<4>, dim3((Lmax + 255) / 256, B), dim3(256), 0, s, fr, window, frames, T, hop, win, Lmax, wav);
+  else vnr_launch(gl_final_kernel<kMaxOv>, dim3((Lmax + 255) / 256, B), dim3(256), 0, s, fr, window, frames, T, hop, win, Lmax, wav);
   return hipGetLastError();
 }
 

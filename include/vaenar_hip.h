@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VNR_ABI_VERSION 2
+#define VNR_ABI_VERSION 3
 
 typedef struct vnr_context *vnr_handle;
 
@@ -208,6 +208,11 @@ int vnr_op_attention(vnr_handle h, const float *d_q, int ldq, const float *d_k, 
 /* tf.keras.layers.LayerNormalization() over the last axis (eps 1e-3): rows x dim. */
 int vnr_op_layer_norm(vnr_handle h, const float *d_x, const float *d_gamma, const float *d_beta,
                       int rows, int dim, float *d_y);
+/* tf.random.normal(shape, mean=0, stddev) of BasePrior._initial_sample (modules/prior.py:35, stddev = temperature) and
+ * BasePosterior.reparameterize (modules/posterior.py:35): n floats ~ N(0, stddev^2) written on the device by a counter-based
+ * Philox-4x32-10 generator + Box-Muller (element block j = elements 4j..4j+3 <- counter j + offset, key = seed), so a
+ * temperature > 0 run uploads no noise.  Deterministic in (seed, offset); disjoint offset ranges give independent streams. */
+int vnr_random_normal(vnr_handle h, uint64_t seed, uint64_t offset, float stddev, float *d_out, size_t n);
 /* PositionalEncoding.positional_encoding (modules/utils.py:333-355): d_out [T,dim]. */
 int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float *d_out);
 
@@ -274,6 +279,16 @@ int vnr_comm_destroy(vnr_handle h);
 /* d loss / d variable of the last vnr_train_step (n floats, layout of the variable) -- tape.gradient (train.py:136). */
 int vnr_get_gradient(vnr_handle h, const char *path, float *host, int64_t n);
 
+/* Optimizer state -- the reference checkpoints tf.train.Checkpoint(step, optimizer, model) and restores all three
+ * (train.py:246-255): Adam's first / second moment of a trainable variable (slot "m" / "v", layout of the variable; zero
+ * until a step has run) and Adam's iteration counter (`optimizer.iterations`, which sets the bias correction of the next step).
+ * Restore order: vnr_set_weight (all) -> vnr_finalize_weights -> vnr_set_optimizer_slot / _step; updating an EXISTING
+ * variable with vnr_set_weight keeps the optimizer state, adding or resizing one discards it. */
+int vnr_get_optimizer_slot(vnr_handle h, const char *path, const char *slot, float *host, int64_t n);
+int vnr_set_optimizer_slot(vnr_handle h, const char *path, const char *slot, const float *host, int64_t n);
+int vnr_get_optimizer_step(vnr_handle h, int64_t *iterations);
+int vnr_set_optimizer_step(vnr_handle h, int64_t iterations);
+
 /* VAENAR.init (models/models.py:212-226) <- train.py:176-179 init_step: text encoder (training=True) ->
  * TransformerPrior.init (prior.py:171-186: every ActNormFlow sets log_scale / bias from the statistics of its input,
  * flow.py:189-196) -> decoder at max_reduction_factor.  d_reduced_lengths = ceil(mel_lengths / max_rf), Tz = their
@@ -286,7 +301,8 @@ int vnr_init(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
 
 /* ---- instrumentation ------------------------------------------------------------------------ */
 /* When enabled every kernel launch is bracketed by HIP events on the handle's stream and
- * accumulated per kernel class ("gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm",
+ * accumulated per kernel class ("gemm": tiled GEMM launches on the 3-term split-fp16 path, "gemm_fp32": tiled GEMM launches
+ * on exact fp32 MFMA, "chain": row-panel chain launches (split), "attn_self", "attn_cross", "attn_cross_ali", "layer_norm",
  * "misc").  vnr_profile_get synchronises.  flops/bytes are the ALGORITHMIC counts of the
  * launches (2*M*N*K per GEMM; Q+K+V+ctx(+alignments) bytes per attention). */
 int vnr_profile_enable(vnr_handle h, int on);

@@ -60,7 +60,7 @@ def inference_test():
         model.load_weights(init_weights(hparams, seed=args.seed, mode='synthetic', include_posterior=False))
     else:
         model.load_weights(args.ckpt_path)                                        # replaces Checkpoint.restore :122-123
-    rng = np.random.Generator(np.random.PCG64(args.seed + rank))
+    model.prior.seed(args.seed + rank)                                            # device noise stream (prior.py:35) per rank
     tester = None
     if args.write_wavs:
         from vaenar_tts_amd.audio import TestUtils
@@ -72,12 +72,9 @@ def inference_test():
         predicted_lengths = model.length_predictor(text_embd, t_l, training=False)
         predicted_m_l = predicted_lengths.numpy().astype(np.int32)               # tf.cast(float, int32) :135
         reduced_pred_ml = (predicted_m_l + 80 + rf - 1) // rf                    # :136-137
-        eps = None
-        if args.temperature:
-            eps = (np.float32(args.temperature) * rng.standard_normal(
-                (len(t_l), int(reduced_pred_ml.max()), hparams.Common.latent_dim))).astype(np.float32)
+        # temperature > 0: the initial noise is drawn on the device (vnr_random_normal), nothing is uploaded
         prior_latents, _ = model.prior.sample(reduced_pred_ml, text_embd, t_l, training=False,
-                                              temperature=args.temperature, eps=eps, return_logprobs=False)
+                                              temperature=args.temperature, return_logprobs=False)
         _, prior_dec_outs, prior_dec_alignments = model.decoder(
             prior_latents, text_embd, reduced_pred_ml, t_l, training=False, reduction_factor=rf)
         return prior_dec_outs, predicted_m_l + 80, prior_dec_alignments
@@ -98,7 +95,7 @@ def inference_test():
         outs = prior_outs.numpy()                                                 # device -> host ends the step
         time_end = time.time()
         time_consumed += time_end - time_begin
-        durations += np.sum(pred_m_lens) * 256 / 22050                            # frame_shift / sample_rate :155
+        durations += np.sum(pred_m_lens) * hparams.Audio.frame_shift_sample / hparams.Audio.sample_rate   # inference.py:155
         if args.write_mels:                                                       # audio/utils.py:16-22
             for i, fid in enumerate(ids):
                 np.save(os.path.join(args.test_dir, 'prior-{}-{}.npy'.format(fid, ckpt_step)),
@@ -144,13 +141,9 @@ def synthesize_from_text(argv):
     text_embd = model.text_encoder(text_batch, text_lens, pos_step=text_pos_step, training=False)
     predicted_m_l = model.length_predictor(text_embd, text_lens, training=False).numpy().astype(np.int32)
     reduced_pred_ml = (predicted_m_l + 80 + rf - 1) // rf
-    eps = None
-    if args.temperature:
-        rng = np.random.Generator(np.random.PCG64(args.seed))
-        eps = (np.float32(args.temperature) * rng.standard_normal(
-            (len(text_lens), int(reduced_pred_ml.max()), hparams.Common.latent_dim))).astype(np.float32)
+    model.prior.seed(args.seed)
     prior_latents, _ = model.prior.sample(reduced_pred_ml, text_embd, text_lens, training=False, temperature=args.temperature,
-                                          eps=eps, return_logprobs=False)
+                                          return_logprobs=False)
     _, prediction, _ = model.decoder(prior_latents, text_embd, reduced_pred_ml, text_lens, training=False)
     pred_lens = predicted_m_l + 80
     outs = prediction.numpy()

@@ -149,6 +149,35 @@ def dropout_keep(shape, rate, seed, site):
     return (k >= thresh).reshape(shape)
 
 
+def philox4x32_10(counter, key):
+    """Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter [n,4] uint32, key [2]
+    uint32 -> [n,4] uint32.  Pinned by the Random123 known-answer vectors (tests/test_oracle_kat.py)."""
+    c = np.array(counter, dtype=np.uint64).reshape(-1, 4) & np.uint64(0xFFFFFFFF)
+    k0, k1 = np.uint64(int(key[0]) & 0xFFFFFFFF), np.uint64(int(key[1]) & 0xFFFFFFFF)
+    M0, M1, W0, W1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        c = np.stack([(p1 >> np.uint64(32)) ^ c[:, 1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[:, 3] ^ k1, p0 & mask], 1)
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return c.astype(np.uint32)
+
+
+def philox_normal(n, seed, offset=0, stddev=1.0):
+    """The device generator behind vnr_random_normal (csrc/misc.hip philox_normal_kernel), restated: element block j =
+    elements 4j..4j+3 <- counter (j + offset, 0, 0), key = seed; Box-Muller on ((x >> 8) + 0.5) 2^-24.  float64 arithmetic,
+    rounded to fp32 at the end (the kernel works in fp32: agreement to a few 1e-6)."""
+    nb = (int(n) + 3) // 4
+    ctr = np.arange(nb, dtype=np.uint64) + np.uint64(offset)
+    cnt = np.stack([ctr & np.uint64(0xFFFFFFFF), ctr >> np.uint64(32), np.zeros(nb, np.uint64), np.zeros(nb, np.uint64)], 1)
+    x = philox4x32_10(cnt, (int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)).astype(np.float64)
+    u = (np.floor(x / 256.0).astype(np.float32).astype(np.float64) + 0.5) / 16777216.0
+    u = u.astype(np.float32).astype(np.float64)                       # the kernel forms u in fp32 (exact: 24-bit integers + 0.5)
+    r0, r1 = np.sqrt(-2.0 * np.log(u[:, 0])), np.sqrt(-2.0 * np.log(u[:, 2]))
+    t0, t1 = 2.0 * np.pi * u[:, 1], 2.0 * np.pi * u[:, 3]
+    z = np.stack([r0 * np.cos(t0), r0 * np.sin(t0), r1 * np.cos(t1), r1 * np.sin(t1)], 1).reshape(-1)[:int(n)]
+    return (stddev * z).astype(np.float32)
+
+
 def softmax_last(x):
     """tf.math.softmax: exp(x-max)/sum."""
     m = x.max(-1, keepdims=True)

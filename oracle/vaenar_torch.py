@@ -60,14 +60,17 @@ def conv1d_same(x, kernel, bias):
 
 
 class TorchOracle:
-    def __init__(self, hps, weights, dtype=torch.float64):
+    def __init__(self, hps, weights, dtype=torch.float64, grad=None):
+        """``grad``: track gradients (default: only in float64, the specification; float32 + grad = the quick full-size digest
+        of tests/test_gpu_round2.py)."""
         from vaenar_tts_amd.weights import is_trainable
         self.hps = hps
         _DT[0] = dtype
         self.w = {}
+        want_grad = (dtype == torch.float64) if grad is None else bool(grad)
         for k, v in weights.items():
             t = _t(v).clone()
-            t.requires_grad_(is_trainable(k) and dtype == torch.float64)
+            t.requires_grad_(is_trainable(k) and want_grad)
             self.w[k] = t
         self.dropout_seed = None
         self.update_moving_stats = True

@@ -8,9 +8,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _latest_bench_line():
+    pdir = os.path.join(ROOT, "profiles")
+    f = sorted(x for x in os.listdir(pdir) if x.endswith("_bench.json"))[-1]
+    return f, json.loads(open(os.path.join(pdir, f)).read().strip().splitlines()[-1])
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    lines = open(os.path.join(ROOT, "profiles", "r01_bench.json")).read().strip().splitlines()
-    d = json.loads(lines[-1])
+    fname, d = _latest_bench_line()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -35,5 +40,53 @@ def test_committed_bench_line_has_the_contract_fields():
 def test_bench_cli_flags():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--streams"):
+    for flag in ("--gpus", "--steps", "--warmup", "--streams", "--in-flight"):
         assert flag in out.stdout
+
+
+def test_round2_line_is_coherent():
+    """From round 2 on: `value` is the single-stream schedule the roofline blocks were profiled on, the roofline fraction is
+    taken against the pipe the dominant kernel really uses, and a PMC traffic figure is only printed when its record carries
+    the digest of the running kernel sources."""
+    fname, d = _latest_bench_line()
+    if fname < "r02":
+        return
+    assert d["config"]["batches_in_flight_per_gpu"] == 1
+    r = d["roofline"]
+    assert r["class"] in ("chain", "gemm", "gemm_fp32")
+    assert r["peak"] == (157.3 if r["class"] == "gemm_fp32" else 2500.0)
+    if r["class"] != "gemm_fp32":
+        assert abs(r["achieved"] - 3 * r["algorithmic_tflops"]) < 1e-6 * r["achieved"]
+    assert d["end_to_end"]["kernel_ms_sum"] <= d["ms_per_step"] * 1.02       # same schedule: kernel time fits inside the step
+    if r["traffic"] is not None:
+        assert d["kernel_source_digest"] in r["traffic_source"] or "same kernel sources" in r["traffic_source"]
+
+
+def test_launcher_spawns_n_ranks_with_torchrun_style_env(tmp_path):
+    """`bench.py --gpus N` without WORLD_SIZE: the parent starts N fresh processes (fake worker here: no GPU), each with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, and relays rank 0's stdout."""
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = tmp_path / "fake_worker.py"
+    worker.write_text(
+        "import json, os, sys\n"
+        "e = {k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}\n"
+        "e['argv'] = sys.argv[1:]\n"
+        "open(os.path.join(%r, 'rank%%s.json' %% e['RANK']), 'w').write(json.dumps(e))\n"
+        "if e['RANK'] == '0': print(json.dumps({'n_gpus': int(e['WORLD_SIZE'])}))\n" % str(tmp_path))
+    rc, out0 = bench.launch_ranks(3, ["--gpus", "3", "--steps", "2"], worker=[sys.executable, str(worker)], timeout=60)
+    assert rc == 0 and json.loads(out0.strip())["n_gpus"] == 3
+    envs = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and all(e["argv"] == ["--gpus", "3", "--steps", "2"] for e in envs)
+
+
+def test_launcher_propagates_a_failing_rank(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = tmp_path / "w.py"
+    worker.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(30)\n")
+    t0 = __import__("time").time()
+    rc, _ = bench.launch_ranks(2, [], worker=[sys.executable, str(worker)], timeout=60)
+    assert rc == 7 and __import__("time").time() - t0 < 20      # the surviving rank was terminated, not waited for

@@ -243,3 +243,24 @@ def test_dropout_hash_known_answers():
     assert (k1 == k2).all() and abs(k1.mean() - 0.9) < 5e-3 and abs((k1 == k3).mean() - 0.82) < 1e-2
     assert dropout_keep((64,), 0.0, 1, 0).all()
     assert abs(dropout_keep((200000,), 0.5, 7, 16).mean() - 0.5) < 5e-3
+
+
+def test_philox4x32_10_known_answers():
+    """The counter-based generator behind vnr_random_normal (device noise, prior.py:35 / posterior.py:35): the oracle's
+    restatement reproduces the published Random123 known-answer vectors of philox4x32-10."""
+    from oracle.vaenar_numpy import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in philox4x32_10([ctr], key)[0]) == want
+
+
+def test_philox_normal_moments_and_streams():
+    from oracle.vaenar_numpy import philox_normal
+    z = philox_normal(400000, seed=1234, offset=0)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3 and abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3) < 5e-2
+    # offset = a jump of whole 4-element blocks; stddev scales; a different seed is a different stream
+    assert np.array_equal(philox_normal(64, 1234, offset=10), z[40:104])
+    assert np.allclose(philox_normal(64, 1234, 0, stddev=0.5), 0.5 * z[:64], atol=1e-7)
+    assert abs(np.corrcoef(philox_normal(100000, 1235), z[:100000])[0, 1]) < 1e-2

@@ -192,3 +192,71 @@ def test_object_graph_of_saved_model_weights(tmp_path):
     # and load_model_weights is unaffected by the extra entry
     w2 = ck.load_model_weights(prefix, hps)
     assert set(w2) == set(w)
+
+
+# ---- the training checkpoint (train.py:246-255): model + Adam slots + counters, CheckpointManager -----------------------------
+def _tiny_state():
+    from vaenar_tts_amd.configs import tiny_hps
+    from vaenar_tts_amd.weights import init_weights, is_trainable
+    hps = tiny_hps()
+    w = {k: np.asarray(v, np.float32) for k, v in init_weights(hps, seed=1).items()}
+    r = np.random.default_rng(0)
+    m = {k: r.standard_normal(a.shape).astype(np.float32) for k, a in w.items() if is_trainable(k)}
+    v = {k: np.abs(r.standard_normal(a.shape)).astype(np.float32) for k, a in w.items() if is_trainable(k)}
+    return hps, w, m, v
+
+
+def test_training_checkpoint_round_trip_and_keys(tmp_path):
+    from vaenar_tts_amd import tf_checkpoint as tc
+    hps, w, m, v = _tiny_state()
+    prefix = str(tmp_path / "ckpt-3")
+    tc.save_training_checkpoint(prefix, w, m, v, iterations=1234567890123, step=41, save_counter=3, learning_rate=1.25e-4)
+    keys = {k: (tuple(s), d) for k, s, d in tc.list_variables(prefix)}
+    # the names TF2's object-based saver gives tf.train.Checkpoint(step, optimizer, model) with a Keras Adam
+    assert keys["step/.ATTRIBUTES/VARIABLE_VALUE"] == ((), np.int64) and keys["save_counter/.ATTRIBUTES/VARIABLE_VALUE"] == ((), np.int64)
+    assert keys["optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE"] == ((), np.int64)
+    for name in ("learning_rate", "beta_1", "beta_2", "decay"):
+        assert keys["optimizer/%s/.ATTRIBUTES/VARIABLE_VALUE" % name] == ((), np.float32)
+    k = "model/decoder/pre_projection/kernel"
+    assert keys[k + "/.ATTRIBUTES/VARIABLE_VALUE"][0] == w["decoder/pre_projection/kernel"].shape
+    for slot in ("m", "v"):
+        assert keys["%s/.OPTIMIZER_SLOT/optimizer/%s/.ATTRIBUTES/VARIABLE_VALUE" % (k, slot)][0] == w["decoder/pre_projection/kernel"].shape
+    assert not any("moving_mean/.OPTIMIZER_SLOT" in x for x in keys)            # BN statistics are not optimised
+    back = tc.load_training_checkpoint(prefix, hps)
+    assert back["iterations"] == 1234567890123 and back["step"] == 41 and back["save_counter"] == 3
+    assert all(np.array_equal(back["weights"][p], w[p]) for p in w)
+    assert all(np.array_equal(back["m"][p], m[p]) and np.array_equal(back["v"][p], v[p]) for p in m)
+    # the model-only reader (inference.py:122-123 + expect_partial) skips the optimizer entries
+    only = tc.load_model_weights(prefix, hps)
+    assert set(only) == set(w) and all(np.array_equal(only[p], w[p]) for p in w)
+    # object graph: every slot variable hangs off the optimizer node and points at its original variable
+    g = tc.parse_object_graph(tc.read_checkpoint(prefix, with_strings=True)[tc.OBJECT_GRAPH_KEY], with_slots=True)
+    root_children = dict((name, nid) for nid, name in g[0][0])
+    assert {"model", "optimizer", "step", "save_counter"} <= set(root_children)
+    slots = g[root_children["optimizer"]][2]
+    assert len(slots) == 2 * len(m)
+    for orig, slot, nid in slots[:20]:
+        ok = g[orig][1][0][2]                       # checkpoint key of the original variable
+        assert g[nid][1][0][2] == ok[:-len(tc.SUFFIX)] + "/.OPTIMIZER_SLOT/optimizer/" + slot + tc.SUFFIX
+
+
+def test_checkpoint_manager_numeric_order_and_max_to_keep(tmp_path):
+    """a lexicographic sort resumes from ckpt-9 when ckpt-10..ckpt-89 exist.  The manager follows the
+    `checkpoint` state file like tf.train.CheckpointManager.latest_checkpoint, and falls back to the NUMERIC counter."""
+    from vaenar_tts_amd import tf_checkpoint as tc
+    hps, w, m, v = _tiny_state()
+    small = {k: w[k] for k in list(w)[:3]}
+    mgr = tc.CheckpointManager(str(tmp_path), max_to_keep=4)
+    for i in range(1, 13):
+        p = mgr.save(lambda prefix, n: tc.save_training_checkpoint(prefix, small, {}, {}, iterations=i, step=i - 1, save_counter=n))
+        assert os.path.basename(p) == "ckpt-%d" % i
+    names = sorted(f for f in os.listdir(tmp_path) if f.endswith(".index"))
+    assert names == ["ckpt-10.index", "ckpt-11.index", "ckpt-12.index", "ckpt-9.index"]          # 4 kept; note the lexicographic trap
+    state = open(tmp_path / "checkpoint").read()
+    assert state.startswith('model_checkpoint_path: "ckpt-12"') and state.count("all_model_checkpoint_paths") == 4
+    assert os.path.basename(tc.CheckpointManager(str(tmp_path)).latest_checkpoint) == "ckpt-12"
+    os.remove(tmp_path / "checkpoint")                                                            # no state file: numeric order
+    fresh = tc.CheckpointManager(str(tmp_path))
+    assert os.path.basename(fresh.latest_checkpoint) == "ckpt-12" and fresh.next_counter() == 13
+    assert tc.load_training_checkpoint(fresh.latest_checkpoint)["step"] == 11
+    assert tc.CheckpointManager(str(tmp_path / "empty")).latest_checkpoint is None

@@ -7,7 +7,10 @@ vaenar_tts_amd.models.VAENAR (training-mode forward, backward and Adam on the GP
 
 Differences forced by the environment: no TensorFlow -> batches are synthetic (``--data_dir synthetic``: seeded random
 utterances of ``--t_text`` x ``--t_mel``) or a directory of the reference's ``{train,dev}-*.tfrecords`` files, read without
-TensorFlow by vaenar_tts_amd/tf_record_utils.py; checkpoints are ``.npz`` files of the object-graph variable tree (``ckpt-<epoch>.npz``).
+TensorFlow by vaenar_tts_amd/tf_record_utils.py.  Checkpoints are what the reference's tf.train.Checkpoint(step, optimizer, model) +
+CheckpointManager(max_to_keep=20) write (:246-249): TensorFlow tensor bundles ``ckpt-<save_counter>.index`` / ``.data-*`` holding
+the variables, Adam's slots and counters and the epoch counter, plus the ``checkpoint`` state file ``latest_checkpoint`` reads
+(vaenar_tts_amd/tf_checkpoint.py, no TensorFlow); a restart restores all three, so Adam resumes with its moments and bias correction.
 With torchrun (WORLD_SIZE > 1) the run is data-parallel: the batch is sharded by utterance over the ranks, every rank
 holds a replica, and the flat gradient is all-reduced with RCCL over xGMI inside vnr_train_step (one exchange per step);
 the host control plane (gloo) only carries the RCCL id, barriers and the averaged log scalars.
@@ -22,7 +25,8 @@ from vaenar_tts_amd import dist as vdist
 from vaenar_tts_amd.configs import DataBakerHPS, LJHPS, tiny_hps
 from vaenar_tts_amd.models import VAENAR
 from vaenar_tts_amd.synthetic import make_batch
-from vaenar_tts_amd.weights import init_weights, load_npz, save_npz
+from vaenar_tts_amd.tf_checkpoint import CheckpointManager
+from vaenar_tts_amd.weights import init_weights
 
 
 def synthetic_batches(hps, n_batches, batch_size, t_text, t_mel, seed):
@@ -84,34 +88,44 @@ def main():
     train = [vdist.shard_batch(b, rank, world) for b in train]
     dev = [vdist.shard_batch(b, rank, world) for b in dev]
 
-    # 2. model + optimizer (train.py:114-117)
-    ckpts = sorted(f for f in os.listdir(args.model_dir) if f.startswith('ckpt-') and f.endswith('.npz'))
-    weights = load_npz(os.path.join(args.model_dir, ckpts[-1])) if ckpts else init_weights(hps, seed=seed, mode='reference')
-    model = VAENAR(hps, device=local_rank, weights=weights)
+    # 2. model + optimizer (train.py:114-117) and the checkpoint manager (train.py:246-255)
+    manager = CheckpointManager(args.model_dir, max_to_keep=20)
+    latest = manager.latest_checkpoint                        # the state file's entry (numeric order of the files without one)
+    model = VAENAR(hps, device=local_rank, weights=init_weights(hps, seed=seed, mode='reference'))
+    step = 0
+    if latest:                                                # every rank restores variables, Adam slots and counters itself
+        step = model.restore_checkpoint(latest)
+        if rank == 0:
+            print("Restored from {}".format(latest))
+    elif rank == 0:
+        print("Initializing from scratch.")
     if world > 1:                                             # data-parallel: bind the RCCL communicator
         uid = vdist.broadcast_bytes(model.engine.comm_unique_id() if rank == 0 else None)
         model.engine.comm_init(world, rank, uid)
-    step = int(ckpts[-1][5:-4]) if ckpts else 0
     kw_init, kw_end, kw_epochs = hps.Train.kl_weight_init, hps.Train.kl_weight_end, hps.Train.kl_weight_increase_epoch
     kw_step = (kw_end - kw_init) / kw_epochs                 # train.py:230-234
 
-    def save(ep):
+    def save():                                               # manager.save(): rank 0 writes (BatchNorm moving statistics are rank 0's)
+        path = None
         if rank == 0:
-            path = os.path.join(args.model_dir, 'ckpt-%d.npz' % ep)
-            save_npz(path, model.get_weights())
-            return path
+            path = manager.save(lambda prefix, n: model.save_checkpoint(prefix, step=step, save_counter=n))
+        vdist.barrier()
+        return path
 
-    if not ckpts:                                             # train.py:256-267
+    if not latest:                                            # train.py:256-267
         b = train[0]
         model.init(text_inputs=b["ids"], mel_lengths=b["mel_lengths"], text_lengths=b["text_lengths"], dropout_seed=seed)
         if world > 1:
             model.engine.comm_broadcast_weights()             # ActNorm init and BN statistics of rank 0 everywhere
-        print("Initial checkpoint for step 0: {}".format(save(0)))
+        path = save()
+        if rank == 0:
+            print("Initial checkpoint for step {}: {}".format(step, path))
         out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw_init, hps.Common.max_reduction_factor,
                                dropout_seed=seed + rank)
-        print('Initial step: total {:.6f}, mel-l2 {:.6f}, kl {:.3f}, len-l2 {:.3f}'.format(*out))
+        if rank == 0:
+            print('Initial step: total {:.6f}, mel-l2 {:.6f}, kl {:.3f}, len-l2 {:.3f}'.format(*out))
 
-    it = 0
+    it = model.engine.get_optimizer_step()                    # Adam iterations so far: dropout seeds continue after a restart
     for epoch in range(step + 1, args.epochs + 1):            # train.py:269-306
         kw = kw_init + kw_step * epoch if epoch <= kw_epochs else kw_end
         rf = get_reduction_factor(hps, epoch)
@@ -143,7 +157,10 @@ def main():
         if rank == 0:
             print('Epoch {}:  train-total {}, train-mel-l2 {}, train-kl {},train-len-l2 {}, dev-total {}, dev-l2 {}, dev-kl {}, '
                   'dev-len-l2 {}'.format(epoch, *acc, *dacc))
-            print("Saved checkpoint for epoch {}: {}".format(epoch, save(epoch)))
+        path = save()                                         # train.py:300-303: save, THEN step += 1 (the stored counter lags by one)
+        if rank == 0:
+            print("Saved checkpoint for epoch {}: {}".format(step, path))
+        step += 1
     vdist.barrier()
     model.engine.close()
 

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
 
@@ -90,12 +90,17 @@ PROTOTYPES = {
     "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
+    "vnr_random_normal": [_vp, C.c_uint64, C.c_uint64, _f, _vp, _sz],
     "vnr_voc_mel_to_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _f, _vp],
     "vnr_voc_griffin_lim": [_vp, _vp, _vp, C.c_uint64, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vnr_set_option": [_vp, C.c_char_p, _i],
     "vnr_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "vnr_train_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _f, _f, _f, _f, _f, _f, _i, _vp],
     "vnr_get_gradient": [_vp, C.c_char_p, _vp, C.c_int64],
+    "vnr_get_optimizer_slot": [_vp, C.c_char_p, C.c_char_p, _vp, C.c_int64],
+    "vnr_set_optimizer_slot": [_vp, C.c_char_p, C.c_char_p, _vp, C.c_int64],
+    "vnr_get_optimizer_step": [_vp, _pi64],
+    "vnr_set_optimizer_step": [_vp, C.c_int64],
     "vnr_comm_unique_id": [_vp, C.c_char_p],
     "vnr_comm_init": [_vp, _i, _i, C.c_char_p],
     "vnr_comm_broadcast_weights": [_vp],
@@ -286,6 +291,12 @@ class Engine:
             x = x.numpy()
         return self.to_device(np.asarray(x), dtype)
 
+    def random_normal(self, shape, seed, offset=0, stddev=1.0):
+        """tf.random.normal(shape, stddev=stddev) drawn on the device (Philox-4x32-10, vnr_random_normal)."""
+        a = DeviceArray(self, shape, np.float32)
+        check(self.lib.vnr_random_normal(self.handle, int(seed) & (2 ** 64 - 1), int(offset), float(stddev), a.ptr, a.size), self.handle)
+        return a
+
     def synchronize(self):
         check(self.lib.vnr_synchronize(self.handle), self.handle)
 
@@ -327,6 +338,24 @@ class Engine:
         out = np.empty(shape, np.float32)
         check(self.lib.vnr_get_gradient(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
         return out
+
+    # -- optimizer state (train.py:246-255: Checkpoint(step, optimizer, model)) ----------------
+    def get_optimizer_slot(self, path, slot, shape):
+        out = np.empty(shape, np.float32)
+        check(self.lib.vnr_get_optimizer_slot(self.handle, path.encode(), slot.encode(), out.ctypes.data, out.size), self.handle)
+        return out
+
+    def set_optimizer_slot(self, path, slot, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        check(self.lib.vnr_set_optimizer_slot(self.handle, path.encode(), slot.encode(), a.ctypes.data, a.size), self.handle)
+
+    def get_optimizer_step(self):
+        n = C.c_int64(0)
+        check(self.lib.vnr_get_optimizer_step(self.handle, C.byref(n)), self.handle)
+        return n.value
+
+    def set_optimizer_step(self, iterations):
+        check(self.lib.vnr_set_optimizer_step(self.handle, int(iterations)), self.handle)
 
     def load_weights(self, weights):
         for k, v in weights.items():

@@ -45,45 +45,68 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr int kXchg = 8192;                         // bytes of exchange space per wave
 }  // namespace
 
+// Persistent form (round 2): a workgroup owns a CHUNK of consecutive query tiles of one (batch, head) -- `nchunk` chunks per pair,
+// grid = B.H.nchunk -- instead of one tile.  K and V of the wave's key block are loaded ONCE and stay in registers; the Q tile of
+// the next iteration is requested right after the S^T MFMAs of the current one (its registers are dead by then), so from the
+// second tile on no operand load is exposed, and the alignment / context stores of tile i drain under the MFMAs of tile i+1
+// instead of all 19.7 MB leaving at the same moment at the end of 832 simultaneous one-tile workgroups.
+// LDS hazards across iterations: the exchange space is only written after barrier 1 of an iteration, which every wave reaches
+// after its merge reads of the previous iteration -- no extra barrier, no double buffer.
 template <bool ALI>
-__global__ void __launch_bounds__(256, 4)
-attn3_kernel(const Attn3Args a, int nqt) {
+__global__ void __launch_bounds__(256, 2)
+attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* stats = reinterpret_cast<float*>(smem + 4 * kXchg);      // [4 waves][m | l][32]
 
-  // XCD-aware work map (as attention2): all query tiles of one (batch, head) share K/V -> same id mod 8 = same L2
+  // XCD-aware work map (as attention2): all chunks of one (batch, head) share K/V -> same id mod 8 = same L2
   const int npairs = a.B * a.H;
   const int wg = blockIdx.x;
-  int pair, qidx;
+  int pair, chunk;
   if ((npairs & 7) == 0) {
     const int xcd = wg & 7, j = wg >> 3, ppx = npairs >> 3;
-    qidx = j / ppx;
-    pair = (j - qidx * ppx) * 8 + xcd;
+    chunk = j / ppx;
+    pair = (j - chunk * ppx) * 8 + xcd;
   } else {
-    qidx = wg / npairs;
-    pair = wg - qidx * npairs;
+    chunk = wg / npairs;
+    pair = wg - chunk * npairs;
   }
+  const int qt_begin = (int)(((long long)chunk * nqt) / nchunk), qt_end = (int)(((long long)(chunk + 1) * nqt) / nchunk);
+  if (qt_begin >= qt_end) return;                     // (workgroup-uniform)
   const int b = pair / a.H, hd = pair - b * a.H;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int q0 = qidx * 32, kb0 = 32 * wave;
+  const int kb0 = 32 * wave;
   const bool active = kb0 < a.Tk;                     // wave-uniform: this wave's key block exists
   const bool partial = kb0 + 32 > a.Tk;               // ... but not all of it
 
-  // ---- operand loads: every one a fully coalesced 1 KiB wave read of an operand-major image tile (common.h).  All 24 are
-  //      issued before the first MFMA so that V's HBM round trip overlaps Q/K's.
+  // ---- operand loads: every one a fully coalesced 1 KiB wave read of an operand-major image tile (common.h).  K / V go straight
+  //      to registers, once.  The Q tile travels through LDS: each wave fetches a quarter of the NEXT tile (2 KiB) right after its
+  //      S^T MFMAs, parks it in LDS after the statistics barrier and every wave reads the whole tile back at the top of the next
+  //      iteration -- so the only vector-memory wait inside the loop sits BEFORE the iteration's stores are issued, and the
+  //      alignment / context stores are never waited for (vmcnt counts stores too: a register prefetch consumed at the loop top
+  //      would drain them every iteration).
   h8 qhi[4], qlo[4], khi[4], klo[4], vhi[2][2], vlo[2][2];
+  const int ttq = (a.Tq + 31) >> 5, ttk = (a.Tk + 31) >> 5;
+  const char* qbase = a.Qi + (size_t)(b * a.H + hd) * ttq * kAoiTile + wave * 2048 + lane * 16;
+  char* qlds = smem + 4 * kXchg + 4 * 64 * sizeof(float);        // [8 KiB] the current Q tile, image layout
+  h8 qn0, qn1;                                                     // this wave's quarter of the next Q tile
+  auto fetch_q = [&](int qidx) {
+    const char* qp = qbase + (size_t)qidx * kAoiTile;
+    qn0 = *reinterpret_cast<const h8*>(qp);
+    qn1 = *reinterpret_cast<const h8*>(qp + 1024);
+  };
+  auto park_q = [&]() {
+    *reinterpret_cast<h8*>(qlds + wave * 2048 + lane * 16) = qn0;
+    *reinterpret_cast<h8*>(qlds + wave * 2048 + 1024 + lane * 16) = qn1;
+  };
+  fetch_q(qt_begin);
   {
-    const int ttq = (a.Tq + 31) >> 5, ttk = (a.Tk + 31) >> 5;
-    const char* qp = a.Qi + ((size_t)(b * a.H + hd) * ttq + qidx) * kAoiTile + lane * 16;
     const size_t kt = ((size_t)(b * a.H + hd) * ttk + (active ? wave : 0)) * kAoiTile + lane * 16;
     const char* kp = a.Ki + kt;
     const char* vp = a.Vi + kt;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      qhi[t] = *reinterpret_cast<const h8*>(qp + 1024 * t);
-      qlo[t] = *reinterpret_cast<const h8*>(qp + 4096 + 1024 * t);
       khi[t] = *reinterpret_cast<const h8*>(kp + 1024 * t);
       klo[t] = *reinterpret_cast<const h8*>(kp + 4096 + 1024 * t);
     }
@@ -97,127 +120,148 @@ attn3_kernel(const Attn3Args a, int nqt) {
   }
   const int qlen = a.q_len ? a.q_len[b] : a.Tq;
   const int klen = a.k_len ? a.k_len[b] : a.Tk;
-
-  f32x16 st;
+  __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): Q quarter, K and V are in registers; nothing is outstanding at the loop top
+  if (active && partial) {                            // positions past Tk hold whatever the workspace held: force zeros (once)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st[r] = 0.f;
-  if (active) {
+    for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
+      for (int e = 0; e < 8; ++e) {
+        const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (key >= a.Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+      }
   }
-
-  // ---- logits (log2 domain) and masks ------------------------------------------------------------------------------------
+  park_q();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   const float c = (a.temperature != 1.0f) ? 0.125f * kLog2e / a.temperature : 0.125f * kLog2e;
-  const int iq = q0 + l31;
-  if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen) {          // wave-uniform: nothing masked in this block
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] *= c;
-  } else {
-    const bool qvalid = iq < qlen;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = kb0 + frow3(r, half);
-      float s = st[r] * c;
-      s = (qvalid && j < klen) ? s : kMaskFill * kLog2e;          // attention.py:240
-      if (j >= a.Tk) s = -INFINITY;                                 // key does not exist
-      st[r] = s;
-    }
-  }
-  float mt = -INFINITY;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
-  mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-  const float m_w = fmaxf(mt, -3.0e38f);                            // finite floor: a wave without keys gives p = 0, not NaN
-  float ls = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_w); st[r] = p; ls += p; }
-  ls += __shfl_xor(ls, 32, 64);
-  if (half == 0) { stats[wave * 64 + l31] = m_w; stats[wave * 64 + 32 + l31] = ls; }
+  char* xb = smem + wave * kXchg;                                  // this wave's exchange space
 
-  // ---- O^T partial = V^T.P^T over this wave's 32 keys, from the UNNORMALISED p (relative to this wave's maximum): issued before
-  //      the statistics barrier so that the exchange latency hides under the MFMAs.  Transposed accumulation (as in
-  //      attn3g_kernel): a lane owns one query, so the factor 2^(m_w - M) / L is an in-lane product afterwards.
-  f32x16 O[2];
+#pragma unroll 1
+  for (int qidx = qt_begin; qidx < qt_end; ++qidx) {
+    const int q0 = qidx * 32;
+    const bool more = qidx + 1 < qt_end;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+    for (int t = 0; t < 4; ++t) {
+      qhi[t] = *reinterpret_cast<const h8*>(qlds + 1024 * t + lane * 16);
+      qlo[t] = *reinterpret_cast<const h8*>(qlds + 4096 + 1024 * t + lane * 16);
+    }
+    f32x16 st;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
-  if (active) {
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    if (active) {
 #pragma unroll
-    for (int tp = 0; tp < 2; ++tp) {
-      if (partial) {                                  // positions past Tk hold whatever the workspace held: force zeros
+      for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
+    }
+    if (more) fetch_q(qidx + 1);                      // lands under this tile's softmax and P.V MFMAs
+
+    // ---- logits (log2 domain) and masks ----------------------------------------------------------------------------------
+    const int iq = q0 + l31;
+    if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen) {          // wave-uniform: nothing masked in this block
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
-          if (key >= a.Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+      for (int r = 0; r < 16; ++r) st[r] *= c;
+    } else {
+      const bool qvalid = iq < qlen;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kb0 + frow3(r, half);
+        float s = st[r] * c;
+        s = (qvalid && j < klen) ? s : kMaskFill * kLog2e;          // attention.py:240
+        if (j >= a.Tk) s = -INFINITY;                                 // key does not exist
+        st[r] = s;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_w = fmaxf(mt, -3.0e38f);                            // finite floor: a wave without keys gives p = 0, not NaN
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_w); st[r] = p; ls += p; }
+    ls += __shfl_xor(ls, 32, 64);
+    if (half == 0) { stats[wave * 64 + l31] = m_w; stats[wave * 64 + 32 + l31] = ls; }
+
+    // ---- O^T partial = V^T.P^T over this wave's 32 keys, from the UNNORMALISED p (relative to this wave's maximum): issued
+    //      before the statistics barrier so that the exchange latency hides under the MFMAs.  Transposed accumulation (as in
+    //      attn3g_kernel): a lane owns one query, so the factor 2^(m_w - M) / L is an in-lane product afterwards.
+    f32x16 O[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+    if (active) {
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = st[8 * tp + e];
+        h8 phi, plo;
+        split8x(pv, phi, plo);
+        O[0] = mfma3x(vhi[tp][0], vlo[tp][0], phi, plo, O[0]);
+        O[1] = mfma3x(vhi[tp][1], vlo[tp][1], phi, plo, O[1]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // every wave has read the current Q tile (its S^T MFMAs precede the barrier): park the next one.  The wait below is the
+    // only vmcnt wait of the iteration and precedes the iteration's stores
+    if (more) { __builtin_amdgcn_s_waitcnt(0x0F70); park_q(); }
+    float f;
+    {
+      float mw[4], lw[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
+      const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+      float L = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) L += lw[w] * __builtin_amdgcn_exp2f(mw[w] - M);
+      f = __builtin_amdgcn_exp2f(m_w - M) * (1.0f / L);              // softmax, attention.py:242 (one division per row)
+    }
+
+    if (ALI && active) {
+      // alignment rows: normalise, 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
+      float* xw = reinterpret_cast<float*>(xb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 p4 = {st[4 * j] * f, st[4 * j + 1] * f, st[4 * j + 2] * f, st[4 * j + 3] * f};
+        *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int rr = 8 * x + (lane >> 3), kc = lane & 7;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
+        const int qrow = q0 + rr, key = kb0 + 4 * kc;
+        if (qrow < a.Tq) {
+          float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
+          if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
         }
       }
-      float pv[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pv[e] = st[8 * tp + e];
-      h8 phi, plo;
-      split8x(pv, phi, plo);
-      O[0] = mfma3x(vhi[tp][0], vlo[tp][0], phi, plo, O[0]);
-      O[1] = mfma3x(vhi[tp][1], vlo[tp][1], phi, plo, O[1]);
     }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  float f;
-  {
-    float mw[4], lw[4];
+    // ---- sum the four partial tiles: rows [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row], already scaled ---
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
-    const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
-    float L = 0.f;
+    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int w = 0; w < 4; ++w) L += lw[w] * __builtin_amdgcn_exp2f(mw[w] - M);
-    f = __builtin_amdgcn_exp2f(m_w - M) * (1.0f / L);              // softmax, attention.py:242 (one division per row)
-  }
-
-  char* xb = smem + wave * kXchg;                                  // this wave's exchange space
-  if (ALI && active) {
-    // alignment rows: normalise, 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
-    float* xw = reinterpret_cast<float*>(xb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 p4 = {st[4 * j] * f, st[4 * j + 1] * f, st[4 * j + 2] * f, st[4 * j + 3] * f};
-      *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
-    }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const int rr = 8 * x + (lane >> 3), kc = lane & 7;
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
-      const int qrow = q0 + rr, key = kb0 + 4 * kc;
-      if (qrow < a.Tq) {
-        float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
-        if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 o4 = {O[nb][4 * jj] * f, O[nb][4 * jj + 1] * f, O[nb][4 * jj + 2] * f, O[nb][4 * jj + 3] * f};
+        *reinterpret_cast<f32x4*>(xb + l31 * 256 + (((nb * 8 + 2 * jj + half) ^ (l31 & 15)) << 4)) = o4;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + rr * 256 + ((ch ^ (rr & 15)) << 4));
+      const int row = q0 + rr;
+      if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
     }
-  }
-  // ---- sum the four partial tiles: rows [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row], already scaled -----
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const f32x4 o4 = {O[nb][4 * jj] * f, O[nb][4 * jj + 1] * f, O[nb][4 * jj + 2] * f, O[nb][4 * jj + 3] * f};
-      *reinterpret_cast<f32x4*>(xb + l31 * 256 + (((nb * 8 + 2 * jj + half) ^ (l31 & 15)) << 4)) = o4;
-    }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + rr * 256 + ((ch ^ (rr & 15)) << 4));
-    const int row = q0 + rr;
-    if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
   }
 }
 
@@ -413,11 +457,20 @@ hipError_t launch_attention3(const Attn3Args& a, hipStream_t s) {
   if (a.Tk <= 0 || a.Tq <= 0 || !a.Qi || !a.Ki || !a.Vi || !a.ctx || (a.ldo & 3)) return hipErrorInvalidValue;
   if (a.ali && (a.Tk > 128 || a.causal)) return hipErrorInvalidValue;     // alignments: single-round kernel only
   const int nqt = (a.Tq + 31) / 32;
-  const size_t lds = 4 * kXchg + 4 * 64 * sizeof(float);
+  const size_t lds = 4 * kXchg + 4 * 64 * sizeof(float) + kAoiTile;      // exchange space, statistics, the Q tile of attn3_kernel
   dim3 grid(nqt * a.H * a.B);
   static const bool force_general = getenv("VNR_ATTN3_GENERAL") != nullptr;   // A/B switch: looped kernel even where the single-round one applies
-  if (a.ali) vnr_launch(attn3_kernel<true>, grid, dim3(256), lds, s, a, nqt);
-  else if (!force_general && a.Tk <= 128 && !a.causal) vnr_launch(attn3_kernel<false>, grid, dim3(256), lds, s, a, nqt);   // 8.7 vs 9.4 us at 400x128
+  // chunks of query tiles per (batch, head) for the persistent single-round kernel: about two workgroups per CU (512), never
+  // more chunks than tiles.  VNR_ATTN3_CHUNKS overrides (0 = one tile per workgroup, the round-1 decomposition)
+  static const char* env_chunks = getenv("VNR_ATTN3_CHUNKS");
+  int nchunk = nqt;
+  if (!env_chunks || atoi(env_chunks) > 0) {
+    const int want = env_chunks ? atoi(env_chunks) : (512 + a.B * a.H - 1) / (a.B * a.H);
+    nchunk = want < nqt ? (want < 1 ? 1 : want) : nqt;
+  }
+  dim3 grid1(nchunk * a.H * a.B);
+  if (a.ali) vnr_launch(attn3_kernel<true>, grid1, dim3(256), lds, s, a, nqt, nchunk);
+  else if (!force_general && a.Tk <= 128 && !a.causal) vnr_launch(attn3_kernel<false>, grid1, dim3(256), lds, s, a, nqt, nchunk);
   else vnr_launch(attn3g_kernel, grid, dim3(256), lds, s, a, nqt);
   return hipGetLastError();
 }

@@ -229,6 +229,8 @@ hipError_t launch_gl_pass(const float* S, const float* ang0, const float* fr_pre
                           const float* window, int B, int T, int hop, int win, hipStream_t s);
 void voc_tables(int win, std::vector<float>& tw, std::vector<float>& window);     // host: twiddles exp(-2 pi j m / 2048) and periodic Hann, from float64
 hipError_t launch_gl_final(const float* fr, const float* window, const int32_t* frames, int B, int T, int hop, int win, float* wav, hipStream_t s);
+// tf.random.normal replacement: Philox-4x32-10 + Box-Muller, out[i] ~ N(0, stddev^2) (misc.hip)
+hipError_t launch_philox_normal(float* out, size_t n, unsigned long long seed, unsigned long long offset, float stddev, hipStream_t s);
 hipError_t launch_layer_norm(const float* x, const float* gamma, const float* beta, int rows,
                              int dim, float* y, hipStream_t s);
 hipError_t launch_positional_encoding(int T, int dim, float step, float* out, hipStream_t s);

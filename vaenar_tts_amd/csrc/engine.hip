@@ -62,8 +62,10 @@ struct FlowStep {
 };
 
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
-enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_COUNT };
-const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc"};
+// "gemm": tiled GEMM launches on the split-fp16 path (3 f16 MFMA FLOPs per algorithmic FLOP); "gemm_fp32": tiled GEMM launches on
+// exact fp32 MFMA; "chain": panel_chain_kernel launches (always split)
+enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_GEMM_F32, CLS_CHAIN, CLS_COUNT };
+const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc", "gemm_fp32", "chain"};
 
 // Dropout sites (one mask stream per tf.keras.layers.Dropout instance of the path): encoder.py:70,87; utils.py:73,84
 // (prenet / postnet convolutions); utils.py:11-17 (posterior PreNet, two uses of one layer); posterior.py:99,122
@@ -223,7 +225,7 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
     }
   }
   g.wide_tiles = h->gemm_wide_tiles ? 1 : 0;
-  ProfScope ps(h, CLS_GEMM, 2.0 * g.M * (double)g.N * g.K, 0.0);
+  ProfScope ps(h, g.Wsplit ? CLS_GEMM : CLS_GEMM_F32, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e) +
                                    " (M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) + " K=" + std::to_string(g.K) + ")");
@@ -278,7 +280,7 @@ int chain_params(vnr_handle h, ChainArgs& g) {
 int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   TRY(chain_params(h, g));
   g.rows64 = h->chain_rows64 ? 1 : 0;
-  ProfScope ps(h, CLS_GEMM, flops, 0.0);
+  ProfScope ps(h, CLS_CHAIN, flops, 0.0);
   hipError_t e = launch_panel_chain(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("panel chain launch: ") + hipGetErrorString(e));
   return VNR_OK;
@@ -1229,12 +1231,14 @@ int vnr_synchronize(vnr_handle h) {
 }
 
 int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int64_t* shape, int ndim) {
-  if (h && h->train) train_free(h);          // optimizer state and gradient tables point into the weight store
   if (!h || !path || !host || ndim < 0 || ndim > 4 || (ndim > 0 && !shape)) return fail(h, VNR_ERR_ARG, "bad argument");
   HIP_TRY(h, hipSetDevice(h->device));
   int64_t n = 1;
   std::vector<int64_t> shp;
   for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(h, VNR_ERR_ARG, "bad shape"); n *= shape[i]; shp.push_back(shape[i]); }
+  // optimizer state and gradient tables point into the weight store: they survive an in-place update of an existing variable
+  // (a checkpoint restore), but not a new or resized one
+  if (h->train) { auto it = h->w.find(path); if (it == h->w.end() || it->second.n != n || it->second.shape != shp) train_free(h); }
   Tensor& t = h->w[path];
   if (t.d && t.n != n) { hipFree(t.d); t.d = nullptr; }
   if (!t.d) HIP_TRY(h, hipMalloc((void**)&t.d, (size_t)n * sizeof(float)));
@@ -1664,6 +1668,46 @@ int vnr_get_gradient(vnr_handle h, const char* path, float* host, int64_t n) {
   return vnr_memcpy_d2h(h, host, h->train->g[it->second], (size_t)n * sizeof(float));
 }
 
+// ---- optimizer state (train.py:246-249: tf.train.Checkpoint(step, optimizer, model) saves / restores Adam's slots) --------
+static int opt_slot(vnr_handle h, const char* path, const char* slot, float** p, int64_t n) {
+  if (!h || !path || !slot) return fail(h, VNR_ERR_ARG, "null argument");
+  if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
+  HIP_TRY(h, hipSetDevice(h->device));
+  TRY(train_prepare(h));
+  auto it = h->train->index.find(path);
+  if (it == h->train->index.end()) return fail(h, VNR_ERR_WEIGHT, std::string("not a trainable variable: ") + path);
+  if (n != h->train->n[it->second]) return fail(h, VNR_ERR_ARG, std::string("size mismatch for ") + path);
+  if (!strcmp(slot, "m")) *p = h->train->m[it->second];
+  else if (!strcmp(slot, "v")) *p = h->train->v[it->second];
+  else return fail(h, VNR_ERR_ARG, std::string("unknown optimizer slot ") + slot + " (Adam has m and v)");
+  return VNR_OK;
+}
+int vnr_get_optimizer_slot(vnr_handle h, const char* path, const char* slot, float* host, int64_t n) {
+  float* p = nullptr;
+  if (!host) return fail(h, VNR_ERR_ARG, "null argument");
+  TRY(opt_slot(h, path, slot, &p, n));
+  return vnr_memcpy_d2h(h, host, p, (size_t)n * sizeof(float));
+}
+int vnr_set_optimizer_slot(vnr_handle h, const char* path, const char* slot, const float* host, int64_t n) {
+  float* p = nullptr;
+  if (!host) return fail(h, VNR_ERR_ARG, "null argument");
+  TRY(opt_slot(h, path, slot, &p, n));
+  return vnr_memcpy_h2d(h, p, host, (size_t)n * sizeof(float));
+}
+int vnr_get_optimizer_step(vnr_handle h, int64_t* iterations) {
+  if (!h || !iterations) return fail(h, VNR_ERR_ARG, "null argument");
+  *iterations = h->train ? (int64_t)h->train->step : 0;
+  return VNR_OK;
+}
+int vnr_set_optimizer_step(vnr_handle h, int64_t iterations) {
+  if (!h || iterations < 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
+  HIP_TRY(h, hipSetDevice(h->device));
+  TRY(train_prepare(h));
+  h->train->step = (long)iterations;
+  return VNR_OK;
+}
+
 // VAENAR.init (models.py:212-226): encoder(training=True) -> prior.init -> decoder(training=True, rf = max).
 static int init_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths, int B,
                      int Tt, int Tz, float pos_step, const float* d_eps, float* d_mel) {
@@ -1771,6 +1815,14 @@ int vnr_op_layer_norm(vnr_handle h, const float* d_x, const float* d_gamma, cons
   if (!h || !d_x || !d_gamma || !d_beta || !d_y) return fail(h, VNR_ERR_ARG, "null argument");
   HIP_TRY(h, hipSetDevice(h->device));
   return run_ln(h, d_x, d_gamma, d_beta, rows, dim, d_y);
+}
+
+// tf.random.normal(shape, stddev) on the device (prior.py:35, posterior.py:35)
+int vnr_random_normal(vnr_handle h, uint64_t seed, uint64_t offset, float stddev, float* d_out, size_t n) {
+  if (!h || !d_out) return fail(h, VNR_ERR_ARG, "null argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  RUN_MISC(h, launch_philox_normal(d_out, n, seed, offset, stddev, h->stream));
+  return VNR_OK;
 }
 
 int vnr_op_positional_encoding(vnr_handle h, int T, int dim, float step, float* d_out) {

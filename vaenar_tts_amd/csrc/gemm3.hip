@@ -199,37 +199,42 @@ panel_chain_kernel(const ChainArgs g) {
           afr[set][rt][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off(32 * rt + l31, akt, 4 + 2 * t + half));
         }
     };
-    read_a(0, 0);
+    // The k-loop exists three times, selected ONCE per stage by wave-uniform conditions, so that its body is straight-line
+    // code: with the selection inside the loop (round 1) the accumulator became a phi of three paths and the compiler drained
+    // the matrix pipe after every k-tile (s_nop 11 + sixteen v_mov_b64 copies of the accumulator between the MFMA groups of
+    // consecutive k-tiles: ~45 % MFMA issue).  Padding k-tiles (kt >= nk) are not skipped either: their weight operands arrive
+    // as zeros from the out-of-range refill, the MFMAs add exact zeros.
+    auto kloop = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;      // 0: D^T (lane <-> activation row), 1: D (V image stage), 2: idle wave
+      if (MODE != 2) read_a(0, 0);
 #pragma unroll 1
-    for (int kb = 0; kb < npad; kb += PF) {
+      for (int kb = 0; kb < npad; kb += PF) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int kt = kb + u;
-        read_a(kt + 1, (u + 1) & 1);
-        if (wave_on && kt < st.nk) {
-          if (!vswap) {
+        for (int u = 0; u < PF; ++u) {
+          if (MODE != 2) {
+            read_a(kb + u + 1, (u + 1) & 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)                                   // D^T: lane <-> activation row
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int rt = 0; rt < RT; ++rt) {
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t + 1], acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
-              }
-          } else {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)                                   // D: lane <-> output column (V image stage)
-#pragma unroll
-              for (int rt = 0; rt < RT; ++rt) {
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t], acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t + 1], wreg[u][2 * t], acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t + 1], acc[rt], 0, 0, 0);
+                if (MODE == 0) {
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t], afr[u & 1][rt][2 * t + 1], acc[rt], 0, 0, 0);
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][2 * t + 1], afr[u & 1][rt][2 * t], acc[rt], 0, 0, 0);
+                } else {
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t], acc[rt], 0, 0, 0);
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t + 1], wreg[u][2 * t], acc[rt], 0, 0, 0);
+                  acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[u & 1][rt][2 * t], wreg[u][2 * t + 1], acc[rt], 0, 0, 0);
+                }
               }
           }
+          fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)
         }
-        fetch(u);                                                         // refill this slot PF tiles ahead (flat sequence)
       }
-    }
+    };
+    if (!wave_on) kloop(std::integral_constant<int, 2>{});
+    else if (!vswap) kloop(std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 1>{});
     stamp(2 + 2 * si);
     wstamp(si, 1);
     // ---- FFN second layer: accumulate over hidden chunks (modes 1,2: no epilogue yet) ----------------------------------

@@ -640,4 +640,46 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
   return hipGetLastError();
 }
 
+
+// ---- tf.random.normal on the device (prior.py:35, posterior.py:35): Philox-4x32-10 counter-based generator -------------------
+// Element block j (4 normals: elements 4j .. 4j+3) uses counter (lo32(j + offset), hi32(j + offset), 0, 0) and key (lo32(seed),
+// hi32(seed)); ten rounds with the published multipliers / Weyl constants; the four 32-bit outputs x0..x3 make two Box-Muller
+// pairs: u = ((x >> 8) + 0.5) 2^-24 in (0, 1), r = sqrt(-2 ln u_a), theta = 2 pi u_b -> r cos(theta), r sin(theta).  Same
+// statement in oracle/vaenar_numpy.py (philox_normal).  TensorFlow's own Philox stream layout is not reproduced (its op-level
+// seeding is unavailable without TensorFlow): parity runs inject eps, this generator serves temperature > 0 runs.
+namespace {
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+  const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+  const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+  const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+  c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+}
+__global__ void __launch_bounds__(256) philox_normal_kernel(float* out, size_t n, unsigned long long seed, unsigned long long offset, float stddev) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (4 * j >= n) return;
+  const unsigned long long ctr = (unsigned long long)j + offset;
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  const float k24 = 1.0f / 16777216.0f;
+  const float ua = ((float)(c0 >> 8) + 0.5f) * k24, ub = ((float)(c1 >> 8) + 0.5f) * k24;
+  const float uc = ((float)(c2 >> 8) + 0.5f) * k24, ud = ((float)(c3 >> 8) + 0.5f) * k24;
+  const float r0 = sqrtf(-2.0f * logf(ua)), r1 = sqrtf(-2.0f * logf(uc));
+  float s0, q0, s1, q1;
+  sincosf(6.28318530717958647692f * ub, &s0, &q0);
+  sincosf(6.28318530717958647692f * ud, &s1, &q1);
+  const float z[4] = {stddev * r0 * q0, stddev * r0 * s0, stddev * r1 * q1, stddev * r1 * s1};
+  if (4 * j + 3 < n && !(reinterpret_cast<uintptr_t>(out) & 15)) *reinterpret_cast<float4*>(out + 4 * j) = make_float4(z[0], z[1], z[2], z[3]);
+  else
+    for (int e = 0; e < 4; ++e) if (4 * j + e < n) out[4 * j + e] = z[e];
+}
+}  // namespace
+hipError_t launch_philox_normal(float* out, size_t n, unsigned long long seed, unsigned long long offset, float stddev, hipStream_t s) {
+  if (!n) return hipSuccess;
+  const size_t blocks = ((n + 3) / 4 + 255) / 256;
+  vnr_launch(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, n, seed, offset, stddev);
+  return hipGetLastError();
+}
+
 }  // namespace vnr

@@ -102,7 +102,7 @@ class VAENAR:
             rl = self._len_cache[key] = eng.to_device(reduced, np.int32)
         C = self.hps.Common.latent_dim
         if eps is None and float(temperature) != 0.0:
-            eps = (np.float32(temperature) * self.prior.rng.standard_normal((B, Tz, C))).astype(np.float32)
+            eps = self.prior.draw((B, Tz, C), float(temperature))        # on the device (prior.py:35)
         eps_d = None if eps is None else eng.asarray(eps, np.float32)
         if eps_d is not None:
             assert eps_d.shape == (B, Tz, C), (eps_d.shape, (B, Tz, C))
@@ -128,7 +128,7 @@ class VAENAR:
         Returns (decoded_outs [B,Tm,out_dim], l2_loss, kl_divergence, length_loss, dec_alignments); with
         reduce_loss the three losses are means over the batch (models.py:84,92,101), otherwise [B] vectors.
         ``eps`` [B,1,Tz,C] or [B,Tz,C] replaces tf.random.normal of posterior.reparameterize
-        (posterior.py:35); default: drawn from self.prior.rng.  The backward pass / optimizer is not built."""
+        (posterior.py:35); default: drawn on the device (prior.draw).  (The backward pass and Adam: ``train_step``.)"""
         assert self.n_sample == 1
         eng = self.engine
         eng.set_option("training", 1 if training else 0)
@@ -147,7 +147,7 @@ class VAENAR:
         Tz = (Tm + rf - 1) // rf
         C = self.hps.Common.latent_dim
         if eps is None:
-            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+            eps = self.prior.draw((B, Tz, C))                              # on the device (posterior.py:35 / prior.py:35)
         eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:128
         dec = self.decoder
@@ -189,7 +189,7 @@ class VAENAR:
         tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
         C = self.hps.Common.latent_dim
         if eps is None:
-            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+            eps = self.prior.draw((B, Tz, C))                              # on the device (posterior.py:35 / prior.py:35)
         eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:214
         mel = eng.empty((B, Tz * rf, self.decoder.out_dim))
@@ -217,7 +217,7 @@ class VAENAR:
         Tz = (Tm + rf - 1) // rf
         C = self.hps.Common.latent_dim
         if eps is None:
-            eps = self.prior.rng.standard_normal((B, Tz, C)).astype(np.float32)
+            eps = self.prior.draw((B, Tz, C))                              # on the device (posterior.py:35 / prior.py:35)
         eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)
         tr = self.hps.Train
@@ -239,6 +239,47 @@ class VAENAR:
             sh = spec[k]
             out[k] = self.engine.get_gradient(k, sh if len(sh) else (1,)).reshape(sh)
         return out
+
+    # optimizer state: the `optimizer` part of tf.train.Checkpoint(step, optimizer, model) (train.py:246-255) ------------
+    def get_optimizer_state(self):
+        """({path: Adam m}, {path: Adam v}, iterations) of every trainable variable (zeros / 0 before the first step)."""
+        from .weights import weight_spec, is_trainable
+        spec = weight_spec(self.hps)
+        m, v = {}, {}
+        for k in (p for p in spec if is_trainable(p)):
+            sh = spec[k]
+            m[k] = self.engine.get_optimizer_slot(k, "m", sh if len(sh) else (1,)).reshape(sh)
+            v[k] = self.engine.get_optimizer_slot(k, "v", sh if len(sh) else (1,)).reshape(sh)
+        return m, v, self.engine.get_optimizer_step()
+
+    def set_optimizer_state(self, m, v, iterations):
+        """Restore Adam's slots and iteration counter (after ``load_weights``): the next train_step continues the
+        interrupted run -- same moments, same bias correction."""
+        for k, a in m.items():
+            self.engine.set_optimizer_slot(k, "m", a)
+        for k, a in v.items():
+            self.engine.set_optimizer_slot(k, "v", a)
+        self.engine.set_optimizer_step(int(iterations))
+
+    def save_checkpoint(self, prefix, step=0, save_counter=1):
+        """``manager.save()`` of train.py:262,301: TensorFlow tensor bundle ``<prefix>.index`` / ``.data-*`` with the model
+        variables, Adam's slots and counters, the epoch counter ``step`` (tf_checkpoint.save_training_checkpoint)."""
+        from .tf_checkpoint import save_training_checkpoint
+        m, v, it = self.get_optimizer_state()
+        save_training_checkpoint(prefix, self.get_weights(), m, v, iterations=it, step=step, save_counter=save_counter,
+                                 learning_rate=self.hps.Train.learning_rate)
+        return prefix
+
+    def restore_checkpoint(self, prefix):
+        """``checkpoint.restore(manager.latest_checkpoint)`` of train.py:249: variables, optimizer slots and counters.
+        Returns the stored epoch counter ``step`` (train.py:252); bundles without optimizer entries restore the model only."""
+        from .tf_checkpoint import load_training_checkpoint
+        ck = load_training_checkpoint(prefix, self.hps, strict=False)
+        self.engine.load_weights(ck["weights"])
+        if ck["m"] and ck["v"]:
+            self.set_optimizer_state(ck["m"], ck["v"], ck["iterations"] or 0)
+        self._len_cache = {}
+        return ck["step"] or 0
 
     def get_weights(self, paths=None):
         """{path: ndarray} read back from the engine (after init / training-mode forwards)."""

@@ -11,13 +11,26 @@ class TransformerPrior(EngineModule):
         if inverse:
             raise NotImplementedError("inverse=True flows are not used by LJHPS/DataBakerHPS (hparams.py:344)")
         self.channels = channels
-        self.rng = np.random.Generator(np.random.PCG64(0))
+        self.noise_seed = 0          # seed / running offset of the device generator (vnr_random_normal): tf.random.normal's role
+        self.noise_offset = 0
+
+    def seed(self, seed):
+        """Re-seed the device noise stream (tf.random.set_seed's role for prior.py:35 / posterior.py:35)."""
+        self.noise_seed, self.noise_offset = int(seed), 0
+
+    def draw(self, shape, stddev=1.0):
+        """tf.random.normal(shape, stddev=stddev) ON THE DEVICE: a Philox-4x32 stream keyed by ``noise_seed``; successive
+        draws take disjoint counter ranges.  Nothing crosses PCIe."""
+        n = int(np.prod(shape))
+        a = self.engine.random_normal(shape, self.noise_seed, self.noise_offset, stddev)
+        self.noise_offset += (n + 3) // 4
+        return a
 
     def sample(self, targets_lengths, condition_inputs, condition_lengths=None, training=None,
                temperature=1.0, eps=None, return_logprobs=True):
         """prior.py:154-169.  ``eps`` (already scaled by the temperature, [B, max(len), C]) replaces
-        tf.random.normal (prior.py:35) when given; otherwise it is drawn on the host from
-        ``self.rng`` (temperature 0 -> exact zeros, the inference.py:95 default)."""
+        tf.random.normal (prior.py:35) when given; otherwise it is drawn on the device (``draw``; temperature 0 -> exact zeros,
+        the inference.py:95 default -- no noise buffer at all)."""
         self._no_training(training)
         e = self.engine
         lens_h = targets_lengths.numpy() if hasattr(targets_lengths, "numpy") and not isinstance(
@@ -29,7 +42,7 @@ class TransformerPrior(EngineModule):
         zl = e.asarray(targets_lengths if not isinstance(targets_lengths, np.ndarray) else lens_h, np.int32)
         tl = self._i32(condition_lengths, B, Tt)
         if eps is None and float(temperature) != 0.0:
-            eps = (np.float32(temperature) * self.rng.standard_normal((B, Tz, self.channels))).astype(np.float32)
+            eps = self.draw((B, Tz, self.channels), float(temperature))
         eps_d = None if eps is None else self._f32(eps)
         if eps_d is not None:
             assert eps_d.shape == (B, Tz, self.channels), (eps_d.shape, (B, Tz, self.channels))

@@ -17,7 +17,7 @@ Object-based (TF2 / Keras) checkpoints name a variable by its attribute path fro
 ``model/<attr>/<attr>/.../.ATTRIBUTES/VARIABLE_VALUE`` (list elements by index) -- exactly the paths of
 ``vaenar_tts_amd/weights.py`` under the root attribute ``model`` (train.py:246).  Optimizer slots
 (``optimizer/...`` and ``.../.OPTIMIZER_SLOT/...``), the ``step`` counter and the ``_CHECKPOINTABLE_OBJECT_GRAPH`` string are
-skipped by ``load_model_weights``.
+skipped by ``load_model_weights`` and read by ``load_training_checkpoint``.
 
 ``write_checkpoint`` produces well-formed bundles (readable by ``tf.train.load_checkpoint`` / ``list_variables``).
 ``save_model_weights`` adds the ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry that object-based ``restore`` walks: a serialized
@@ -26,7 +26,9 @@ children{1: node_id, 2: local_name}, 2: attributes{1: name, 2: full_name, 3: che
 root, one node per attribute-path prefix (list elements by index, like Keras' list wrappers), a variable node carrying the
 attribute ``VARIABLE_VALUE`` with its checkpoint key -- stored as a DT_STRING scalar in the bundle's string layout (varint64
 lengths, fixed32 masked CRC-32C of the lengths as uint32, then the bytes; the entry CRC runs over lengths-as-uint32, that
-checksum and the bytes).  Optimizer slot variables are not written (``expect_partial()`` in the reference, inference.py:123).
+checksum and the bytes).  ``save_model_weights`` writes the variables only (what ``expect_partial()`` restores at
+inference.py:123); ``save_training_checkpoint`` / ``load_training_checkpoint`` / ``CheckpointManager`` are the training
+checkpoint of train.py:246-249 (model + Adam slots + iteration / epoch counters, ``checkpoint`` state file, max_to_keep).
 
 PARITY UNPINNED against bundles written by real TensorFlow (none exist in this environment; the published checkpoints of
 the reference are behind a Google-Drive link, README.md:4): the format statements above are the published ones, pinned by
@@ -281,42 +283,66 @@ def write_checkpoint(prefix, tensors):
 OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
 
 
-def object_graph_proto(paths, root="model"):
-    """Serialized TrackableObjectGraph for variables at the attribute paths ``root/<path>`` (see the module docstring)."""
-    nodes = [{"children": [], "attr": None}]                      # node 0: the tf.train.Checkpoint object
+def object_graph_proto(paths, root="model", extra=(), slots=()):
+    """Serialized TrackableObjectGraph for variables at the attribute paths ``root/<path>`` (see the module docstring).
+    ``extra``: further variable attribute paths from the Checkpoint root (``step``, ``save_counter``, ``optimizer/iter`` ...);
+    ``slots``: (original variable path under ``root``, slot name) pairs -- each gets its own node with the checkpoint key
+    ``root/<path>/.OPTIMIZER_SLOT/optimizer/<slot>/.ATTRIBUTES/VARIABLE_VALUE`` and a ``slot_variables`` reference
+    ``{1: original_variable_node_id, 2: slot_name, 3: slot_variable_node_id}`` on the ``optimizer`` node."""
+    nodes = [{"children": [], "attr": None, "slots": []}]         # node 0: the tf.train.Checkpoint object
     index = {(): 0}
-    for p in sorted(paths):
-        parts = tuple([root] + p.split("/"))
+
+    def add(parts):
         for d in range(1, len(parts) + 1):
             if parts[:d] not in index:
                 index[parts[:d]] = len(nodes)
-                nodes.append({"children": [], "attr": None})
+                nodes.append({"children": [], "attr": None, "slots": []})
                 nodes[index[parts[:d - 1]]]["children"].append((index[parts[:d]], parts[d - 1]))
-        nodes[index[parts]]["attr"] = "/".join(parts) + SUFFIX
+        return index[parts]
+
+    for p in sorted(paths):
+        parts = tuple([root] + p.split("/"))
+        nodes[add(parts)]["attr"] = ("/".join(parts) + SUFFIX, "/".join(parts))
+    for p in sorted(extra):
+        parts = tuple(p.split("/"))
+        nodes[add(parts)]["attr"] = (p + SUFFIX, p)
+    if slots:
+        opt = add(("optimizer",))
+        for p, slot in sorted(slots):
+            orig = index[tuple([root] + p.split("/"))]
+            nid = len(nodes)
+            key = "%s/%s/.OPTIMIZER_SLOT/optimizer/%s%s" % (root, p, slot, SUFFIX)
+            nodes.append({"children": [], "attr": (key, "Adam/%s/%s" % (p, slot)), "slots": []})
+            nodes[opt]["slots"].append((orig, slot, nid))
     out = b""
     for n in nodes:
         body = b"".join(_ld(1, _field(1, 0, _varint(cid)) + _ld(2, name.encode())) for cid, name in n["children"])
         if n["attr"]:
-            key = n["attr"]
-            body += _ld(2, _ld(1, b"VARIABLE_VALUE") + _ld(2, key[:-len(SUFFIX)].encode()) + _ld(3, key.encode()))
+            key, full = n["attr"]
+            body += _ld(2, _ld(1, b"VARIABLE_VALUE") + _ld(2, full.encode()) + _ld(3, key.encode()))
+        for orig, slot, nid in n["slots"]:
+            body += _ld(3, _field(1, 0, _varint(orig)) + _ld(2, slot.encode()) + _field(3, 0, _varint(nid)))
         out += _ld(1, body)
     return out
 
 
-def parse_object_graph(buf):
-    """[(children [(node_id, local_name)], attributes [(name, full_name, checkpoint_key)])] of a TrackableObjectGraph."""
+def parse_object_graph(buf, with_slots=False):
+    """[(children [(node_id, local_name)], attributes [(name, full_name, checkpoint_key)])] of a TrackableObjectGraph
+    (``with_slots``: a third element [(original_variable_node_id, slot_name, slot_variable_node_id)])."""
     nodes = []
     for num, _, node in _parse(buf):
         if num != 1:
             continue
-        children, attrs = [], []
+        children, attrs, slots = [], [], []
         for n2, _, val in _parse(node):
             f = {k: v for k, _, v in _parse(val)}
             if n2 == 1:
                 children.append((int(f.get(1, 0)), f.get(2, b"").decode()))
             elif n2 == 2:
                 attrs.append((f.get(1, b"").decode(), f.get(2, b"").decode(), f.get(3, b"").decode()))
-        nodes.append((children, attrs))
+            elif n2 == 3:
+                slots.append((int(f.get(1, 0)), f.get(2, b"").decode(), int(f.get(3, 0))))
+        nodes.append((children, attrs, slots) if with_slots else (children, attrs))
     return nodes
 
 
@@ -325,3 +351,114 @@ def save_model_weights(prefix, weights, root="model"):
     tensors = {"%s/%s%s" % (root, p, SUFFIX): np.asarray(a, np.float32) for p, a in weights.items()}
     tensors[OBJECT_GRAPH_KEY] = object_graph_proto(weights.keys(), root)          # bytes -> DT_STRING scalar
     write_checkpoint(prefix, tensors)
+
+
+# ---- the training checkpoint of train.py:246-249: tf.train.Checkpoint(step, optimizer, model) + CheckpointManager ----------
+def save_training_checkpoint(prefix, weights, opt_m, opt_v, iterations, step, save_counter, learning_rate=1.25e-4, beta_1=0.9,
+                             beta_2=0.999, decay=0.0, root="model"):
+    """What ``manager.save()`` writes at train.py:262,301: the model variables, Adam's slots
+    (``model/<path>/.OPTIMIZER_SLOT/optimizer/{m,v}/.ATTRIBUTES/VARIABLE_VALUE``) and hyper-parameter variables
+    (``optimizer/{iter,learning_rate,beta_1,beta_2,decay}``), the epoch counter ``step`` (int64) and ``save_counter``."""
+    t = {"%s/%s%s" % (root, p, SUFFIX): np.asarray(a, np.float32) for p, a in weights.items()}
+    for slot, tree in (("m", opt_m), ("v", opt_v)):
+        for p, a in tree.items():
+            t["%s/%s/.OPTIMIZER_SLOT/optimizer/%s%s" % (root, p, slot, SUFFIX)] = np.asarray(a, np.float32)
+    extra = {"step": np.asarray(step, np.int64), "save_counter": np.asarray(save_counter, np.int64),
+             "optimizer/iter": np.asarray(iterations, np.int64), "optimizer/learning_rate": np.asarray(learning_rate, np.float32),
+             "optimizer/beta_1": np.asarray(beta_1, np.float32), "optimizer/beta_2": np.asarray(beta_2, np.float32),
+             "optimizer/decay": np.asarray(decay, np.float32)}
+    for k, a in extra.items():
+        t[k + SUFFIX] = a
+    slots = [(p, "m") for p in opt_m] + [(p, "v") for p in opt_v]
+    t[OBJECT_GRAPH_KEY] = object_graph_proto(weights.keys(), root, extra=extra.keys(), slots=slots)
+    write_checkpoint(prefix, t)
+
+
+def load_training_checkpoint(prefix, hps=None, root="model", strict=True):
+    """``checkpoint.restore(manager.latest_checkpoint)`` of train.py:249: {"weights", "m", "v": {path: float32 ndarray},
+    "iterations", "step", "save_counter": int (None when the bundle has no such entry)}."""
+    pre, tag = root + "/", "/.OPTIMIZER_SLOT/optimizer/"
+    out = {"weights": {}, "m": {}, "v": {}, "iterations": None, "step": None, "save_counter": None}
+    for k, a in read_checkpoint(prefix).items():
+        if not k.endswith(SUFFIX):
+            continue
+        k = k[:-len(SUFFIX)]
+        if k.startswith(pre) and tag in k:
+            p, slot = k[len(pre):].split(tag)
+            if slot in ("m", "v"):
+                out[slot][p] = a.astype(np.float32)
+        elif k.startswith(pre):
+            out["weights"][k[len(pre):]] = a.astype(np.float32)
+        elif k == "optimizer/iter":
+            out["iterations"] = int(a)
+        elif k in ("step", "save_counter"):
+            out[k] = int(a)
+    if hps is not None:
+        from .weights import weight_spec
+        spec = weight_spec(hps)
+        missing = [p for p in spec if p not in out["weights"]]
+        bad = [p for p in spec if p in out["weights"] and tuple(out["weights"][p].shape) != tuple(spec[p])]
+        if strict and (missing or bad):
+            raise KeyError("checkpoint %s: missing %s, mis-shaped %s" % (prefix, missing[:5], bad[:5]))
+    return out
+
+
+class CheckpointManager:
+    """tf.train.CheckpointManager(checkpoint, directory, max_to_keep=20) as train.py:248 uses it: files ``ckpt-<save_counter>``,
+    a ``checkpoint`` state file (text-format CheckpointState: ``model_checkpoint_path`` + ``all_model_checkpoint_paths``) that
+    ``latest_checkpoint`` reads, oldest files deleted beyond ``max_to_keep``.  (keep_checkpoint_every_n_hours is not mirrored.)"""
+
+    def __init__(self, directory, max_to_keep=20, checkpoint_name="ckpt"):
+        import os
+        self.directory, self.max_to_keep, self.name = directory, max_to_keep, checkpoint_name
+        os.makedirs(directory, exist_ok=True)
+        self.checkpoints = self._read_state()
+
+    def _state_path(self):
+        import os
+        return os.path.join(self.directory, "checkpoint")
+
+    def _read_state(self):
+        import os
+        import re
+        names = []
+        if os.path.exists(self._state_path()):
+            for line in open(self._state_path()):
+                m = re.match(r'\s*all_model_checkpoint_paths:\s*"(.*)"', line)
+                if m:
+                    names.append(m.group(1))
+        found = [n for n in names if os.path.exists(os.path.join(self.directory, os.path.basename(n) + ".index"))]
+        if not found:      # no (usable) state file: fall back to the files themselves, ordered by their NUMERIC counter
+            pat = re.compile(r"^%s-(\d+)\.index$" % re.escape(self.name))
+            nums = sorted(int(m.group(1)) for m in (pat.match(f) for f in os.listdir(self.directory)) if m)
+            found = ["%s-%d" % (self.name, n) for n in nums]
+        return [os.path.basename(n) for n in found]
+
+    @property
+    def latest_checkpoint(self):
+        import os
+        return os.path.join(self.directory, self.checkpoints[-1]) if self.checkpoints else None
+
+    def next_counter(self):
+        return (int(self.checkpoints[-1].rsplit("-", 1)[1]) + 1) if self.checkpoints else 1
+
+    def save(self, write_fn):
+        """``write_fn(prefix, save_counter)`` writes the bundle; returns the prefix (``<directory>/ckpt-<save_counter>``)."""
+        import glob
+        import os
+        n = self.next_counter()
+        name = "%s-%d" % (self.name, n)
+        prefix = os.path.join(self.directory, name)
+        write_fn(prefix, n)
+        self.checkpoints.append(name)
+        while self.max_to_keep and len(self.checkpoints) > self.max_to_keep:
+            old = self.checkpoints.pop(0)
+            for f in glob.glob(os.path.join(self.directory, old + ".index")) + glob.glob(os.path.join(self.directory, old + ".data-*")):
+                os.remove(f)
+        tmp = self._state_path() + ".tmp"
+        with open(tmp, "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % self.checkpoints[-1])
+            for c in self.checkpoints:
+                f.write('all_model_checkpoint_paths: "%s"\n' % c)
+        os.replace(tmp, self._state_path())
+        return prefix

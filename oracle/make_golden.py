@@ -117,6 +117,58 @@ def build_train(name="train_tiny"):
     return out
 
 
+# Fixtures of the TRAINING path produced by the REFERENCE's own Python (models.VAENAR / modules.* imported from /root/reference and
+# executed over oracle/tf_shim_torch: float64 torch tensors, torch.autograd in place of tf.GradientTape): VAENAR.call with
+# training=True (Dropout on the engine's counter-based masks, BatchNormalization on batch statistics), the loss of train.py:135
+# and d loss / d every trainable variable, the moving statistics after the forward, and VAENAR.init (models.py:212-226).
+REF_TRAIN_CASES = {
+    # name: (hps factory, B, T_text, T_mel, text_step, mel_step, rf, weight seed)
+    "refshim_train_tiny": (tiny_hps, 3, 11, 40, 3, 7, 2, SEED),
+    "refshim_train_lj": (lambda: LJHPS, 2, 19, 46, 5, 9, 2, SEED),
+}
+
+
+def build_ref_train(name):
+    from oracle.run_reference_on_shim import reference_call_training, reference_init, reference_train_step
+    mk, B, Tt, Tm, ts, ms, rf, seed = REF_TRAIN_CASES[name]
+    hps = mk()
+    w = init_weights(hps, seed=seed, mode="synthetic")
+    b = make_batch(B, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
+                   text_step=ts, mel_step=ms)
+    r = np.random.Generator(np.random.PCG64(31))
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, (Tm + rf - 1) // rf, hps.Common.latent_dim)).astype(np.float32)
+    out = dict(ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], mels=mels, eps=eps,
+               reduction_factor=np.int64(rf), dropout_seed=np.int64(11), weight_seed=np.int64(seed),
+               weights_sha256=np.frombuffer(weights_digest(w).encode(), np.uint8))
+    for tag, kw in (("kw1", 1.0), ("kw1e-5", 1e-5)):           # kl weight 1 (all terms visible) and the schedule's 1e-5
+        sc, g, preds, stats = reference_train_step(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps, rf, kw, 11)
+        out[tag + "/kl_weight"] = np.float64(kw)
+        out[tag + "/scalars"] = np.array([sc["loss"], sc["mel_l2"], sc["kl"], sc["length_l2"]], np.float64)
+        for k in sorted(g):
+            out[tag + "/gdig/" + k] = digest(g[k])
+            if tag == "kw1" and g[k].size <= 4096:              # small variables in full (biases, LayerNorm / ActNorm / scalars ...)
+                out["kw1/grad/" + k] = g[k].astype(np.float32)
+        if tag == "kw1":
+            out["predictions"] = preds.astype(np.float32)
+            for k, v in stats.items():
+                out["moving/" + k] = v.astype(np.float64)
+    outs, l2, kl, ll, ali = reference_call_training(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps, rf, 11)
+    out.update(call_l2=l2.astype(np.float64), call_kl=kl.astype(np.float64), call_length=ll.astype(np.float64))
+    for k, v in ali.items():
+        out["call_ali/" + k] = v.astype(np.float32)
+    # VAENAR.init at max_reduction_factor (train.py:176-179, 262)
+    mrf = hps.Common.max_reduction_factor
+    Tz5 = int(((b["mel_lengths"].astype(np.int64) + mrf - 1) // mrf).max())
+    eps5 = r.standard_normal((B, Tz5, hps.Common.latent_dim)).astype(np.float32)
+    mel, after = reference_init(hps, w, b["ids"], b["mel_lengths"], b["text_lengths"], eps5, 5)
+    out.update(init_eps=eps5, init_dropout_seed=np.int64(5), init_mel=mel.astype(np.float32))
+    for k, v in after.items():
+        if np.abs(v - np.asarray(w[k], np.float64)).max() > 0:          # what init changed: ActNorm variables, BN moving statistics
+            out["init/" + k] = v.astype(np.float64)
+    return out
+
+
 def digest(a):
     """[16 samples at fixed strided flat positions | sum | l2 norm | max abs] of an array, float64."""
     f = np.asarray(a, np.float64).reshape(-1)
@@ -136,6 +188,9 @@ def main():
         for name in REF_CASES:
             np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref(name))
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python over the tf shim)")
+        for name in REF_TRAIN_CASES:
+            np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref_train(name))
+            print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python, training mode, over the torch tf shim)")
 
 
 if __name__ == "__main__":

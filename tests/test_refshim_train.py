@@ -1,0 +1,165 @@
+"""Training mode pinned by the REFERENCE's own Python.
+
+tests/golden/refshim_train_{tiny,lj}.npz are produced by /root/reference's ``models.VAENAR`` executed over
+oracle/tf_shim_torch (float64 torch tensors; torch.autograd stands in for tf.GradientTape): ``model(..., training=True)``
+with the loss of train.py:135 and d loss / d every trainable variable, the BN moving statistics after the forward, and
+``model.init`` (models.py:212-226).  Here:
+  * CPU: the fixtures are reproducible from the reference (this container only), and both restatements
+    (oracle/vaenar_torch.py autograd, oracle/vaenar_numpy.py forward / init) agree with them;
+  * GPU: the HIP training step, training-mode forward and init are compared with the fixtures directly -- reference-made
+    numbers, no builder-authored oracle in the loop.
+TensorFlow's kernel numerics stay unpinned (the shim restates them)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.make_golden import REF_TRAIN_CASES, SEED, digest, weights_digest
+from vaenar_tts_amd.weights import init_weights
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_REF = os.path.isdir("/root/reference")
+
+
+def _load(name):
+    with np.load(os.path.join(GOLD, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    hps = REF_TRAIN_CASES[name][0]()
+    w = init_weights(hps, seed=int(g["weight_seed"]), mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode(), "synthetic weight generator changed"
+    return g, hps, w
+
+
+def _dig_close(d, ref, n, rel):
+    mx = max(ref[18], 1e-30)
+    return (np.abs(d[:16] - ref[:16]).max() <= rel * mx + 1e-13 and abs(d[16] - ref[16]) <= rel * mx * max(1.0, np.sqrt(n)) * 4 + 1e-12
+            and abs(d[17] - ref[17]) <= rel * max(ref[17], 1e-30) + 1e-13 and abs(d[18] - ref[18]) <= rel * mx + 1e-13)
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference checkout only exists in the build container")
+def test_fixture_is_reproducible_from_the_reference():
+    """oracle/make_golden.build_ref_train re-run now == the committed file (tiny case; diff 0)."""
+    from oracle.make_golden import build_ref_train
+    fresh = build_ref_train("refshim_train_tiny")
+    with np.load(os.path.join(GOLD, "refshim_train_tiny.npz")) as z:
+        assert set(z.files) == set(fresh)
+        for k in z.files:
+            assert np.array_equal(z[k], fresh[k]), k
+
+
+@pytest.mark.parametrize("name", sorted(REF_TRAIN_CASES))
+def test_autograd_restatement_matches_reference_training(name):
+    """oracle/vaenar_torch.py (the checker of tests/test_gpu_train.py) against the reference's own training forward + autograd."""
+    from oracle.vaenar_torch import TorchOracle
+    g, hps, w = _load(name)
+    rf, seed = int(g["reduction_factor"]), int(g["dropout_seed"])
+    for tag in ("kw1", "kw1e-5"):
+        kw = float(g[tag + "/kl_weight"])
+        o = TorchOracle(hps, w)
+        grads, sc = o.gradients(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], rf, g["eps"], kl_weight=kw,
+                                length_weight=hps.Train.length_weight, dropout_seed=seed)
+        np.testing.assert_allclose([sc["loss"], sc["mel_l2"], sc["kl"], sc["length_l2"]], g[tag + "/scalars"], rtol=2e-6)      # (the restatement keeps TF's float32 pos_step = 5.59f / 2.0f; the shim divides in float64)
+        bad = [k for k in grads if not _dig_close(digest(grads[k]), g[tag + "/gdig/" + k], grads[k].size, 1e-5)]
+        assert not bad, bad[:8]
+        if tag == "kw1":
+            for k in grads:
+                if ("kw1/grad/" + k) in g:
+                    ref = g["kw1/grad/" + k]
+                    assert np.abs(grads[k] - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-9, k
+            for k in g:
+                if k.startswith("moving/"):                       # BN moving statistics after ONE training forward
+                    np.testing.assert_allclose(o.w[k[7:]].detach().numpy(), g[k], rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("name", sorted(REF_TRAIN_CASES))
+def test_numpy_oracle_matches_reference_training_forward_and_init(name):
+    """oracle/vaenar_numpy.py: VAENAR.call(training=True) per-utterance terms and VAENAR.init against the reference's."""
+    from oracle.vaenar_numpy import Oracle
+    g, hps, w = _load(name)
+    rf = int(g["reduction_factor"])
+    o = Oracle(hps, {k: np.array(v, copy=True) for k, v in w.items()}, np.float64)
+    o.update_moving_stats = True
+    o.dropout_seed = int(g["dropout_seed"])
+    outs, l2, kl, ll, ali = o.call(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], rf, True, False, g["eps"][:, None].astype(np.float64))
+    np.testing.assert_allclose(outs, g["predictions"], atol=2e-6)
+    np.testing.assert_allclose(l2, g["call_l2"], rtol=1e-7)
+    np.testing.assert_allclose(ll, g["call_length"], rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(kl, g["call_kl"], rtol=1e-6, atol=2e-2)      # float32-cast slogdet in the oracle (flow.py:127)
+    for k in ali:
+        np.testing.assert_allclose(ali[k], g["call_ali/" + k], atol=1e-6)
+    for k in g:
+        if k.startswith("moving/"):
+            np.testing.assert_allclose(o.w[k[7:]], g[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    o2 = Oracle(hps, {k: np.array(v, copy=True) for k, v in w.items()}, np.float64)
+    o2.update_moving_stats = True
+    o2.dropout_seed = int(g["init_dropout_seed"])
+    mel = o2.init(g["ids"], g["mel_lengths"], g["text_lengths"], g["init_eps"].astype(np.float64))
+    np.testing.assert_allclose(mel, g["init_mel"], atol=2e-6)
+    changed = [k[5:] for k in g if k.startswith("init/")]
+    assert any(k.endswith("/0/log_scale") for k in changed) and any(k.endswith("moving_mean") for k in changed)
+    for k in changed:
+        np.testing.assert_allclose(o2.w[k], g["init/" + k], rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+# ---- the HIP path against the reference-made fixtures ------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(REF_TRAIN_CASES))
+def test_hip_training_step_matches_reference_python(name):
+    from vaenar_tts_amd.models import VAENAR
+    g, hps, w = _load(name)
+    rf, seed = int(g["reduction_factor"]), int(g["dropout_seed"])
+    for tag in ("kw1", "kw1e-5"):
+        model = VAENAR(hps, weights=w)
+        try:
+            out = model.train_step(g["ids"], g["mels"], g["text_lengths"], g["mel_lengths"], float(g[tag + "/kl_weight"]), rf, eps=g["eps"],
+                                   dropout_seed=seed, apply_update=False)
+            grads = model.gradients()
+            moving = model.get_weights([k[7:] for k in g if k.startswith("moving/")]) if tag == "kw1" else {}
+        finally:
+            model.engine.close()
+        ref = g[tag + "/scalars"]                                  # loss, mel_l2, kl, length_l2 ; train_step returns (loss, mel_l2, kl, length_l2)
+        np.testing.assert_allclose(out, ref, rtol=2e-4)
+        bad = []
+        for k in grads:
+            d, rd = digest(grads[k]), g[tag + "/gdig/" + k]
+            mx = max(rd[18], 1e-30)
+            ok = (np.abs(d[:16] - rd[:16]).max() <= 2e-3 * mx + 1e-7 and abs(d[17] - rd[17]) <= 2e-3 * rd[17] + 1e-7
+                  and abs(d[18] - rd[18]) <= 2e-3 * mx + 1e-7)
+            if ok and ("kw1/grad/" + k) in g and tag == "kw1":
+                full = g["kw1/grad/" + k]
+                ok = np.abs(grads[k] - full).max() <= 2e-3 * np.abs(full).max() + 1e-7
+            if not ok:
+                bad.append(k)
+        assert not bad, (tag, bad[:10])
+        for k, v in moving.items():
+            np.testing.assert_allclose(v, g["moving/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(REF_TRAIN_CASES))
+def test_hip_training_forward_and_init_match_reference_python(name):
+    from vaenar_tts_amd.models import VAENAR
+    g, hps, w = _load(name)
+    rf = int(g["reduction_factor"])
+    model = VAENAR(hps, weights=w)
+    try:
+        outs, l2, kl, ll, ali = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=rf, training=True,
+                                      reduce_loss=False, eps=g["eps"], dropout_seed=int(g["dropout_seed"]))
+        assert np.abs(outs.numpy() - g["predictions"]).max() < 2e-4
+        np.testing.assert_allclose(l2.numpy(), g["call_l2"], rtol=1e-4)
+        np.testing.assert_allclose(ll.numpy(), g["call_length"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(kl.numpy(), g["call_kl"], rtol=1e-3, atol=6e-2)
+        for k in ali:
+            np.testing.assert_allclose(ali[k].numpy(), g["call_ali/" + k], atol=1e-5)
+    finally:
+        model.engine.close()
+    model = VAENAR(hps, weights=w)
+    try:
+        mel = model.init(g["ids"], g["mel_lengths"], g["text_lengths"], eps=g["init_eps"], dropout_seed=int(g["init_dropout_seed"]))
+        assert np.abs(mel.numpy() - g["init_mel"]).max() < 2e-4
+        changed = [k[5:] for k in g if k.startswith("init/")]
+        got = model.get_weights(changed)
+        for k in changed:
+            np.testing.assert_allclose(got[k], g["init/" + k], rtol=1e-4, atol=2e-5, err_msg=k)
+    finally:
+        model.engine.close()

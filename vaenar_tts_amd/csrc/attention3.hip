@@ -24,7 +24,9 @@
 // rounding of t = s.log2(e) differs from the reference's exp(s - max) by <= 2^-24 . |t| relative -- below 3e-6 for |s| < 40.
 #include "common.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace vnr {
 
@@ -72,6 +74,9 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
   }
   const int qt_begin = (int)(((long long)chunk * nqt) / nchunk), qt_end = (int)(((long long)(chunk + 1) * nqt) / nchunk);
   if (qt_begin >= qt_end) return;                     // (workgroup-uniform)
+  unsigned long long* ts = a.dbg_ts ? a.dbg_ts + (size_t)blockIdx.x * 32 : nullptr;      // measurement only (VNR_ATTN3_TS)
+  auto stamp = [&](int i) { if (ts && threadIdx.x == 0 && i < 32) ts[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   const int b = pair / a.H, hd = pair - b * a.H;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,6 +126,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
   const int qlen = a.q_len ? a.q_len[b] : a.Tq;
   const int klen = a.k_len ? a.k_len[b] : a.Tk;
   __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): Q quarter, K and V are in registers; nothing is outstanding at the loop top
+  stamp(1);
   if (active && partial) {                            // positions past Tk hold whatever the workspace held: force zeros (once)
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
@@ -136,11 +142,13 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
   asm volatile("" ::: "memory");
   const float c = (a.temperature != 1.0f) ? 0.125f * kLog2e / a.temperature : 0.125f * kLog2e;
   char* xb = smem + wave * kXchg;                                  // this wave's exchange space
+  stamp(2);
 
 #pragma unroll 1
   for (int qidx = qt_begin; qidx < qt_end; ++qidx) {
     const int q0 = qidx * 32;
     const bool more = qidx + 1 < qt_end;
+    const int sb = 4 + 6 * (qidx - qt_begin);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       qhi[t] = *reinterpret_cast<const h8*>(qlds + 1024 * t + lane * 16);
@@ -153,6 +161,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
     }
+    stamp(sb);
     if (more) fetch_q(qidx + 1);                      // lands under this tile's softmax and P.V MFMAs
 
     // ---- logits (log2 domain) and masks ----------------------------------------------------------------------------------
@@ -207,7 +216,9 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     asm volatile("" ::: "memory");
     // every wave has read the current Q tile (its S^T MFMAs precede the barrier): park the next one.  The wait below is the
     // only vmcnt wait of the iteration and precedes the iteration's stores
+    stamp(sb + 1);
     if (more) { __builtin_amdgcn_s_waitcnt(0x0F70); park_q(); }
+    stamp(sb + 2);
     float f;
     {
       float mw[4], lw[4];
@@ -242,6 +253,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
         }
       }
     }
+    stamp(sb + 3);
     // ---- sum the four partial tiles: rows [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row], already scaled ---
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -253,6 +265,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(sb + 4);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
@@ -262,7 +275,10 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
       const int row = q0 + rr;
       if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
     }
+    stamp(sb + 5);
   }
+  stamp(30);
+  if (ts && threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ts[31] = ((unsigned long long)(xcc & 15) << 32) | (unsigned)(qt_end - qt_begin); }
 }
 
 // ---- general kernel: any Tk, optional causal mask, online softmax over the key blocks of a wave ----------------------------
@@ -469,6 +485,23 @@ hipError_t launch_attention3(const Attn3Args& a, hipStream_t s) {
     nchunk = want < nqt ? (want < 1 ? 1 : want) : nqt;
   }
   dim3 grid1(nchunk * a.H * a.B);
+  static const char* ts_path = getenv("VNR_ATTN3_TS");             // measurement only: per-workgroup timeline of the alignment kernel
+  if (a.ali && ts_path) {
+    Attn3Args aa = a;
+    const size_t n = (size_t)grid1.x * 32;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemset(d, 0, n * 8);
+    aa.dbg_ts = d;
+    vnr_launch(attn3_kernel<true>, grid1, dim3(256), lds, s, aa, nqt, nchunk);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hbuf(n);
+    (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FILE* f = fopen(ts_path, "ab");
+    if (f) { int hdr[4] = {a.B * a.H, a.Tq, nchunk, (int)grid1.x}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    return hipGetLastError();
+  }
   if (a.ali) vnr_launch(attn3_kernel<true>, grid1, dim3(256), lds, s, a, nqt, nchunk);
   else if (!force_general && a.Tk <= 128 && !a.causal) vnr_launch(attn3_kernel<false>, grid1, dim3(256), lds, s, a, nqt, nchunk);
   else vnr_launch(attn3g_kernel, grid, dim3(256), lds, s, a, nqt);

@@ -196,7 +196,8 @@ struct ChainArgs {
   int M, D, nstages;
   int rows64;                  // 1: 64-row panels (M/64 workgroups), 0: 32-row panels -- see gemm3.hip
   const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded
-  unsigned long long* dbg_ts;   // measurement only: [wgs][64] s_memtime stamps (start, panels, then loop/epilogue per stage)
+  unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
+  int dbg_stage;
   ChainStage st[kMaxChainStages];
 };
 hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);
@@ -217,6 +218,7 @@ struct Attn3Args {
   int B, H, Tq, Tk;
   float temperature;
   int causal = 0;
+  unsigned long long* dbg_ts = nullptr;        // measurement only (VNR_ATTN3_TS): [wgs][32] s_memtime stamps of attn3_kernel
 };
 hipError_t launch_attention3(const Attn3Args& a, hipStream_t s);
 // fp32 [rows][cols] -> operand images (tests, op-level entry; the engine's producers write the images directly)

@@ -70,10 +70,14 @@ panel_chain_kernel(const ChainArgs g) {
   auto panel_ptr = [&](int i) -> char* { return smem + P_OFF + i * PANEL_BYTES; };
   float* scratch = reinterpret_cast<float*>(smem);
   float* prm = reinterpret_cast<float*>(smem + PRM_OFF);       // [stage][256] bias, then the LayerNorm (gamma | beta) slots
-  unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 64 : nullptr;
+  unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 128 : nullptr;
   auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
-  auto wstamp = [&](int si, int i) { if (ts && si == 1 && lane == 0) ts[32 + wave * 4 + i] = __builtin_amdgcn_s_memtime(); };
+  auto wstamp = [&](int si, int i) { if (ts && si == g.dbg_stage && lane == 0) ts[64 + wave * 8 + i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
+  // the second-dispatched half of the workgroup (waves 4..7) loses the per-SIMD issue arbitration against its older partner
+  // on every phase (it leaves each k-loop ~1 kcyc later: profiles/r02_chain_rows32_timeline.txt); one static priority bump
+  // for that half evens the pair out (MI355X_MICROARCH.md, "static priority for the younger half")
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // ---- the weight stream --------------------------------------------------------------------------------------------
   // Every stage's weights sit in an operand-major image: block (column block, k-tile) = 4 x 1 KiB pieces, piece
@@ -182,7 +186,7 @@ panel_chain_kernel(const ChainArgs g) {
     // half panels to coincide with half tiles: rows per batch element % 16 == 0.
     const bool vswap = st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) &&
                        st.acc_mode == 0 && st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY;
-    wstamp(si, 0);
+    wstamp(si, 0);                                       // stage descriptor in registers
     const int npad = (st.nk + PF - 1) / PF * PF;
     // activation operands are read ONE k-tile ahead (registers a[cur] / a[nxt]) so the LDS latency of tile kt+1 hides
     // under the MFMAs of tile kt; reads past the stage's last tile are clamped (harmless re-read)
@@ -200,9 +204,10 @@ panel_chain_kernel(const ChainArgs g) {
         }
     };
     // The k-loop exists three times, selected ONCE per stage by wave-uniform conditions, so that its body is straight-line
-    // code: with the selection inside the loop (round 1) the accumulator became a phi of three paths and the compiler drained
-    // the matrix pipe after every k-tile (s_nop 11 + sixteen v_mov_b64 copies of the accumulator between the MFMA groups of
-    // consecutive k-tiles: ~45 % MFMA issue).  Padding k-tiles (kt >= nk) are not skipped either: their weight operands arrive
+    // code: with the selection inside the loop (round 1) the accumulator became a phi of three paths and the compiler copied it
+    // (s_nop 11 + sixteen v_mov_b64) between the MFMA groups of consecutive k-tiles.  (Measured: the copies were NOT what
+    // bounds the loop -- 1.45 ms per step before and after; neither is the dependent accumulator chain: two alternating
+    // accumulators per wave changed nothing either.)  Padding k-tiles (kt >= nk) are not skipped either: their weight operands arrive
     // as zeros from the out-of-range refill, the MFMAs add exact zeros.
     auto kloop = [&](auto mode_tag) {
       constexpr int MODE = decltype(mode_tag)::value;      // 0: D^T (lane <-> activation row), 1: D (V image stage), 2: idle wave
@@ -249,6 +254,33 @@ panel_chain_kernel(const ChainArgs g) {
       }
     }
     if (st.acc_mode == 1 || st.acc_mode == 2) { lds_barrier(); stamp(3 + 2 * si); continue; }   // the hidden panel may be rewritten next
+    // ---- fast path: a full-width hidden stage h = relu(x.W + b) -> other panel (FFN dense1 chunks, utils.py:49): no residual,
+    //      no LayerNorm, no HBM output, no column masks -- a third of the stages of a block chain
+    if (st.acc_mode == 0 && st.act == ACT_RELU && st.n == 256 && !st.pe && st.res < 0 && !st.gamma && !st.out && st.dst >= 0 &&
+        st.dst != st.a0 && !(st.asw < st.nk && st.dst == st.a1)) {
+      const float* sp = prm + si * 256;
+      char* Dp = panel_ptr(st.dst);
+      const int kt = wave;                                              // this wave's 32 columns = k-tile `wave` of the destination
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int prow = 32 * rt + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bi = *reinterpret_cast<const float4*>(sp + 32 * wave + 8 * q + 4 * half);
+          const float x[4] = {fmaxf(acc[rt][4 * q] * st.scale + bi.x, 0.f), fmaxf(acc[rt][4 * q + 1] * st.scale + bi.y, 0.f),
+                              fmaxf(acc[rt][4 * q + 2] * st.scale + bi.z, 0.f), fmaxf(acc[rt][4 * q + 3] * st.scale + bi.w, 0.f)};
+          h16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+          const int p = 8 * q + 4 * half;
+          *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
+          *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
+        }
+      }
+      wstamp(si, 5);
+      lds_barrier(); stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
     if (vswap) {
       if (wave_on) {
         const int cv = st.aoi_c0 - 2 * st.aoi_D + 32 * wave + l31;          // V column of this lane: head cv >> 6, channel cv & 63
@@ -309,6 +341,7 @@ panel_chain_kernel(const ChainArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[rt][r] = tanhf(v[rt][r]);
     }
+    wstamp(si, 4);                                       // accumulators drained, bias / activation applied
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int row = m0 + 32 * rt + l31, prow = 32 * rt + l31;
@@ -338,51 +371,60 @@ panel_chain_kernel(const ChainArgs g) {
       for (int q = 0; q < 4; ++q)
         if (!cok[q]) v[rt][4 * q] = v[rt][4 * q + 1] = v[rt][4 * q + 2] = v[rt][4 * q + 3] = 0.f;
     }
-    if (st.gamma) {                                                      // LayerNormalization (eps 1e-3), two-pass statistics
+    if (st.gamma) {
+      // LayerNormalization (eps 1e-3).  ONE exchange: every wave reduces its own <= 32 columns of a row to (sum, M2 about its own
+      // mean) -- two in-lane passes and two half-swaps, no LDS -- and the eight partials are merged exactly (Chan et al.):
+      // var.n = sum_w [M2_w + c_w (mean_w - mean)^2].  (Round 1 exchanged the mean first and the centred squares second: two
+      // barriers and two LDS round trips per LayerNorm stage.)
+      int cw = st.n - 32 * wave; cw = cw < 0 ? 0 : (cw > 32 ? 32 : cw);          // valid columns of this wave
+      const float rcw = cw > 0 ? 1.f / (float)cw : 0.f;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         float s1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s1 += v[rt][r];
         s1 += __shfl_xor(s1, 32, 64);
-        if (half == 0) scratch[(32 * rt + l31) * 8 + wave] = s1;
-      }
-      lds_barrier();
-      float mean[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        float mu = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) mu += scratch[(32 * rt + l31) * 8 + w];
-        mu *= 1.f / (float)st.n;
-        mean[rt] = mu;
-        float s2 = 0.f;
+        const float mw = s1 * rcw;
+        float m2 = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float d = cok[q] ? v[rt][4 * q + e] - mu : 0.f;
-            s2 += d * d;
+            const float d = cok[q] ? v[rt][4 * q + e] - mw : 0.f;
+            m2 += d * d;
           }
-        s2 += __shfl_xor(s2, 32, 64);
-        if (half == 0) scratch[ROWS * 8 + (32 * rt + l31) * 8 + wave] = s2;
+        m2 += __shfl_xor(m2, 32, 64);
+        if (half == 0) { scratch[(32 * rt + l31) * 8 + wave] = s1; scratch[ROWS * 8 + (32 * rt + l31) * 8 + wave] = m2; }
       }
       lds_barrier();
       const float* lnp = prm + st.lds_ln;                               // gamma [256] | beta [256]
+      const float rn = 1.f / (float)st.n;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(scratch + (32 * rt + l31) * 8), sb = *reinterpret_cast<const f32x4*>(scratch + (32 * rt + l31) * 8 + 4);
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(scratch + ROWS * 8 + (32 * rt + l31) * 8), mb = *reinterpret_cast<const f32x4*>(scratch + ROWS * 8 + (32 * rt + l31) * 8 + 4);
+        const float sw[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+        const float mq[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += sw[w];
+        const float mu = tot * rn;
         float var = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) var += scratch[ROWS * 8 + (32 * rt + l31) * 8 + w];
-        const float rstd = 1.0f / sqrtf(var * (1.f / (float)st.n) + kLnEps);
+        for (int w = 0; w < 8; ++w) {
+          int c = st.n - 32 * w; c = c < 0 ? 0 : (c > 32 ? 32 : c);
+          const float dm = c > 0 ? sw[w] / (float)c - mu : 0.f;
+          var += mq[w] + (float)c * dm * dm;
+        }
+        const float rstd = 1.0f / sqrtf(var * rn + kLnEps);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = 32 * wave + 8 * q + 4 * half;
           const float4 ga = *reinterpret_cast<const float4*>(lnp + col), be = *reinterpret_cast<const float4*>(lnp + 256 + col);
-          v[rt][4 * q + 0] = (v[rt][4 * q + 0] - mean[rt]) * rstd * ga.x + be.x;
-          v[rt][4 * q + 1] = (v[rt][4 * q + 1] - mean[rt]) * rstd * ga.y + be.y;
-          v[rt][4 * q + 2] = (v[rt][4 * q + 2] - mean[rt]) * rstd * ga.z + be.z;
-          v[rt][4 * q + 3] = (v[rt][4 * q + 3] - mean[rt]) * rstd * ga.w + be.w;
+          v[rt][4 * q + 0] = (v[rt][4 * q + 0] - mu) * rstd * ga.x + be.x;
+          v[rt][4 * q + 1] = (v[rt][4 * q + 1] - mu) * rstd * ga.y + be.y;
+          v[rt][4 * q + 2] = (v[rt][4 * q + 2] - mu) * rstd * ga.z + be.z;
+          v[rt][4 * q + 3] = (v[rt][4 * q + 3] - mu) * rstd * ga.w + be.w;
         }
       }
     } else if (st.dst >= 0 && (st.dst == st.a0 || (st.asw < st.nk && st.dst == st.a1))) {
@@ -437,6 +479,7 @@ panel_chain_kernel(const ChainArgs g) {
         }
       }
     }
+    wstamp(si, 5);                                                    // outputs issued
     lds_barrier();                                                    // panels are complete / free before the next stage
     stamp(3 + 2 * si);
     wstamp(si, 3);
@@ -455,7 +498,9 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
   static const char* ts_path = getenv("VNR_CHAIN_TS");
   if (ts_path) {
     ChainArgs gg = g;
-    const size_t n = (size_t)wgs * 64;
+    static const char* ts_stage = getenv("VNR_CHAIN_TS_STAGE");       // stage whose per-wave stamps are taken (default 1)
+    gg.dbg_stage = ts_stage ? atoi(ts_stage) : 1;
+    const size_t n = (size_t)wgs * 128;
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);
@@ -466,7 +511,7 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     FILE* f = fopen(ts_path, "ab");
-    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 64)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 128)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
   vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, g);

@@ -546,7 +546,9 @@ static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
   static const bool v1 = getenv("VNR_COLSUM_V1") != nullptr;           // A/B switch
   if (!v1 && !(C & 3) && !(ld & 3) && !((size_t)x & 15)) {
-    int rb4 = (M + 31) / 32; if (rb4 > 256) rb4 = 256; if (rb4 < 1) rb4 = 1;
+    // (64 row groups at most: every workgroup ends in one atomic per column, and 256 groups contending for the same 256 words
+    //  cost more than the longer per-thread loops)
+    int rb4 = (M + 63) / 64; if (rb4 > 64) rb4 = 64; if (rb4 < 1) rb4 = 1;
     vnr_launch(col_sum4_kernel, dim3((C + 255) / 256, rb4), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
   } else {
     vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);

@@ -42,11 +42,23 @@ def main():
             n = sum(r[0] for k, r in rows.items() if pred(k))
             b = sum(r[0] * (2 * r[1] + r[2]) * 1024 for k, r in rows.items() if pred(k))
             return b / n if n else None
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_digest
+
+        def gemm2_split(k):           # last template argument of gemm2_kernel: 0 = fp32 MFMA, 1 / 2 = split-fp16 (true / false in round 1)
+            if "gemm2_kernel<" not in k:
+                return None
+            last = k[k.index("<") + 1:k.index(">")].split(",")[-1].strip()
+            return last in ("1", "2", "true")
         out = {
             "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 "
-                      "--profile-steps 1 --no-train --no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
-                      "wide-read correction), WRITE_SIZE uncalibrated; KiB*1024",
-            "gemm_bytes_per_launch": total(lambda k: "gemm2_kernel" in k or "panel_chain_kernel" in k or "gemm_kernel" in k),
+                      "--profile-steps 1 --in-flight 0 --no-train --no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                      "(gfx950 wide-read correction), WRITE_SIZE uncalibrated; KiB*1024",
+            "kernel_source_digest": kernel_source_digest(),      # bench.py prints these figures only while the kernel sources are the same
+            "chain_bytes_per_launch": total(lambda k: "panel_chain_kernel" in k),
+            "gemm_bytes_per_launch": total(lambda k: gemm2_split(k) is True),
+            "gemm_fp32_bytes_per_launch": total(lambda k: gemm2_split(k) is False or "gemm_kernel" in k),
             "cross_attention_ali_bytes_per_launch": total(lambda k: "attn3_kernel<true>" in k or "attn2_kernel<true>" in k),
             "note": "memory-side (fabric) bytes; most of the S1 working set sits in the 256 MiB Infinity Cache, so these are "
                     "largely cache hits, not DRAM",

@@ -137,6 +137,12 @@ struct GemmArgs {
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]
   AoiDesc aoi;                      // mode != 0: C is written as an attention operand image (attention3.hip) instead of fp32
   int wide_tiles = 0;               // split path: prefer 64x128 workgroup tiles (fewer, denser workgroups; engine option "gemm_wide_tiles")
+  // "split rows": an activation matrix [M][C] (C % 32 == 0) stored, per row and per 32-channel tile, as 32 x fp16 hi | 32 x fp16 lo
+  // (x = hi + lo) -- the SAME 128 bytes per (row, tile) as fp32, so every address of the LDS-DMA (plain and conv tap walker) is
+  // unchanged, but the consumer's k-loop needs no fp32 -> (hi, lo) conversion (which outweighed the MFMAs: the same element is
+  // converted once per tap and per column tile, 40x for an encoder convolution).  Split path (Wsplit) only.
+  int a_split = 0;                  // A1 (and A2) are split rows
+  int c_split = 0;                  // C is written as split rows (ldc = C columns, bytes per row = 4 * ldc)
 };
 
 struct AttnArgs {
@@ -247,6 +253,7 @@ hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s)
 // Wt [N][K] fp32 -> operand-major split image [ceil(N/32)][ceil(K/32)][2 steps][hi|lo][64 lanes][8 fp16] (gemm3.hip)
 hipError_t launch_opmajor_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s);
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s);
+hipError_t launch_gather_rows_split(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s);   // out = split rows (dim % 32 == 0)
 hipError_t launch_coupling_bwd(const float* heads, float* z, int M, int half, int zp_off,
                                float* row_logdet, hipStream_t s);
 hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps, int M, int C, float* z,

@@ -124,6 +124,7 @@ struct vnr_context {
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
+  bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
   bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
   // cross K|V panels of the current call that were written as attention operand images (cleared with the workspace)
@@ -225,6 +226,7 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
     }
   }
   g.wide_tiles = h->gemm_wide_tiles ? 1 : 0;
+  if ((g.a_split || g.c_split) && !g.Wsplit) return fail(h, VNR_ERR_STATE, "split-row activations need the split-fp16 weight image of the layer");
   ProfScope ps(h, g.Wsplit ? CLS_GEMM : CLS_GEMM_F32, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e) +
@@ -698,9 +700,11 @@ int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb
   return VNR_OK;
 }
 
+// a_split / c_split: the input / output activation is in "split rows" (common.h, GemmArgs::a_split) -- inference mode only
 int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather, int B, int T, int act,
-             int bn_first, float* y) {
+             int bn_first, float* y, int a_split = 0, int c_split = 0) {
   GemmArgs g;
+  g.a_split = a_split; g.c_split = c_split;
   g.A1 = x; g.lda1 = c.cin; g.K1 = c.k * c.cin; g.K = c.k * c.cin; g.Wt = c.wt; g.ldw = c.k * c.cin;
   g.bias = c.bias; g.act = act; g.bn_scale = c.bn_scale; g.bn_shift = c.bn_shift; g.bn_first = bn_first;
   g.C = y; g.ldc = c.cout; g.M = B * T; g.N = c.cout; g.taps = c.k; g.conv_T = T; g.conv_C = c.cin;
@@ -723,6 +727,18 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
   RUN_MISC(h, launch_bn_train_finish(mean, sq, M, C, c.gamma, c.beta, 0.99f, c.moving_mean, c.moving_var, sc, sh, h->stream));
   RUN_MISC(h, launch_rowop(y, M, C, sc, sh, nullptr, 1, 0.f, c.drop_rate, site_key(h->drop_seed, c.site), y, h->stream));
   return VNR_OK;
+}
+// A conv stack can hand its activations from layer to layer as split rows when the split-fp16 path is on for this scope, every
+// layer has its weight image and the channel counts are whole 32-channel tiles (option "split_rows", default 1)
+bool split_rows_ok(vnr_handle h, const std::vector<ConvL>& convs, int M) {
+  if (!h->split_rows || h->training || !h->split_enabled || !h->split_scope || convs.empty() || M < 64) return false;      // (run_gemm takes the split path from 64 rows)
+  static const bool v1 = getenv("VNR_GEMM_V1") != nullptr;
+  if (v1) return false;
+  for (const ConvL& c : convs) {
+    SplitRef r;
+    if ((c.cout & 31) || !split_lookup(h, c.wt, c.k * c.cin, c.cout, r)) return false;
+  }
+  return true;
 }
 // the moving statistics changed (training-mode forward): refresh the folded inference affine of every BN
 int refresh_bn_affine(vnr_handle h) {
@@ -769,10 +785,14 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
   float* cur = xa; float* nxt = xb;
   // Embedding (encoder.py:81): a 4 MB row gather, then the conv stack (utils.py:33-38) on the DMA GEMM kernel
   if (c.enc_embd_dim > Dm) return fail(h, VNR_ERR_ARG, "embd_dim larger than pre_hidden is not supported");
-  RUN_MISC(h, launch_gather_rows(h->emb, ids, M, c.enc_embd_dim, nxt, h->stream));
+  // split rows through the conv stack (embedding -> 3 convolutions -> projection): no fp32 -> (hi, lo) conversion in any k-loop
+  SplitRef rproj;
+  const bool sr = split_rows_ok(h, h->enc_convs, M) && !(c.enc_embd_dim & 31) && !(Dm & 31) && split_lookup(h, h->enc_proj_wt, Dm, Dm, rproj);
+  if (sr) RUN_MISC(h, launch_gather_rows_split(h->emb, ids, M, c.enc_embd_dim, nxt, h->stream));
+  else RUN_MISC(h, launch_gather_rows(h->emb, ids, M, c.enc_embd_dim, nxt, h->stream));
   std::swap(cur, nxt);
   for (size_t i = 0; i < h->enc_convs.size(); ++i) {
-    TRY(run_conv(h, h->enc_convs[i], cur, nullptr, B, T, c.enc_pre_activation, c.enc_bn_before_act, nxt));
+    TRY(run_conv(h, h->enc_convs[i], cur, nullptr, B, T, c.enc_pre_activation, c.enc_bn_before_act, nxt, sr, sr));
     std::swap(cur, nxt);
   }
   const float* pe = nullptr;
@@ -780,6 +800,7 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
   GemmArgs g;
   g.A1 = cur; g.lda1 = Dm; g.K1 = Dm; g.K = Dm; g.Wt = h->enc_proj_wt; g.ldw = Dm; g.bias = h->enc_proj_b;
   g.pe = pe; g.pe_T = T; g.pe_w = h->enc_pos_weight; g.C = nxt; g.ldc = Dm; g.M = M; g.N = Dm;
+  g.a_split = sr;
   TRY(run_gemm(h, g));                                       // prenet.projection + pos_weight*PE (encoder.py:85-86)
   if (h->training && c.enc_pos_drop_rate > 0.f)              // pe_dropout (encoder.py:87)
     RUN_MISC(h, launch_rowop(nxt, M, Dm, nullptr, nullptr, nullptr, 1, 0.f, c.enc_pos_drop_rate, site_key(h->drop_seed, SITE_ENC_PE), nxt, h->stream));
@@ -981,13 +1002,17 @@ int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const
   WS(pa, (size_t)Mm * Fp); WS(pb, (size_t)Mm * Fp);
   const float* cur = init; float* nxt = pa;
   const int nconv = (int)h->post_convs.size();
+  // split rows between the PostNet layers (the first layer reads the fp32 initial outputs: 80 channels are not whole tiles)
+  SplitRef rres;
+  const bool sr = nconv > 0 && split_rows_ok(h, h->post_convs, Mm) && split_lookup(h, h->dec_res_wt, Fp, od, rres);
   for (int i = 0; i < nconv; ++i) {   // PostNet (utils.py:98-115): tanh x (n-1), identity; BN after act
-    TRY(run_conv(h, h->post_convs[i], cur, nullptr, B, Tm, i < nconv - 1 ? ACT_TANH : ACT_IDENTITY, 0, nxt));
+    TRY(run_conv(h, h->post_convs[i], cur, nullptr, B, Tm, i < nconv - 1 ? ACT_TANH : ACT_IDENTITY, 0, nxt, sr && i > 0, sr));
     cur = nxt; nxt = (nxt == pa) ? pb : pa;
   }
   const int kres = nconv > 0 ? Fp : od;
   g = GemmArgs(); g.A1 = cur; g.lda1 = kres; g.K1 = kres; g.K = kres; g.Wt = h->dec_res_wt; g.ldw = kres; g.bias = h->dec_res_b;
   g.residual = init; g.ldr = od; g.C = outputs; g.ldc = od; g.M = Mm; g.N = od;
+  g.a_split = sr;
   TRY(run_gemm(h, g));               // residual_projection + initial_outs (decoder.py:197-198)
   return VNR_OK;
 }
@@ -1890,6 +1915,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "gemm_wide_tiles")) { h->gemm_wide_tiles = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_rows64")) { h->chain_rows64 = value != 0; return VNR_OK; }
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
+  if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }

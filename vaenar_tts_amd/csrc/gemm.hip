@@ -403,7 +403,7 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
 
   static const bool force_v1 = getenv("VNR_GEMM_V1") != nullptr;   // A/B switch for measurements
   if (!force_v1 && gemm2_supported(g)) return launch_gemm2(g, s);
-  if (g.aoi.mode) return hipErrorInvalidValue;       // operand-image epilogues exist in gemm2 only
+  if (g.aoi.mode || g.a_split || g.c_split) return hipErrorInvalidValue;       // operand-image / split-row formats exist in gemm2 only
 
   if (g.ln_gamma) {
     if (g.taps > 0 || g.gather_ids || g.bn_scale || g.pe || g.N > 256) return hipErrorInvalidValue;

@@ -45,7 +45,9 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, bool SPLIT>
+// SPLIT: 0 = fp32 MFMA; 1 = split-fp16 weights, fp32 activations split in registers; 2 = split-fp16 weights AND activations
+// already stored as split rows (GemmArgs::a_split): the k-loop is ds_read + MFMA only
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, int SPLIT>
 __global__ void __launch_bounds__(WM* WN * 64)
 gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;
@@ -267,6 +269,18 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     }
     f16x8 ahi[2][MI], alo[2][MI], bhi[2][NI], blo[2][NI];
     auto fragS = [&](const char* As, const char* Bs, int t, int set) {
+      if constexpr (SPLIT == 2) {                          // A rows arrive pre-split: same chunk geometry as the weight image
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ahi[set][i] = *reinterpret_cast<const f16x8*>(As + i * 4096 + rdB[t][0]);
+          alo[set][i] = *reinterpret_cast<const f16x8*>(As + i * 4096 + rdB[t][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bhi[set][j] = *reinterpret_cast<const f16x8*>(Bs + j * 4096 + rdB[t][0]);
+          blo[set][j] = *reinterpret_cast<const f16x8*>(Bs + j * 4096 + rdB[t][1]);
+        }
+      } else {
       f32x4 x0[MI], x1[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -286,6 +300,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
           split_f16(x0[i][e] * a_sc, h, l); ahi[set][i][e] = h; alo[set][i][e] = l;
           split_f16(x1[i][e] * a_sc, h, l); ahi[set][i][4 + e] = h; alo[set][i][4 + e] = l;
         }
+      }
     };
     auto mfmaS = [&](int set, int kt_dma, int ns, bool with_dma) {
       int d = 0;
@@ -432,6 +447,15 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             const float4 pe4 = pev[j][q], r4 = res[j][q];
             v[0] += g.pe_w * pe4.x + r4.x; v[1] += g.pe_w * pe4.y + r4.y; v[2] += g.pe_w * pe4.z + r4.z; v[3] += g.pe_w * pe4.w + r4.w;
             if (g.aoi.mode) aoi_store4(g.aoi, row, col, v);      // attention operand image instead of fp32
+            else if (g.c_split) {                                // split rows: 4 x fp16 hi at its place in the 32-channel tile, lo 64 bytes on
+              typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+              h4_t hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(v[e], hh, ll); hi[e] = hh; lo[e] = ll; }
+              char* pc = reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4 + (col >> 5) * 128 + (col & 31) * 2;
+              *reinterpret_cast<h4_t*>(pc) = hi;
+              *reinterpret_cast<h4_t*>(pc + 64) = lo;
+            }
             else out_store4(g.C + (size_t)row * g.ldc + col, v[0], v[1], v[2], v[3]);
           }
       }
@@ -587,7 +611,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, int SPLIT = 0>
 static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = LN ? 1 : (g.N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 128 + (LN ? (size_t)32 * BN * 4 : 0);
@@ -643,6 +667,7 @@ bool gemm2_supported(const GemmArgs& g) {
   if (((size_t)g.N * g.ldw + g.K) * 4 >= lim) return false;
   if (g.ln_gamma && (g.N > 256 || g.taps > 0 || g.bn_scale || g.pe)) return false;
   if (g.aoi.mode && (g.ln_gamma || (g.N & 3) || (g.ldc & 3) || (g.residual && (g.ldr & 3)))) return false;   // image stores: 4-column groups
+  if ((g.a_split || g.c_split) && (!g.Wsplit || g.ln_gamma || g.aoi.mode || (g.c_split && ((g.N & 31) || (g.ldc & 31))))) return false;
   return true;
 }
 
@@ -651,7 +676,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   const GemmArgs& g = g_in;
   static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
   if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
-    if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 3, true, true>(g, s) : launch2<32, 256, 1, 4, 3, true, true>(g, s);
+    if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 3, true, 1>(g, s) : launch2<32, 256, 1, 4, 3, true, 1>(g, s);
     static const int stile = getenv("VNR_SPLIT_TILE") ? atoi(getenv("VNR_SPLIT_TILE")) : -1;   // measurement knob
     static const int sstages = getenv("VNR_SPLIT_STAGES") ? atoi(getenv("VNR_SPLIT_STAGES")) : -1;   // measurement knob
     int t = stile, ns = sstages;
@@ -660,9 +685,13 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // With several batches in flight (wide_tiles) the 64x128 tile wins everywhere: +4 % aggregate throughput (tools/ab_tiles.sh)
     if (t < 0) t = ((g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128)) ? 1 : 2;
     if (ns < 0) ns = 3;
-    if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, true>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, true>(g, s) : launch2<128, 128, 2, 2, 3, false, true>(g, s);
-    if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, true>(g, s) : launch2<64, 128, 2, 2, 3, false, true>(g, s);
-    return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, true>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, true>(g, s) : launch2<64, 64, 2, 2, 3, false, true>(g, s);
+    if (g.a_split) {                                                       // activations arrive as split rows (64x64 / 64x128 tiles, 3 stages)
+      if ((g.K & 31) || (g.K1 & 31) || (g.taps > 0 && (g.conv_C & 31)) || g.a_absmax) return hipErrorInvalidValue;
+      return t == 1 ? launch2<64, 128, 2, 2, 3, false, 2>(g, s) : launch2<64, 64, 2, 2, 3, false, 2>(g, s);
+    }
+    if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, 1>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, 1>(g, s) : launch2<128, 128, 2, 2, 3, false, 1>(g, s);
+    if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, 1>(g, s) : launch2<64, 128, 2, 2, 3, false, 1>(g, s);
+    return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, 1>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, 1>(g, s) : launch2<64, 64, 2, 2, 3, false, 1>(g, s);
   }
   if (g.ln_gamma) {
     (void)st;

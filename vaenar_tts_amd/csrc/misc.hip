@@ -325,6 +325,31 @@ gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ 
   float* dst = out + (size_t)row * dim;
   for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
 }
+// Embedding gather straight into "split rows" (common.h, GemmArgs::a_split): lane handles 4 channels of one row
+__global__ void __launch_bounds__(256)
+gather_rows_split_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, int rows, int dim, char* __restrict__ out) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* src = table + (size_t)ids[row] * dim;
+  char* dst = out + (size_t)row * dim * 4;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(src + c);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+    char* p = dst + (c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<h4*>(p) = hi;
+    *reinterpret_cast<h4*>(p + 64) = lo;
+  }
+}
+hipError_t launch_gather_rows_split(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s) {
+  if (dim & 31) return hipErrorInvalidValue;
+  vnr_launch(gather_rows_split_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, rows, dim, reinterpret_cast<char*>(out));
+  return hipGetLastError();
+}
 hipError_t launch_gather_rows(const float* table, const int32_t* ids, int rows, int dim, float* out, hipStream_t s) {
   if (dim & 3) return hipErrorInvalidValue;
   vnr_launch(gather_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, table, ids, rows, dim, out);

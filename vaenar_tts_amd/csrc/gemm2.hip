@@ -15,6 +15,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace vnr {
@@ -217,6 +218,15 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   // (lgkmcnt(0)) before it passed the barrier of iteration kt-1.
   const int nk = (g.K + 31) >> 5;
   float a_inv = 1.f;                                  // inverse of the gradient pre-scale of A (split path, see below)
+  // a tile made of V-type image columns only (and nothing but a scale in the epilogue) is computed un-transposed: see mfmaS
+  bool vtile = false;
+  if (SPLIT && !LN && g.aoi.mode >= 2 && !(g.aoi.T & 15) && !(g.aoi.D & 63) && !g.bias && g.act == ACT_IDENTITY && !g.bn_scale && !g.pe &&
+      !g.residual && !(g.M & 15)) {
+    if (g.aoi.mode == 2) vtile = true;
+    else if (g.aoi.mode == 3) vtile = (n0 % (2 * g.aoi.D)) >= g.aoi.D && ((n0 + BN - 1) % (2 * g.aoi.D)) >= g.aoi.D && (n0 / (2 * g.aoi.D)) == ((n0 + BN - 1) / (2 * g.aoi.D));
+    else if (g.aoi.mode == 4) vtile = n0 >= 2 * g.aoi.D;
+    if (n0 + BN > g.N) vtile = false;                 // (ragged last tile: generic path)
+  }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
   // LayerNorm row panels: the residual tile [32][N] is fetched NOW by LDS-DMA into a staging region behind the
@@ -302,17 +312,25 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         }
       }
     };
-    auto mfmaS = [&](int set, int kt_dma, int ns, bool with_dma) {
+    // VT (tile-uniform, chosen once per workgroup): the tile holds only V-type columns of an attention operand image -> the
+    // product is formed UN-transposed (operands swapped: lane <-> output column, registers <-> rows in k-slot order), so that 8
+    // consecutive accumulator registers are one 16-byte unit of the V image and the epilogue writes coalesced 1 KiB pieces
+    // instead of sixteen 2-byte scatters per 4 values (the cross K|V panel GEMM spent most of its 81 us there).
+    auto mfmaS = [&](auto vt_tag, int set, int kt_dma, int ns, bool with_dma) {
+      constexpr bool VT = decltype(vt_tag)::value;
       int d = 0;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], ahi[set][i], acc[i][j], 0, 0, 0);   // D^T
+          if (VT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[set][i], bhi[set][j], acc[i][j], 0, 0, 0);   // D
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], ahi[set][i], acc[i][j], 0, 0, 0);      // D^T
           if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], alo[set][i], acc[i][j], 0, 0, 0);
+          if (VT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[set][i], bhi[set][j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[set][j], alo[set][i], acc[i][j], 0, 0, 0);
           if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[set][j], ahi[set][i], acc[i][j], 0, 0, 0);
+          if (VT) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[set][i], blo[set][j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[set][j], ahi[set][i], acc[i][j], 0, 0, 0);
           if (with_dma && d < LPW) { issue_one(kt_dma, ns, d); ++d; }
         }
       if (with_dma)
@@ -324,23 +342,26 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     fragS(smem + wm * TM * 128, smem + BM * 128 + wn * TN * 128, 0, 0);
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
-      const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
-      int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;
-      int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;
-      __builtin_amdgcn_sched_barrier(0);
-      fragS(As, Bs, 1, 1);                               // second k16 step of this tile
-      mfmaS(0, kt + NSTAGE - 1, ns, true);               // first step + DMA of tile kt+NSTAGE-1
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      mfmaS(1, 0, 0, false);
-      fragS(smem + nx * STAGE_BYTES + wm * TM * 128, smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128, 0, 0);
-      slot = nx;
-    }
+    auto kloopS = [&](auto vt_tag) {
+      int slot = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        const char* As = smem + slot * STAGE_BYTES + wm * TM * 128;
+        const char* Bs = smem + slot * STAGE_BYTES + BM * 128 + wn * TN * 128;
+        int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;
+        int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        fragS(As, Bs, 1, 1);                               // second k16 step of this tile
+        mfmaS(vt_tag, 0, kt + NSTAGE - 1, ns, true);       // first step + DMA of tile kt+NSTAGE-1
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        mfmaS(vt_tag, 1, 0, 0, false);
+        fragS(smem + nx * STAGE_BYTES + wm * TM * 128, smem + nx * STAGE_BYTES + BM * 128 + wn * TN * 128, 0, 0);
+        slot = nx;
+      }
+    };
+    if (vtile) kloopS(std::true_type{}); else kloopS(std::false_type{});
   } else {
   f32x4 fa[2][MI], fb[2][NI];
     auto frag = [&](const char* As, const char* Bs, int c8, int set) {
@@ -410,6 +431,34 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   // row's LayerNorm statistics are an in-lane sum plus one cross-half shuffle.
   stamp(3);
   const float ascale = SPLIT ? g.acc_scale * a_inv : 1.0f;
+  if (!LN && vtile) {
+    // accumulator layout D: lane (l31, half) <-> column n of the 32-column block, register r <-> row (r & 3) + 8 (r >> 2) + 4 half
+    // of the 32-row block; registers 8 tp .. 8 tp + 7 are the eight k-slots of 16-key half tile tp (common.h, V tile)
+    const int Hh = g.aoi.D >> 6;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+        int blk = 0, cc = n;
+        if (g.aoi.mode == 3) { blk = n / (2 * g.aoi.D); cc = n - blk * 2 * g.aoi.D - g.aoi.D; }
+        else if (g.aoi.mode == 4) cc = n - 2 * g.aoi.D;
+        const int head = cc >> 6, dch = cc & 63;
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+          const int R = m0 + wm * TM + i * 32 + 16 * tp;
+          if (R >= g.M) continue;
+          const int bb = R / g.aoi.T, tt = R - bb * g.aoi.T;
+          f16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { _Float16 hh, ll; split_f16(acc[i][j][8 * tp + e] * ascale, hh, ll); hi[e] = hh; lo[e] = ll; }
+          char* pd = g.aoi.vt + (size_t)blk * g.aoi.blk_bytes + ((size_t)(bb * Hh + head) * g.aoi.TT + (tt >> 5)) * kAoiTile +
+                     ((tt >> 4) & 1) * 2048 + ((dch >> 5) & 1) * 1024 + ((half * 32 + (dch & 31)) << 4);
+          *reinterpret_cast<f16x8*>(pd) = hi;
+          *reinterpret_cast<f16x8*>(pd + 4096) = lo;
+        }
+      }
+  } else
   if (!LN) {
     if (vec_ok) {
 #pragma unroll

@@ -13,6 +13,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 hps = LJHPS
 model = VAENAR(hps, weights=init_weights(hps, seed=1234, mode="synthetic"))
+import os
+for kv in os.environ.get("VNR_TRAIN_OPTS", "").split():          # engine options for A/B runs, e.g. VNR_TRAIN_OPTS="gemm_wide_tiles=1"
+    k, v = kv.split("=")
+    model.engine.set_option(k, int(v))
 b = make_batch(B, 128, 800, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=False)
 r = np.random.Generator(np.random.PCG64(5))
 mels = r.standard_normal((B, 800, 80)).astype(np.float32)

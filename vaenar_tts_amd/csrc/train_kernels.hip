@@ -81,19 +81,33 @@ gemm_tn_kernel(const float* A, int lda, const float* B, int ldb, float* C, int l
 // LDS, and stored reduction-major ([column][m], 8 consecutive m = one 16-byte MFMA operand), so the inner loop is
 // ds_read_b128 + MFMA only: 6 MFMAs of 8 passes per 32-row tile instead of 16 MFMAs of 16 passes.
 typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+// Round 2: templated on the per-wave tile count (TK x TN tiles of 32 x 32): <1,1> is the round-1 kernel (64 x 64 per workgroup,
+// 6 MFMAs per wave per 32-row tile against 16 scalar loads + 64 conversion instructions + a workgroup barrier: 12 % of the
+// matrix pipe); <2,2> computes 128 x 128 per workgroup (the same loads and conversions per row feed four times the MFMAs) but
+// is slower in the step (see launch_gemm_tn_scaled) and stays an experiment switch.
+template <int TK, int TN>
 __global__ void __launch_bounds__(256)
 gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
                      int rows_per_split, const unsigned* b_absmax) {
   constexpr int CS = 40;                                   // column stride in halfs (80 B: 16-byte aligned, bank-spread)
-  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][64 * CS], Al[2][64 * CS], Bh[2][64 * CS], Bl[2][64 * CS];
+  constexpr int KW = 64 * TK, NW = 64 * TN;                // workgroup tile: KW output rows (k) x NW output columns (n)
+  extern __shared__ __attribute__((aligned(16))) char tn_smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(tn_smem);     // [2][KW * CS]
+  _Float16* Al = Ah + 2 * KW * CS;
+  _Float16* Bh = Al + 2 * KW * CS;                         // [2][NW * CS]
+  _Float16* Bl = Bh + 2 * NW * CS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
-  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int k0 = blockIdx.x * KW, n0 = blockIdx.y * NW;
   const int m_lo = blockIdx.z * rows_per_split;
   int m_hi = m_lo + rows_per_split; if (m_hi > M) m_hi = M;
-  f32x16 acc;
+  f32x16 acc[TK][TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // B is a GRADIENT: its magnitude follows the loss scale (kl_weight 1e-5 puts whole branches at 1e-9), far outside the fp16
   // range.  It is pre-scaled by the power of two that maps the launch-wide max |B| (found by a preceding abs-max pass) to
   // ~2^14; the hi/lo pair then resolves 2^-39 of that maximum, and the accumulator is scaled back exactly at the end.
@@ -108,33 +122,39 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
       binv = __uint_as_float((unsigned)(-sft + 127) << 23);
     }
   }
-  // loader: column `col` of the 64-wide strip, rows 8*rg .. 8*rg+7 of the 32-row tile (a wave reads 256 contiguous bytes per row)
+  // loader: columns `col + 64 c` of the strips, rows 8*rg .. 8*rg+7 of the 32-row tile (a wave reads 256 contiguous bytes per row)
   const int col = tid & 63, rg = tid >> 6;
-  const bool a_ok = k0 + col < K, b_ok = n0 + col < N;
-  float ra[8], rb[8];
+  float ra[TK][8], rb[TN][8];
   auto gload = [&](int m0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int m = m0 + 8 * rg + e;
-      float va = 0.f, vb = 0.f;
-      if (m < m_hi) {
-        const int t = m % T, ts = t + shift;
-        if (a_ok && ts >= 0 && ts < T) va = A[(size_t)(m + shift) * lda + k0 + col];
-        if (b_ok) vb = B[(size_t)m * ldb + n0 + col] * bscale;
-      }
-      ra[e] = va; rb[e] = vb;
+      const bool mok = m < m_hi;
+      const int t = mok ? m % T : 0, ts = t + shift;
+      const bool aok = mok && ts >= 0 && ts < T;
+#pragma unroll
+      for (int c = 0; c < TK; ++c) ra[c][e] = (aok && k0 + col + 64 * c < K) ? A[(size_t)(m + shift) * lda + k0 + col + 64 * c] : 0.f;
+#pragma unroll
+      for (int c = 0; c < TN; ++c) rb[c][e] = (mok && n0 + col + 64 * c < N) ? B[(size_t)m * ldb + n0 + col + 64 * c] * bscale : 0.f;
     }
   };
   auto lstore = [&](int buf) {
-    h16x8_t ah, al, bh, bl;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      _Float16 h = (_Float16)ra[e]; ah[e] = h; al[e] = (_Float16)(ra[e] - (float)h);
-      h = (_Float16)rb[e]; bh[e] = h; bl[e] = (_Float16)(rb[e] - (float)h);
+    for (int c = 0; c < TK; ++c) {
+      h16x8_t ah, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)ra[c][e]; ah[e] = h; al[e] = (_Float16)(ra[c][e] - (float)h); }
+      const int o = buf * KW * CS + (col + 64 * c) * CS + 8 * rg;
+      *reinterpret_cast<h16x8_t*>(&Ah[o]) = ah; *reinterpret_cast<h16x8_t*>(&Al[o]) = al;
     }
-    const int o = col * CS + 8 * rg;
-    *reinterpret_cast<h16x8_t*>(&Ah[buf][o]) = ah; *reinterpret_cast<h16x8_t*>(&Al[buf][o]) = al;
-    *reinterpret_cast<h16x8_t*>(&Bh[buf][o]) = bh; *reinterpret_cast<h16x8_t*>(&Bl[buf][o]) = bl;
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+      h16x8_t bh, bl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)rb[c][e]; bh[e] = h; bl[e] = (_Float16)(rb[c][e] - (float)h); }
+      const int o = buf * NW * CS + (col + 64 * c) * CS + 8 * rg;
+      *reinterpret_cast<h16x8_t*>(&Bh[o]) = bh; *reinterpret_cast<h16x8_t*>(&Bl[o]) = bl;
+    }
   };
   int buf = 0;
   if (m_lo < m_hi) { gload(m_lo); lstore(0); }
@@ -142,27 +162,43 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
   for (int m0 = m_lo; m0 < m_hi; m0 += 32) {
     const bool more = m0 + 32 < m_hi;
     if (more) gload(m0 + 32);                              // next tile's global loads fly under this tile's MFMAs
-    const int oa = (wk * 32 + l31) * CS + 8 * half, ob = (wn * 32 + l31) * CS + 8 * half;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const h16x8_t ah = *reinterpret_cast<const h16x8_t*>(&Ah[buf][oa + 16 * st]);
-      const h16x8_t al = *reinterpret_cast<const h16x8_t*>(&Al[buf][oa + 16 * st]);
-      const h16x8_t bh = *reinterpret_cast<const h16x8_t*>(&Bh[buf][ob + 16 * st]);
-      const h16x8_t bl = *reinterpret_cast<const h16x8_t*>(&Bl[buf][ob + 16 * st]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      h16x8_t ah[TK], al[TK], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TK; ++i) {
+        const int oa = buf * KW * CS + ((wk * TK + i) * 32 + l31) * CS + 8 * half + 16 * st;
+        ah[i] = *reinterpret_cast<const h16x8_t*>(&Ah[oa]); al[i] = *reinterpret_cast<const h16x8_t*>(&Al[oa]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ob = buf * NW * CS + ((wn * TN + j) * 32 + l31) * CS + 8 * half + 16 * st;
+        bh[j] = *reinterpret_cast<const h16x8_t*>(&Bh[ob]); bl[j] = *reinterpret_cast<const h16x8_t*>(&Bl[ob]);
+      }
+#pragma unroll
+      for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-  const int n = n0 + wn * 32 + l31;
-  if (n < N)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = k0 + wk * 32 + frow_t(r, half);
-      if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[r] * binv);
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + l31;
+      if (n < N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = k0 + (wk * TK + i) * 32 + frow_t(r, half);
+          if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv);
+        }
     }
 }
 // max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0.
@@ -232,18 +268,41 @@ hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
                           int shift, hipStream_t s) {
   return launch_gemm_tn_scaled(A, lda, B, ldb, C, ldc, M, K, N, T, shift, nullptr, s);
 }
-hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
-                                 int shift, const unsigned* b_absmax, hipStream_t s) {
-  const int tk = (K + 63) / 64, tn = (N + 63) / 64;
-  static const int target = getenv("VNR_GEMM_TN_WGS") ? atoi(getenv("VNR_GEMM_TN_WGS")) : 1024;     // measurement knob
+template <int TK, int TN>
+static hipError_t launch_tn_cfg(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+                                const unsigned* b_absmax, int target, hipStream_t s) {
+  constexpr int KW = 64 * TK, NW = 64 * TN;
+  const int tk = (K + KW - 1) / KW, tn = (N + NW - 1) / NW;
   int splits = target / (tk * tn); if (splits < 1) splits = 1;
-  int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
+  int max_splits = (M + 127) / 128; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
   int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
   splits = (M + rps - 1) / rps;
-  static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
-  if (v1) vnr_launch(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
-  else vnr_launch(gemm_tn_split_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
+  const size_t lds = (size_t)2 * 2 * (KW + NW) * 40 * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) { (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<TK, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  vnr_launch(gemm_tn_split_kernel<TK, TN>, dim3(tk, tn, splits), dim3(256), (unsigned)lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
   return hipGetLastError();
+}
+hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
+                                 int shift, const unsigned* b_absmax, hipStream_t s) {
+  static const int target = getenv("VNR_GEMM_TN_WGS") ? atoi(getenv("VNR_GEMM_TN_WGS")) : 1024;     // measurement knob
+  static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
+  if (v1) {
+    const int tk = (K + 63) / 64, tn = (N + 63) / 64;
+    int splits = target / (tk * tn); if (splits < 1) splits = 1;
+    int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
+    int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M + rps - 1) / rps;
+    vnr_launch(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+    return hipGetLastError();
+  }
+  // 64 x 64 workgroup tiles by default.  The 128 x 128 variant (VNR_GEMM_TN_TILE=2) measured SLOWER on the T1 step (45.9 vs
+  // 43.8 ms): 80 KB of LDS leave one workgroup per CU where the 64 x 64 kernel keeps three, and this kernel lives on
+  // co-resident workgroups hiding each other's barrier per 32-row tile, not on operand reuse
+  static const int force = getenv("VNR_GEMM_TN_TILE") ? atoi(getenv("VNR_GEMM_TN_TILE")) : 0;
+  const bool big = force == 2 && K >= 128 && N >= 128 && (long long)((K + 127) / 128) * ((N + 127) / 128) * ((M + 127) / 128) >= 256;
+  if (big) return launch_tn_cfg<2, 2>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target / 2, s);
+  return launch_tn_cfg<1, 1>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target, s);
 }
 
 // ---- attention backward -----------------------------------------------------------------------------------------------
@@ -666,9 +725,85 @@ ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int
     atomicAdd(dbeta + c, rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c]);
   }
 }
+// Second generation (round 2) for D = 64 * NJ (256: NJ = 4, 512: NJ = 8): 16 lanes per row with 16-byte accesses (16 rows per
+// workgroup trip instead of 4), three 4-step reductions per row instead of five 6-step ones.  The first version moved 4 bytes
+// per lane per access and spent most of its 46 us per call in 30 dependent shuffles per row.
+template <int NJ>
+__global__ void __launch_bounds__(256)
+ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, float* dv, float* dgamma, float* dbeta) {
+  constexpr int D = 64 * NJ;
+  const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;           // 16 row groups of 16 lanes
+  float4 ga[NJ], pg[NJ], pb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    ga[j] = *reinterpret_cast<const float4*>(gamma + 64 * j + 4 * l16);
+    pg[j] = make_float4(0.f, 0.f, 0.f, 0.f); pb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto red16 = [](float x) { x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 1, 64); return x; };
+  for (int r = blockIdx.x * 16 + rg; r < rows; r += gridDim.x * 16) {
+    float4 x[NJ], d[NJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      x[j] = *reinterpret_cast<const float4*>(v + (size_t)r * D + 64 * j + 4 * l16);
+      d[j] = *reinterpret_cast<const float4*>(dy + (size_t)r * D + 64 * j + 4 * l16);
+      s += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+    }
+    const float mu = red16(s) * (1.f / (float)D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      x[j].x -= mu; x[j].y -= mu; x[j].z -= mu; x[j].w -= mu;
+      q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+    }
+    const float rstd = 1.0f / sqrtf(red16(q) * (1.f / (float)D) + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
+    float4 g[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      x[j].x *= rstd; x[j].y *= rstd; x[j].z *= rstd; x[j].w *= rstd;            // xhat
+      g[j] = make_float4(d[j].x * ga[j].x, d[j].y * ga[j].y, d[j].z * ga[j].z, d[j].w * ga[j].w);
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * x[j].x + g[j].y * x[j].y) + (g[j].z * x[j].z + g[j].w * x[j].w);
+      pg[j].x += d[j].x * x[j].x; pg[j].y += d[j].y * x[j].y; pg[j].z += d[j].z * x[j].z; pg[j].w += d[j].w * x[j].w;
+      pb[j].x += d[j].x; pb[j].y += d[j].y; pb[j].z += d[j].z; pb[j].w += d[j].w;
+    }
+    s1 = red16(s1) * (1.f / (float)D); s2 = red16(s2) * (1.f / (float)D);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 o = make_float4(rstd * (g[j].x - s1 - x[j].x * s2), rstd * (g[j].y - s1 - x[j].y * s2),
+                                   rstd * (g[j].z - s1 - x[j].z * s2), rstd * (g[j].w - s1 - x[j].w * s2));
+      *reinterpret_cast<float4*>(dv + (size_t)r * D + 64 * j + 4 * l16) = o;
+    }
+  }
+  // column partials: 16 row groups -> 1 through LDS (one [16][D] buffer, used for dgamma then for dbeta), then one atomic per
+  // column per workgroup
+  __shared__ float red[16][D + 4];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(&red[rg][64 * j + 4 * l16]) = pass == 0 ? pg[j] : pb[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += red[k][c];
+      atomicAdd((pass == 0 ? dgamma : dbeta) + c, a);
+    }
+    __syncthreads();
+  }
+}
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma,
                          float* dbeta, hipStream_t s) {
   if (D > 512) return hipErrorInvalidValue;
+  static const bool v1 = getenv("VNR_LN_BWD_V1") != nullptr;          // A/B switch: the first-generation wave-per-row kernel
+  const bool al = !(((size_t)v | (size_t)dy | (size_t)dv | (size_t)gamma) & 15);
+  if (!v1 && al && (D == 256 || D == 512)) {
+    int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, dgamma, dbeta);
+    else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, dgamma, dbeta);
+    return hipGetLastError();
+  }
   int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
   vnr_launch(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
   return hipGetLastError();

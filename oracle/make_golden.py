@@ -88,6 +88,26 @@ def build_ref(name):
     return out
 
 
+def build_ref_nsample(n_sample=2):
+    """VAENAR.call with hps.Train.num_samples = 2 (models.py:146-178), evaluation mode, by the reference's own Python."""
+    from oracle.run_reference_on_shim import reference_call
+    hps = tiny_hps()
+    hps.Train.num_samples = n_sample
+    w = init_weights(hps, seed=7, mode="synthetic")
+    b = make_batch(vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, seed=7, B=3, T_text=11, T_mel=40,
+                   ragged=True, text_step=3, mel_step=7)
+    r = np.random.Generator(np.random.PCG64(8))
+    mels = r.standard_normal((3, 40, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((3, n_sample, 20, hps.Common.latent_dim)).astype(np.float32)
+    outs, l2, kl, ll, ali = reference_call(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps)
+    out = dict(n_sample=np.int64(n_sample), ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], mels=mels, eps=eps,
+               outs=np.asarray(outs, np.float32), l2=np.asarray(l2, np.float64), kl=np.asarray(kl, np.float64), length=np.asarray(ll, np.float64),
+               weights_sha256=np.frombuffer(weights_digest(w).encode(), np.uint8))
+    for k, v in ali.items():
+        out["ali_" + k] = np.asarray(v, np.float32)
+    return out
+
+
 def build_train(name="train_tiny"):
     """Training-step fixture (train.py:127-138) from the autograd restatement: losses, the gradient of every trainable
     variable and the displacement of every variable after one Keras Adam step, each as a 19-number digest."""
@@ -188,6 +208,8 @@ def main():
         for name in REF_CASES:
             np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref(name))
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python over the tf shim)")
+        np.savez_compressed(os.path.join(d, "refshim_nsample2.npz"), **build_ref_nsample(2))
+        print("wrote refshim_nsample2", os.path.getsize(os.path.join(d, "refshim_nsample2.npz")) // 1024, "KiB (reference's own Python, num_samples = 2)")
         for name in REF_TRAIN_CASES:
             np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref_train(name))
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python, training mode, over the torch tf shim)")

@@ -185,3 +185,23 @@ def test_gpu_training_step_reproduces_golden():
         mx = max(ref[18], 1e-30)
         assert np.abs(d[:16] - ref[:16]).max() <= 2e-3 * mx + 1e-7, k                    # sampled entries
         assert abs(d[17] - ref[17]) <= 2e-3 * ref[17] + 1e-7 and abs(d[18] - ref[18]) <= 2e-3 * mx + 1e-7, k   # l2 norm, max
+
+
+def test_n_sample_2_fixture_equals_tiled_single_sample_oracle():
+    """tests/golden/refshim_nsample2.npz (the reference's own Python with hps.Train.num_samples = 2) against the NumPy oracle run
+    on the batch tiled n_sample times: the equivalence the engine-side implementation of n_sample > 1 relies on."""
+    from oracle.vaenar_numpy import Oracle
+    from vaenar_tts_amd.configs import tiny_hps
+    g = _load("refshim_nsample2")
+    hps = tiny_hps()
+    w = init_weights(hps, seed=7, mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode()
+    n = int(g["n_sample"])
+    rep = lambda a: np.repeat(a, n, axis=0)      # noqa: E731
+    B, _, Tz, C = g["eps"].shape
+    outs, l2, kl, ll, _ = Oracle(hps, w, np.float64).call(rep(g["ids"]), rep(g["mels"]), rep(g["mel_lengths"]), rep(g["text_lengths"]), 2,
+                                                          False, False, g["eps"].reshape(B * n, 1, Tz, C).astype(np.float64))
+    np.testing.assert_allclose(outs, g["outs"], atol=5e-6)
+    np.testing.assert_allclose(l2.reshape(B, n).mean(1), g["l2"], rtol=1e-5)
+    np.testing.assert_allclose(ll.reshape(B, n)[:, 0], g["length"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(kl.reshape(B, n).mean(1), g["kl"], rtol=1e-5, atol=2e-2)

@@ -305,3 +305,35 @@ def test_frame_counts_population():
     print("frame counts:", json.dumps(res))
     # the split path may not be worse than exact fp32 MFMA at deciding the integer
     assert res["split_encoder=1"]["mismatches"] <= res["split_encoder=0"]["mismatches"] + 1
+
+
+# ---- n_sample > 1 in VAENAR.call (models.py:146-178) -----------------------------------------------------------------------------
+def _nsample_fixture():
+    with np.load(os.path.join(ROOT, "tests", "golden", "refshim_nsample2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    hps = tiny_hps()
+    hps.Train.num_samples = int(g["n_sample"])
+    w = init_weights(hps, seed=7, mode="synthetic")
+    return g, hps, w
+
+
+def test_n_sample_2_matches_reference_python():
+    """hps.Train.num_samples = 2: decoded outputs for batch * n_sample latents, per-utterance terms averaged over the samples --
+    against a fixture made by the reference's own Python (oracle/make_golden.py: build_ref_nsample)."""
+    g, hps, w = _nsample_fixture()
+    model = VAENAR(hps, weights=w)
+    try:
+        assert model.n_sample == 2
+        outs, l2, kl, ll, ali = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,
+                                      reduce_loss=False, eps=g["eps"])
+        assert outs.shape == g["outs"].shape and np.abs(outs.numpy() - g["outs"]).max() < 2e-4
+        np.testing.assert_allclose(l2, g["l2"], rtol=1e-4)
+        np.testing.assert_allclose(ll, g["length"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(kl, g["kl"], rtol=1e-3, atol=6e-2)
+        for k in ali:
+            np.testing.assert_allclose(ali[k].numpy(), g["ali_" + k], atol=1e-5)
+        _, l2m, klm, llm, _ = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,
+                                    reduce_loss=True, eps=g["eps"], return_alignments=False)
+        np.testing.assert_allclose([l2m, llm], [g["l2"].mean(), g["length"].mean()], rtol=1e-3)
+    finally:
+        model.engine.close()

@@ -129,8 +129,32 @@ class VAENAR:
         reduce_loss the three losses are means over the batch (models.py:84,92,101), otherwise [B] vectors.
         ``eps`` [B,1,Tz,C] or [B,Tz,C] replaces tf.random.normal of posterior.reparameterize
         (posterior.py:35); default: drawn on the device (prior.draw).  (The backward pass and Adam: ``train_step``.)"""
-        assert self.n_sample == 1
         eng = self.engine
+        ns = int(self.n_sample)
+        if ns > 1:
+            # n_sample > 1 (models.py:146-178): the reference tiles text_embd / targets / lengths n_sample times (sample index
+            # inner) and decodes batch * n_sample latents.  Same arithmetic here by tiling the INPUTS: the encoder / posterior of
+            # a tiled batch are the same rows repeated (and the same BatchNorm statistics), every (utterance, sample) row then
+            # carries its own eps; the per-utterance terms are means over the samples (models.py:67-95).  Evaluation mode only.
+            assert not training, "n_sample > 1 is supported for the evaluation forward (dev_step); train_step uses n_sample = 1 (hparams.py:247)"
+            assert eps is not None, "n_sample > 1: pass eps [B, n_sample, Tz, C]"
+            ids_h = np.asarray(inputs.numpy() if hasattr(inputs, "numpy") and not isinstance(inputs, np.ndarray) else inputs)
+            B0 = ids_h.shape[0]
+            rep = lambda a: np.repeat(np.asarray(a.numpy() if hasattr(a, "numpy") and not isinstance(a, np.ndarray) else a), ns, axis=0)   # noqa: E731
+            e4 = np.asarray(eps, np.float32)
+            assert e4.ndim == 4 and e4.shape[:2] == (B0, ns), e4.shape
+            self.n_sample = 1
+            try:
+                outs, l2, kl, ll, ali = self.__call__(rep(ids_h), rep(mel_targets), rep(mel_lengths),
+                                                      None if text_lengths is None else rep(text_lengths), reduction_factor, False, False,
+                                                      e4.reshape(B0 * ns, e4.shape[2], e4.shape[3]), return_alignments, dropout_seed)
+            finally:
+                self.n_sample = ns
+            l2, kl, ll = (t.numpy().reshape(B0, ns) for t in (l2, kl, ll))
+            l2, kl, ll = l2.mean(1, dtype=np.float32), kl.mean(1, dtype=np.float32), ll[:, 0]
+            if reduce_loss:
+                l2, kl, ll = (np.float32(t.mean(dtype=np.float32)) for t in (l2, kl, ll))
+            return outs, l2, kl, ll, ali
         eng.set_option("training", 1 if training else 0)
         if training:
             eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)

@@ -57,7 +57,9 @@ def test_round2_line_is_coherent():
     assert r["peak"] == (157.3 if r["class"] == "gemm_fp32" else 2500.0)
     if r["class"] != "gemm_fp32":
         assert abs(r["achieved"] - 3 * r["algorithmic_tflops"]) < 1e-6 * r["achieved"]
-    assert d["end_to_end"]["kernel_ms_sum"] <= d["ms_per_step"] * 1.02       # same schedule: kernel time fits inside the step
+    # same schedule: the kernel time of the profiled pass matches the step (the event-instrumented launches run a few per cent
+    # slower than the plain ones of the timed region; with several batches in flight the sum would be 1.5x the step)
+    assert 0.85 * d["ms_per_step"] <= d["end_to_end"]["kernel_ms_sum"] <= 1.08 * d["ms_per_step"]
     if r["traffic"] is not None:
         assert d["kernel_source_digest"] in r["traffic_source"] or "same kernel sources" in r["traffic_source"]
 

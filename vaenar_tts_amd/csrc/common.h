@@ -202,6 +202,16 @@ struct ChainArgs {
   int M, D, nstages;
   int rows64;                  // 1: 64-row panels (M/64 workgroups), 0: 32-row panels -- see gemm3.hip
   const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded
+  // Fused cross-attention (attention.py:445-447; round 2): before stage `att_stage` runs (<= 0 = none), the workgroup computes the
+  // cross-attention of its 32 rows itself -- queries = panel 1 (left there by the query-projection stage), K / V = the block's
+  // operand images (one 8 KiB tile per (batch, head, 32 keys), Tk <= 128) -- and writes the context into panel 1: chain B,
+  // the attention kernel and chain C of a CrossAttentionBLK become ONE launch (no alignments: prior / posterior blocks).
+  int att_stage;
+  const char* att_K; const char* att_V;        // image bases of this block: [B][H][ceil(Tk/32)][8 KiB]
+  const int32_t* att_qlen; const int32_t* att_klen;
+  int att_Tq, att_Tk, att_B;                   // rows per batch element, keys, batch
+  float att_temp;
+  int att_lds;                                 // (set by launch_panel_chain) byte offset of the merge scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
   ChainStage st[kMaxChainStages];

@@ -124,6 +124,7 @@ struct vnr_context {
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
+  bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
   bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
   bool aoi_enabled = true;       // engine option "attn_presplit": cross-attention on producer-split operands (attention3.hip)
@@ -540,17 +541,25 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   const int PT = D / 32, nchunks = (F + 255) / 256;
   if (chain && 1 + 2 * nchunks + tail_stages > kMaxChainStages) chain = false;
 
+  // one launch for the whole block after the self-attention (chain B -> cross-attention -> chain C): the query projection leaves
+  // q in LDS, the workgroup attends over the text K/V images itself and continues with the context in place (gemm3.hip,
+  // ChainArgs::att_stage).  Needs the operand images of the memory, no alignment output, 32-row panels, four 64-wide heads.
+  const bool fused = chain && ka && !ali && h->fuse_xattn && !h->chain_rows64 && D == 256 && heads * 64 == D && Tt <= 128 &&
+                     3 + 2 * nchunks + tail_stages <= kMaxChainStages;
+  ChainArgs cb; memset(&cb, 0, sizeof(cb));
   if (chain) {
     // chain B: y = LN1(att_proj1(concat(x, sa)) + x) ; q = y . Wq
-    ChainArgs c; memset(&c, 0, sizeof(c));
+    ChainArgs& c = cb;
     c.in0 = x; c.ld0 = D; c.in1 = sa; c.ld1 = D; c.M = M; c.D = D; c.nstages = 2;
     ChainStage& s0 = c.st[0];
     s0.w = r_p1.opm; s0.kt_total = r_p1.kt_total; s0.kt0 = 0; s0.nk = 2 * PT; s0.n = D; s0.a0 = 0; s0.a1 = 1; s0.asw = PT; s0.bias = k.proj1_b;
-    s0.act = ACT_IDENTITY; s0.res = 0; s0.gamma = k.ln1_g; s0.beta = k.ln1_b; s0.acc_mode = 0; s0.out = y; s0.ldo = D; s0.dst = 0; s0.scale = r_p1.scale;
+    s0.act = ACT_IDENTITY; s0.res = 0; s0.gamma = k.ln1_g; s0.beta = k.ln1_b; s0.acc_mode = 0; s0.out = fused ? nullptr : y; s0.ldo = D; s0.dst = 0; s0.scale = r_p1.scale;
     ChainStage& s1 = c.st[1];
     s1.w = r_q.opm; s1.kt_total = r_q.kt_total; s1.kt0 = 0; s1.nk = PT; s1.n = D; s1.a0 = 0; s1.a1 = 0; s1.asw = PT; s1.bias = nullptr; s1.act = ACT_IDENTITY;
-    s1.res = -1; s1.gamma = nullptr; s1.beta = nullptr; s1.acc_mode = 0; s1.out = q; s1.ldo = D; s1.dst = -1; s1.scale = r_q.scale; s1.out_fmt = ka ? 1 : 0; s1.aoi_T = Tq;
-    TRY(run_chain(h, c, 2.0 * M * D * (2.0 * D + D)));
+    s1.res = -1; s1.gamma = nullptr; s1.beta = nullptr; s1.acc_mode = 0; s1.scale = r_q.scale;
+    if (fused) { s1.out = nullptr; s1.ldo = 0; s1.dst = 1; s1.out_fmt = 0; }
+    else { s1.out = q; s1.ldo = D; s1.dst = -1; s1.out_fmt = ka ? 1 : 0; s1.aoi_T = Tq; }
+    if (!fused) TRY(run_chain(h, c, 2.0 * M * D * (2.0 * D + D)));
   } else {
     g = GemmArgs(); g.A1 = x; g.lda1 = D; g.K1 = D; g.A2 = sa; g.lda2 = D; g.K = 2 * D; g.Wt = k.proj1_wt; g.ldw = 2 * D;
     g.bias = k.proj1_b; g.residual = x; g.ldr = D; g.ln_gamma = k.ln1_g; g.ln_beta = k.ln1_b; g.C = y; g.ldc = D; g.M = M; g.N = D;
@@ -561,7 +570,9 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     TRY(run_gemm(h, g));
   }
   // cross attention
-  if (ka) {
+  if (fused) {
+    // (inside the chain launch below)
+  } else if (ka) {
     Attn3Args t;
     t.Qi = reinterpret_cast<const char*>(q);
     t.Ki = ka->d.qk + (size_t)kv_blk * ka->d.blk_bytes; t.Vi = ka->d.vt + (size_t)kv_blk * ka->d.blk_bytes;
@@ -581,6 +592,13 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     ChainArgs c; memset(&c, 0, sizeof(c));
     c.in0 = y; c.ld0 = D; c.in1 = ca; c.ld1 = D; c.M = M; c.D = D;
     int n = 0;
+    if (fused) {                                           // chain B's two stages first, then the attention, then chain C
+      c = cb;
+      n = 2;
+      c.att_stage = 2;
+      c.att_K = ka->d.qk + (size_t)kv_blk * ka->d.blk_bytes; c.att_V = ka->d.vt + (size_t)kv_blk * ka->d.blk_bytes;
+      c.att_qlen = q_len; c.att_klen = m_len; c.att_Tq = Tq; c.att_Tk = Tt; c.att_B = B; c.att_temp = tau;
+    }
     ChainStage* s = &c.st[n++];
     s->w = r_p2.opm; s->kt_total = r_p2.kt_total; s->kt0 = 0; s->nk = 2 * PT; s->n = D; s->a0 = 0; s->a1 = 1; s->asw = PT; s->bias = k.proj2_b; s->act = ACT_IDENTITY;
     s->res = 0; s->gamma = k.ln2_g; s->beta = k.ln2_b; s->acc_mode = 0; s->out = nullptr; s->ldo = 0; s->dst = 0; s->scale = r_p2.scale;
@@ -598,6 +616,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
       s->out = last ? out : nullptr; s->ldo = D; s->dst = last ? 0 : -1; s->scale = r_f2.scale;
     }
     double fl = 2.0 * M * D * (2.0 * D) + 4.0 * M * (double)D * F;
+    if (fused) fl += 2.0 * M * D * (2.0 * D + D) + 4.0 * (double)B * heads * Tq * (double)Tt * 64;     // chain B + the attention products
     for (size_t i = 0; i < tails.size(); ++i)
       for (int c0 = 0; c0 < tails[i].n; c0 += 256) {
         const int w = (tails[i].n - c0 < 256) ? tails[i].n - c0 : 256;
@@ -1916,6 +1935,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "chain_rows64")) { h->chain_rows64 = value != 0; return VNR_OK; }
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
+  if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }

@@ -171,6 +171,143 @@ panel_chain_kernel(const ChainArgs g) {
 
 #pragma unroll 1
   for (int si = 0; si < g.nstages; ++si) {
+    if (RT == 1 && g.att_stage > 0 && si == g.att_stage) {
+      // ================= fused cross-attention of this panel (see ChainArgs::att_stage) ===================================
+      // wave w: head = w >> 1, key blocks 2 (w & 1) and 2 (w & 1) + 1 (32 keys each, Tk <= 128).  Per block, as attn3_kernel:
+      // S^T = K.Q^T (lane = query row: softmax statistics in-lane + one half swap), logits in the log2 domain, online softmax
+      // over the wave's two blocks, O^T += V^T.P^T.  The two waves of a head are merged through LDS; the context replaces the
+      // queries in panel 1 (split fp16, like any stage output).  A flat 32-row panel can straddle two batch elements (T is not
+      // a multiple of 32): then the whole computation runs once per element and every lane keeps the pass of its own row.
+      typedef _Float16 h8a __attribute__((ext_vector_type(8)));
+      const int head = wave >> 1, kp = wave & 1;
+      const int H = g.D >> 6, TTk = (g.att_Tk + 31) >> 5;
+      const int row = m0 + l31;                                       // this lane's query row (global)
+      int b_lo = m0 / g.att_Tq, b_hi = (m0 + 31 < g.M ? m0 + 31 : g.M - 1) / g.att_Tq;
+      b_lo = __builtin_amdgcn_readfirstlane(b_lo); b_hi = __builtin_amdgcn_readfirstlane(b_hi);
+      char* P1 = panel_ptr(1);
+      float* xs = reinterpret_cast<float*>(smem + g.att_lds);        // merge scratch: [4 heads][32 rows][64 + 2] floats
+      const float c2 = (g.att_temp != 1.0f) ? 0.125f * 1.44269504088896340736f / g.att_temp : 0.125f * 1.44269504088896340736f;
+      for (int bb = b_lo; bb <= b_hi; ++bb) {
+        const int qlen = g.att_qlen ? g.att_qlen[bb] : g.att_Tq, klen = g.att_klen ? g.att_klen[bb] : g.att_Tk;
+        const int tq = row - bb * g.att_Tq;                           // position of this lane's row inside element bb
+        const bool mine = row < g.M && tq >= 0 && tq < g.att_Tq;
+        const bool qvalid = mine && tq < qlen;
+        f32x16 O[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+        for (int x = 0; x < 2; ++x) {
+          const int kb = 2 * kp + x;
+          if (32 * kb >= g.att_Tk) break;                             // (wave-uniform)
+          const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane * 16;
+          const char* vt = g.att_V + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane * 16;
+          h8a khi[4], klo[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { khi[t] = *reinterpret_cast<const h8a*>(kt + 1024 * t); klo[t] = *reinterpret_cast<const h8a*>(kt + 4096 + 1024 * t); }
+          f32x16 sacc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const h8a qh = *reinterpret_cast<const h8a*>(P1 + panel_off(l31, 2 * head + (t >> 1), 2 * (t & 1) + half));
+            const h8a ql = *reinterpret_cast<const h8a*>(P1 + panel_off(l31, 2 * head + (t >> 1), 4 + 2 * (t & 1) + half));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[t], qh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo[t], qh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[t], ql, sacc, 0, 0, 0);
+          }
+          h8a vhi[2][2], vlo[2][2];
+#pragma unroll
+          for (int y = 0; y < 4; ++y) { vhi[y >> 1][y & 1] = *reinterpret_cast<const h8a*>(vt + 1024 * y); vlo[y >> 1][y & 1] = *reinterpret_cast<const h8a*>(vt + 4096 + 1024 * y); }
+          const int kb0 = 32 * kb;
+          float mt = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = kb0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float sv = sacc[r] * c2;
+            sv = (qvalid && j < klen) ? sv : kMaskFill * 1.44269504088896340736f;     // attention.py:240
+            if (j >= g.att_Tk) sv = -INFINITY;                                             // key does not exist
+            sacc[r] = sv;
+            mt = fmaxf(mt, sv);
+          }
+          mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+          const float m_new = fmaxf(fmaxf(m_run, mt), -3.0e38f);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                      // 0 on the first block
+          float ps = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float pr = __builtin_amdgcn_exp2f(sacc[r] - m_new); sacc[r] = pr; ps += pr; }
+          ps += __shfl_xor(ps, 32, 64);
+          l_run = l_run * alpha + ps;
+          if (x > 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) O[nb][r] *= alpha;
+          }
+          m_run = m_new;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            if (kb0 + 32 > g.att_Tk) {                                 // positions past Tk hold whatever the workspace held
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (key >= g.att_Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+              }
+            }
+            h8a phi, plo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)sacc[8 * tp + e]; phi[e] = hh; plo[e] = (_Float16)(sacc[8 * tp + e] - (float)hh); }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+              O[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][nb], phi, O[nb], 0, 0, 0);
+              O[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[tp][nb], phi, O[nb], 0, 0, 0);
+              O[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][nb], plo, O[nb], 0, 0, 0);
+            }
+          }
+        }
+        // merge the two waves of this head: kp = 1 parks (m, l, O) in LDS, kp = 0 combines.  O^T layout: lane = query l31,
+        // register r of block nb = channel 32 nb + frow(r, half)
+        float* xh = xs + head * (32 * 66);
+        const float mfin = fmaxf(m_run, -3.0e38f);
+        if (kp == 1) {
+          if (half == 0) { xh[l31 * 66 + 64] = mfin; xh[l31 * 66 + 65] = l_run; }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xh[l31 * 66 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half] = O[nb][r];
+        }
+        lds_barrier();
+        if (kp == 0) {
+          const float m1 = xh[l31 * 66 + 64], l1 = xh[l31 * 66 + 65];
+          const float M = fmaxf(mfin, m1);
+          const float f0 = __builtin_amdgcn_exp2f(mfin - M), f1 = __builtin_amdgcn_exp2f(m1 - M);
+          const float linv = 1.0f / (l_run * f0 + l1 * f1);                                // softmax denominator, attention.py:242
+          // the context replaces the queries of this lane's row in panel 1 (tiles 2 head, 2 head + 1: read by this head's two
+          // waves only, and both are past their S^T products of this pass: the barrier above).  Rows of the other batch element of a
+          // straddling panel keep their queries for the next pass.
+          if (mine) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                h16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int r = 4 * q + e;
+                  const float xv = (O[nb][r] * f0 + xh[l31 * 66 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half] * f1) * linv;
+                  const _Float16 hh = (_Float16)xv; hi[e] = hh; lo[e] = (_Float16)(xv - (float)hh);
+                }
+                const int pcol = 8 * q + 4 * half;                     // column inside the 32-channel tile 2 head + nb
+                *reinterpret_cast<h16x4*>(P1 + panel_off(l31, 2 * head + nb, pcol >> 3) + (pcol & 4) * 2) = hi;
+                *reinterpret_cast<h16x4*>(P1 + panel_off(l31, 2 * head + nb, 4 + (pcol >> 3)) + (pcol & 4) * 2) = lo;
+              }
+          }
+        }
+        lds_barrier();                                                 // scratch free for the next pass; the context of this pass is in place
+      }
+    }
     const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
     const bool wave_on = 32 * wave < st.n;               // this wave owns output columns 32w .. 32w+31
     const char* const Ap0 = panel_ptr(st.a0);
@@ -533,8 +670,14 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     st.lds_ln = (st.gamma && st.acc_mode != 1 && st.acc_mode != 2) ? g.nstages * 256 + 512 * nln++ : -1;
   }
   const int prm_bytes = (g.nstages * 256 + nln * 512) * 4;
-  if (g.rows64) return launch_chain_rt<2>(g, ChainLds<2>::PRM_OFF + prm_bytes, s);
-  return launch_chain_rt<1>(g, ChainLds<1>::PRM_OFF + prm_bytes, s);
+  if (g.rows64) { if (g.att_stage > 0) return hipErrorInvalidValue; return launch_chain_rt<2>(g, ChainLds<2>::PRM_OFF + prm_bytes, s); }
+  int lds = ChainLds<1>::PRM_OFF + prm_bytes;
+  if (g.att_stage > 0) {                                // merge scratch of the fused cross-attention: [D / 64 heads][32 rows][66 floats]
+    if (g.att_stage >= g.nstages || g.D != 256 || !g.att_K || !g.att_V || g.att_Tk <= 0 || g.att_Tk > 128 || g.att_Tq <= 0) return hipErrorInvalidValue;
+    g.att_lds = (lds + 15) & ~15;
+    lds = g.att_lds + (g.D >> 6) * 32 * 66 * 4;
+  }
+  return launch_chain_rt<1>(g, lds, s);
 }
 
 }  // namespace vnr

@@ -208,6 +208,13 @@ int vnr_op_attention(vnr_handle h, const float *d_q, int ldq, const float *d_k, 
 /* tf.keras.layers.LayerNormalization() over the last axis (eps 1e-3): rows x dim. */
 int vnr_op_layer_norm(vnr_handle h, const float *d_x, const float *d_gamma, const float *d_beta,
                       int rows, int dim, float *d_y);
+/* The kernel gradient tape.gradient (train.py:136) produces for one Dense kernel or one tap of a Conv1D kernel (modules/utils.py:
+ * 33-38, 76-85): d_dw [K,N] = sum over rows m of x[m + shift]^T . dy[m]; a row whose shifted partner falls outside its own
+ * utterance (T rows per utterance, T <= 0: one utterance of M rows) contributes nothing ('same' padding).  d_x rows of ldx floats,
+ * d_dy rows of lddy floats.  This is the operation behind every weight gradient inside vnr_train_step (split-fp16 MFMA, dy
+ * pre-scaled by its maximum); exposed for the op-level parity tests.  Synchronises the stream. */
+int vnr_op_kernel_grad(vnr_handle h, const float *d_x, int ldx, const float *d_dy, int lddy, int M, int K,
+                       int N, int T, int shift, float *d_dw);
 /* tf.random.normal(shape, mean=0, stddev) of BasePrior._initial_sample (modules/prior.py:35, stddev = temperature) and
  * BasePosterior.reparameterize (modules/posterior.py:35): n floats ~ N(0, stddev^2) written on the device by a counter-based
  * Philox-4x32-10 generator + Box-Muller (element block j = elements 4j..4j+3 <- counter j + offset, key = seed), so a

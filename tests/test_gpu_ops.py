@@ -290,3 +290,32 @@ def test_dense_split_fp16(eng, m, k1, k2, n, ln):
         ref = O.layer_norm(f(res) + ref, f(g), f(be))
     scale = np.abs(x).max(1, keepdims=True) if not ln else 1.0
     np.testing.assert_array_less(np.abs(got - ref) / np.maximum(scale, 1.0), 3e-5)
+
+
+@pytest.mark.parametrize("B,T,K,N,shift,scale", [
+    (32, 400, 256, 256, 0, 1.0),        # Dense of a decoder block at T1 size: the 128 x 128 transposing-read kernel
+    (16, 100, 512, 256, 0, 3e-9),       # gradient of loss-scale magnitude (kl_weight 1e-5): the pre-scaling by max |dy|
+    (4, 200, 256, 384, -2, 1.0),        # Conv1D tap left of centre: rows that would cross an utterance boundary drop out
+    (4, 200, 128, 1024, 1, 1.0),        # tap right of centre, wide output
+    (3, 97, 260, 132, 0, 1.0),          # ragged tile edges (K, N multiples of 4 only), M not a multiple of 32
+    (2, 46, 80, 256, 0, 1.0),           # narrow input: second-generation kernel (K < 128)
+    (5, 77, 256, 3, 0, 1.0),            # N = 3: second-generation kernel
+])
+def test_kernel_gradient_gemm(eng, B, T, K, N, shift, scale):
+    """train.py:136 tape.gradient w.r.t. a Dense kernel / one Conv1D tap: dW = sum_m x[m + shift]^T dy[m] inside each utterance.
+    Transpose-detecting inputs (K != N, random), compared with float64; 22-bit operands -> 2e-6 of the largest entry."""
+    r = rng(B * T + K + N)
+    M = B * T
+    x = r.standard_normal((M, K)).astype(np.float32)
+    dy = (scale * r.standard_normal((M, N))).astype(np.float32)
+    dx, ddy = eng.to_device(x), eng.to_device(dy)
+    dw = eng.empty((K, N))
+    _lib.check(eng.lib.vnr_op_kernel_grad(eng.handle, dx.ptr, K, ddy.ptr, N, M, K, N, T, shift, dw.ptr), eng.handle)
+    x3 = x.astype(np.float64).reshape(B, T, K)
+    xs = np.zeros_like(x3)
+    if shift >= 0:
+        xs[:, :T - shift] = x3[:, shift:]
+    else:
+        xs[:, -shift:] = x3[:, :T + shift]
+    ref = np.einsum('btk,btn->kn', xs, dy.astype(np.float64).reshape(B, T, N))
+    np.testing.assert_allclose(dw.numpy(), ref, atol=2e-6 * np.abs(ref).max(), rtol=0)

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "vnr_op_conv1d_bn": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vnr_op_attention": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp],
     "vnr_op_layer_norm": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "vnr_op_kernel_grad": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "vnr_op_positional_encoding": [_vp, _i, _i, _f, _vp],
     "vnr_random_normal": [_vp, C.c_uint64, C.c_uint64, _f, _vp, _sz],
     "vnr_voc_mel_to_linear": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _f, _vp],

@@ -1861,6 +1861,22 @@ int vnr_op_layer_norm(vnr_handle h, const float* d_x, const float* d_gamma, cons
   return run_ln(h, d_x, d_gamma, d_beta, rows, dim, d_y);
 }
 
+// kernel gradient of one Dense / one Conv1D tap as tape.gradient produces it (train.py:136): dW[K][N] = sum_m x[m + shift]^T . dy[m],
+// rows that would cross an utterance boundary (T rows per utterance) skipped -- the op behind every weight gradient of vnr_train_step
+int vnr_op_kernel_grad(vnr_handle h, const float* d_x, int ldx, const float* d_dy, int lddy, int M, int K, int N, int T, int shift, float* d_dw) {
+  if (!h || !d_x || !d_dy || !d_dw || M <= 0 || K <= 0 || N <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  unsigned* amax = nullptr;
+  HIP_TRY(h, hipMalloc(&amax, sizeof(unsigned)));
+  HIP_TRY(h, hipMemsetAsync(amax, 0, sizeof(unsigned), h->stream));
+  HIP_TRY(h, hipMemsetAsync(d_dw, 0, (size_t)K * N * sizeof(float), h->stream));
+  HIP_TRY(h, launch_absmax2d(d_dy, lddy, M, N, amax, h->stream));
+  HIP_TRY(h, launch_gemm_tn_scaled(d_x, ldx, d_dy, lddy, d_dw, N, M, K, N, T > 0 ? T : M, shift, amax, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipFree(amax));
+  return VNR_OK;
+}
+
 // tf.random.normal(shape, stddev) on the device (prior.py:35, posterior.py:35)
 int vnr_random_normal(vnr_handle h, uint64_t seed, uint64_t offset, float stddev, float* d_out, size_t n) {
   if (!h || !d_out) return fail(h, VNR_ERR_ARG, "null argument");

@@ -201,6 +201,293 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
         }
     }
 }
+// Third generation of the kernel-gradient GEMM (round 2).  The second generation spends its time on memory latency: every lane
+// fetches sixteen 4-byte words per 32-row tile one tile ahead, three workgroups per CU hide each other's barrier, and a 64 x 64
+// tile feeds 6 MFMAs per wave per tile (12 % of the matrix pipe, 24 TFLOP/s algorithmic).  Here:
+//   * 128 x 128 output tile per workgroup (4 waves, 64 x 64 each): every row of A and B is fetched by half as many workgroups;
+//   * rows are fetched as float4 (a 32-lane group reads one 512-byte row piece), TWO 32-row tiles ahead, in two register sets;
+//   * the loader splits once into fp16 hi / lo planes in LDS, one 8-byte write per plane per float4.  Plane layout: per 32-column
+//     MFMA tile (stride 2048 + 64 bytes: the four tiles a row piece spans land in different banks), per 16-row MFMA step, per
+//     half h: one 512-byte block [8 rows: 4 g + jr][32 columns] holding rows 8 g + 4 h + jr of the step -- exactly what ONE
+//     transposing read of a wave covers, so every such read is 512 contiguous bytes (a row-major image with an XOR swizzle
+//     measured 3 us per 32-row tile: the transposing read's bank rules are its own);
+//   * the MFMA operands -- 8 consecutive rows of one column per lane -- are gathered by the gfx950 transposing LDS read
+//     (ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 columns] block, each lane supplying the address of 4 contiguous
+//     halves, and every lane receives one column; semantics pinned on the GPU by tools/probes/tr16_probe.hip), two reads per
+//     operand, so no lane ever stores or loads a single half.
+// Same contract as gemm_tn_split_kernel (conv-tap row shift inside an utterance, B pre-scaled by its launch-wide max, float
+// atomics over the row splits).  Needs 16-byte aligned rows (lda, ldb, K, N multiples of 4).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8_t __attribute__((__vector_size__(8 * sizeof(short))));
+__device__ __forceinline__ h16x8_t tn3_operand(const char* p) {
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 512));   // rows + 4: the next block
+  return __builtin_bit_cast(h16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ void tn3_barrier() {           // LDS traffic of this wave complete, then the workgroup barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// 768 threads: waves 0..3 multiply (64 x 64 outputs each), waves 4..11 load, split and store the next tile at the same time (two
+// loader waves per SIMD: while one waits for the address unit to take its next load the other converts) --
+// a timeline of the unspecialised version (profiles/r02_tn3_timeline.txt) showed one workgroup spending 1.0 kcyc per 32-row tile
+// in the MFMA phase, 0.95 in the conversion / LDS stores and 0.6 issuing the loads, strictly one after the other (all four
+// waves in lock step between barriers), and a second workgroup per CU did not get scheduled beside it.
+__global__ void __launch_bounds__(768)
+gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts) {
+  constexpr int TS = 2048 + 64;                            // one 32-column tile of a plane: [2 steps][2 halves][8 rows][32 halves] + pad
+  constexpr int PL = 4 * TS;                               // one plane of one stage: 32 rows x 128 halves
+  extern __shared__ __attribute__((aligned(16))) char tn3_smem[];      // [2 stages][A hi | A lo | B hi | B lo][PL]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // 1-D grid.  Consecutive workgroup ids go round-robin over the 8 XCDs, so within a group of 8 nt ids (nt = tiles per split)
+  // id j runs on XCD j % 8: it takes row split 8 g + j % 8 and tile j / 8 -- the nt tiles that re-read the same rows of A and B
+  // run on ONE XCD at the same time and share its L2
+  const int nt = tk * tn;
+  const int grp = blockIdx.x / (8 * nt), j_in = blockIdx.x - grp * 8 * nt;
+  const int split = grp * 8 + (j_in & 7), tile = j_in >> 3;
+  if (split >= splits) return;
+  const int k0 = (tile % tk) * 128, n0 = (tile / tk) * 128;
+  const int m_lo = split * rows_per_split;
+  int m_hi = m_lo + rows_per_split; if (m_hi > M) m_hi = M;
+  const int nsteps = (m_hi - m_lo + 31) / 32;
+  // measurement only (VNR_GEMM_TN3_TS): per wave [0] start, then one stamp per phase (see tools/tn3_timeline.py)
+  unsigned long long* ts = dbg_ts ? dbg_ts + ((size_t)blockIdx.x * 12 + wave) * 64 : nullptr;
+  int tsi = 1;
+  auto stamp = [&]() { if (ts && lane == 0 && tsi < 64) ts[tsi] = __builtin_amdgcn_s_memtime(); ++tsi; };
+  if (ts && lane == 0) ts[0] = __builtin_amdgcn_s_memtime();
+
+  if (wave >= 4) {
+    // ================= loader waves =================================================================================
+    const int ptid = tid - 256;
+    float bscale = 1.f;                                    // (see gemm_tn_split_kernel)
+    {
+      const unsigned bits = b_absmax ? *b_absmax : 0u;
+      const int e = (int)(bits >> 23) & 0xff;
+      if (e > 0 && e < 255) {
+        int sft = 14 - (e - 127);
+        if (sft > 126) sft = 126; if (sft < -126) sft = -126;
+        bscale = __uint_as_float((unsigned)(sft + 127) << 23);
+      }
+    }
+    // float4 number ptid & 31 of rows (ptid >> 5) + 16 i, i = 0..1
+    constexpr int RPT = 2, RS = 32 / RPT;                  // rows per thread, row stride
+    const int lrow = ptid >> 5, lc4 = ptid & 31;
+    const bool a_col = k0 + 4 * lc4 < K, b_col = n0 + 4 * lc4 < N;
+    // row m = lrow + 16 i: step m >> 4 = i, g = (m >> 3) & 1, h = (m >> 2) & 1, jr = m & 3
+    const int lds_w = (lc4 >> 3) * TS + ((lrow >> 2) & 1) * 512 + (4 * ((lrow >> 3) & 1) + (lrow & 3)) * 64 + (lc4 & 7) * 8;      // + i * 1024
+    // rows are read through buffer descriptors: a row that does not exist (beyond the split, or shifted across an utterance
+    // boundary) gets an out-of-range offset -- zeros, no memory traffic, and NO branch, so every tile issues exactly eight loads
+    // and the compiler's waits are exact counts (the other sets stay in flight), never a drain
+    // (descriptor of A based at row `shift`: the offsets below stay non-negative for taps left of centre; rows before the first are
+    //  never read -- they fail the utterance test)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A) + (ptrdiff_t)shift * lda, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned kOobT = 0x80000000u;
+    const unsigned a_c = (unsigned)(k0 + 4 * lc4) * 4u, b_c = (unsigned)(n0 + 4 * lc4) * 4u;
+    // per-row state: the byte offsets of the workgroup's first tile stay in registers (out of range for columns that do not
+    // exist) and the tile advance is the SCALAR offset operand of the buffer load; the position inside the utterance is kept
+    // incrementally (one division per row per workgroup, not per tile)
+    int mrow = m_lo + lrow;
+    int tpos[RPT];
+    unsigned offa[RPT], offb[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      tpos[i] = (mrow + RS * i) % T;
+      offa[i] = a_col ? (unsigned)(mrow + RS * i) * (unsigned)lda * 4u + a_c : kOobT;
+      offb[i] = b_col ? (unsigned)(mrow + RS * i) * (unsigned)ldb * 4u + b_c : kOobT;
+    }
+    const unsigned stepa = 32u * (unsigned)lda * 4u, stepb = 32u * (unsigned)ldb * 4u;
+    const int step_t = 32 % T;
+    unsigned soa = 0, sob = 0;
+    auto gload = [&](f32x4 (&ra)[RPT], f32x4 (&rb)[RPT]) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const bool mok = mrow + RS * i < m_hi;
+        const int tsh = tpos[i] + shift;
+        const bool aok = mok && tsh >= 0 && tsh < T;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aok ? offa[i] : kOobT, soa, 0));
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, mok ? offb[i] : kOobT, sob, 0));
+        tpos[i] += step_t;
+        if (tpos[i] >= T) tpos[i] -= T;
+      }
+      mrow += 32; soa += stepa; sob += stepb;
+    };
+    // hi = x rounded toward zero to fp16, lo = (x - hi) likewise: v_cvt_pkrtz packs two at a time and the difference is one mixed
+    // fma per element, x * scale - hi (the pair resolves 22 bits either way; truncation leaves a bias of ~2^-23 relative -- far
+    // inside the gradient tolerance).  `one` is 1.0 the optimiser cannot see, so that A takes the same single-instruction form.
+    typedef __fp16 pk2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    float one;
+    asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
+    auto split4 = [&](const f32x4& v, float sc, bool scaled, char* hi_p, char* lo_p) {
+      u32x2_t hi, lo;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const pk2_t h = scaled ? __builtin_amdgcn_cvt_pkrtz(x0 * sc, x1 * sc) : __builtin_amdgcn_cvt_pkrtz(x0, x1);
+        const pk2_t l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(x0, sc, -(float)h[0]), __builtin_fmaf(x1, sc, -(float)h[1]));
+        hi[e] = __builtin_bit_cast(unsigned, h); lo[e] = __builtin_bit_cast(unsigned, l);
+      }
+      *reinterpret_cast<u32x2_t*>(hi_p) = hi; *reinterpret_cast<u32x2_t*>(lo_p) = lo;
+    };
+    auto lstore = [&](const f32x4 (&ra)[RPT], const f32x4 (&rb)[RPT], int stage) {
+      char* base = tn3_smem + stage * 4 * PL + lds_w;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int o = i * 1024;
+        split4(ra[i], one, false, base + o, base + PL + o);
+        split4(rb[i], bscale, true, base + 2 * PL + o, base + 3 * PL + o);
+      }
+    };
+    // store one set and refill it four tiles ahead, row by row: every register quad is re-requested right after its conversion, so
+    // the address-unit queueing of the eight loads (0.5 - 0.7 kcyc when issued back to back) hides under the conversions
+    auto refill = [&](f32x4 (&ra)[RPT], f32x4 (&rb)[RPT], int stage) {
+      char* base = tn3_smem + stage * 4 * PL + lds_w;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int o = i * 1024;
+        const bool mok = mrow + RS * i < m_hi;
+        const int tsh = tpos[i] + shift;
+        const bool aok = mok && tsh >= 0 && tsh < T;
+        split4(ra[i], one, false, base + o, base + PL + o);
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aok ? offa[i] : kOobT, soa, 0));
+        split4(rb[i], bscale, true, base + 2 * PL + o, base + 3 * PL + o);
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, mok ? offb[i] : kOobT, sob, 0));
+        tpos[i] += step_t;
+        if (tpos[i] >= T) tpos[i] -= T;
+      }
+      mrow += 32; soa += stepa; sob += stepb;
+    };
+    // FOUR tiles in flight, one per register set (prefetch distance two measured latency-bound: 1.2 - 1.5 kcyc waiting in front of
+    // every store phase).  Each quarter of the loop body consumes its set (vmcnt(24): the other three stay in flight) and refills
+    // it four tiles ahead.  The loop is entered with exactly the state it is left with (sets 1, 2, 3, 0 from oldest to newest) and
+    // has no exit inside the body, which keeps the compiler's wait counts exact across the back edge; the tile count is padded to
+    // a multiple of 4 (tiles past the end read nothing and store zeros; the launcher cuts the rows in multiples of 128).
+    f32x4 ra0[RPT], rb0[RPT], ra1[RPT], rb1[RPT], ra2[RPT], rb2[RPT], ra3[RPT], rb3[RPT];
+    gload(ra0, rb0);                                       // tile 0
+    __builtin_amdgcn_sched_barrier(0);                     // (issue order = program order: the wait counts depend on it)
+    gload(ra1, rb1);                                       // tile 1
+    __builtin_amdgcn_sched_barrier(0);
+    gload(ra2, rb2);                                       // tile 2
+    __builtin_amdgcn_sched_barrier(0);
+    gload(ra3, rb3);                                       // tile 3
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(ra0, rb0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    gload(ra0, rb0);                                       // tile 4
+    stamp();
+    tn3_barrier();                                         // tile 0 visible
+    for (int s = 0; s < nsteps; s += 4) {                  // multipliers: tile s from stage 0 ...
+      refill(ra1, rb1, 1);                                 // tile s + 1 stored, tile s + 5 requested
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      tn3_barrier();
+      stamp();
+      refill(ra2, rb2, 0);                                 // ... tile s + 1 from stage 1; tile s + 2 goes to stage 0
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      tn3_barrier();
+      stamp();
+      refill(ra3, rb3, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      tn3_barrier();
+      stamp();
+      refill(ra0, rb0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      tn3_barrier();
+      stamp();
+    }
+    return;
+  }
+
+  // ================= multiplier waves =================================================================================
+  const int wk = wave & 1, wn = wave >> 1, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // reader: 16-lane group q = lane >> 4 -> columns 16 (q & 1) .. + 15 of a 32-column MFMA tile, rows 8 (q >> 1) + 4 h + jr;
+  // this lane supplies the address of row jr = (lane & 15) >> 2, columns 4 (lane & 3) .. + 3 of the group's block
+  const int q = lane >> 4, jr = (lane & 15) >> 2;
+  const int rd = (4 * (q >> 1) + jr) * 64 + 32 * (q & 1) + 8 * (lane & 3);
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { offA[i] = rd + (2 * wk + i) * TS; offB[i] = rd + (2 * wn + i) * TS; }
+  auto compute = [&](int stage) {
+    const char* base = tn3_smem + stage * 4 * PL;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      h16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = tn3_operand(base + offA[i] + st * 1024); al[i] = tn3_operand(base + PL + offA[i] + st * 1024);
+        bh[i] = tn3_operand(base + 2 * PL + offB[i] + st * 1024); bl[i] = tn3_operand(base + 3 * PL + offB[i] + st * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  tn3_barrier();                                           // tile 0 visible
+  stamp();
+  for (int s = 0; s < nsteps; s += 4) {                    // (same number of barriers as the loaders: groups of four tiles)
+    compute(0);
+    stamp();
+    tn3_barrier();
+    stamp();
+    if (s + 1 < nsteps) compute(1);
+    stamp();
+    tn3_barrier();
+    stamp();
+    if (s + 2 < nsteps) compute(0);
+    stamp();
+    tn3_barrier();
+    stamp();
+    if (s + 3 < nsteps) compute(1);
+    stamp();
+    tn3_barrier();
+    stamp();
+  }
+  float binv = 1.f;
+  {
+    const unsigned bits = b_absmax ? *b_absmax : 0u;
+    const int e = (int)(bits >> 23) & 0xff;
+    if (e > 0 && e < 255) {
+      int sft = 14 - (e - 127);
+      if (sft > 126) sft = 126; if (sft < -126) sft = -126;
+      binv = __uint_as_float((unsigned)(-sft + 127) << 23);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + (2 * wn + j) * 32 + l31;
+      if (n < N)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = k0 + (2 * wk + i) * 32 + frow_t(r, half);
+          if (k < K) {
+            if (dbg_out == 0) atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv);
+            else if (dbg_out == 1) C[(size_t)k * ldc + n] = acc[i][j][r] * binv;       // (measurement only: wrong sums)
+          }
+        }
+    }
+}
 // max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0.
 // Second generation (round 2): the first version gave a contiguous 13 MB gradient 50 workgroups of one 256 KB pseudo-row each
 // and a 256-column strided view one active wave per workgroup -- 32 us per call, 1500 calls per training step.  Now: a flat
@@ -300,6 +587,38 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   // 43.8 ms): 80 KB of LDS leave one workgroup per CU where the 64 x 64 kernel keeps three, and this kernel lives on
   // co-resident workgroups hiding each other's barrier per 32-row tile, not on operand reuse
   static const int force = getenv("VNR_GEMM_TN_TILE") ? atoi(getenv("VNR_GEMM_TN_TILE")) : 0;
+  static const bool no3 = getenv("VNR_GEMM_TN_V2") != nullptr;      // A/B switch: the second-generation kernel everywhere
+  static const int target3 = getenv("VNR_GEMM_TN3_WGS") ? atoi(getenv("VNR_GEMM_TN3_WGS")) : 192;   // measurement knob
+  if (!no3 && K >= 128 && N >= 128 && !(lda & 3) && !(ldb & 3) && !(K & 3) && !(N & 3) && !((size_t)A & 15) && !((size_t)B & 15) && M >= 256) {
+    const int tk = (K + 127) / 128, tn = (N + 127) / 128;
+    int splits = target3 / (tk * tn); if (splits < 1) splits = 1;
+    int max_splits = M / 128; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
+    int rps = ((M + splits - 1) / splits + 127) / 128 * 128;          // whole groups of four 32-row tiles
+    splits = (M + rps - 1) / rps;
+    const unsigned lds = 2 * 4 * 4 * (2048 + 64);
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+    static const int dbg_out = getenv("VNR_GEMM_TN3_OUT") ? atoi(getenv("VNR_GEMM_TN3_OUT")) : 0;   // measurement knob: 1 plain stores, 2 none
+    static const char* ts_path = getenv("VNR_GEMM_TN3_TS");        // measurement only: s_memtime stamps of every wave appended to this file
+    if (ts_path) {
+      const unsigned wgs = (unsigned)((splits + 7) / 8 * 8 * tk * tn);
+      const size_t n = (size_t)wgs * 12 * 64;
+      unsigned long long* d = nullptr;
+      if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemset(d, 0, n * 8);
+      vnr_launch(gemm_tn3_kernel, dim3(wgs), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, dbg_out, tk, tn, splits, d);
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> hbuf(n);
+      (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(d);
+      FILE* f = fopen(ts_path, "ab");
+      if (f) { int hdr[4] = {M, K, N, (int)wgs}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+      return hipGetLastError();
+    }
+    vnr_launch(gemm_tn3_kernel, dim3((unsigned)((splits + 7) / 8 * 8 * tk * tn)), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps,
+               b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr);
+    return hipGetLastError();
+  }
   const bool big = force == 2 && K >= 128 && N >= 128 && (long long)((K + 127) / 128) * ((N + 127) / 128) * ((M + 127) / 128) >= 256;
   if (big) return launch_tn_cfg<2, 2>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target / 2, s);
   return launch_tn_cfg<1, 1>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target, s);

@@ -254,7 +254,10 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams).
  * "gemm_wide_tiles" (default 0): the same trade for the tiled GEMM kernel (64x128 workgroup tiles wherever N >= 128).
  * "split_rows" (default 1): the conv stacks (encoder prenet, PostNet) hand their activations from layer to layer as pre-split
- * fp16 hi|lo rows (same bytes as fp32) so that the consumers' k-loops run without fp32 -> (hi, lo) conversions. */
+ * fp16 hi|lo rows (same bytes as fp32) so that the consumers' k-loops run without fp32 -> (hi, lo) conversions.
+ * "fuse_xattn" (default 1): a CrossAttentionBLK (attention.py:436-452) whose alignments are not requested runs its query
+ * projection, the cross-attention over the text and everything after it as ONE chain launch (the workgroup attends for its own
+ * 32 rows); 0 = three launches (chain, attention kernel, chain).  Blocks whose alignments are returned are never fused. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,

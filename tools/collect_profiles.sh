@@ -16,4 +16,6 @@ python3 tools/rocpd_summary.py $(ls $O/tr/*.db $O/tr/*/*.db 2>/dev/null | head -
 rm -rf $O/kt $O/pf $O/pw $O/tr
 for c in 8; do rm -f /tmp/a3.bin; VNR_ATTN3_TS=/tmp/a3.bin python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/attn3_timeline.py /tmp/a3.bin > $O/attn3_timeline.txt 2>&1; done
 rm -f /tmp/cts.bin; VNR_CHAIN_TS=/tmp/cts.bin VNR_CHAIN_TS_STAGE=1 python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/chain_timeline.py /tmp/cts.bin > $O/chain_rows32_timeline.txt 2>&1
+rm -f /tmp/tn3.bin; TN_SHAPES=25600x512x512,12800x256x256 VNR_GEMM_TN3_TS=/tmp/tn3.bin python3 tools/tn_bench.py 1 > /dev/null 2>&1; python3 tools/tn3_timeline.py /tmp/tn3.bin > $O/tn3_timeline.txt 2>&1
+rocprofv3 --kernel-trace -d $O/sq -o s -- python3 bench.py --steps 6 --warmup 3 --profile-steps 0 --in-flight 0 --no-cpu-baseline --no-train > $O/sq.log 2>&1; python3 tools/launch_sequence.py $(ls $O/sq/*.db $O/sq/*/*.db 2>/dev/null | head -1) > $O/launch_sequence.txt; rm -rf $O/sq
 tail -c 800 $O/bench.json; echo; head -14 $O/kernel_stats.txt | cut -c1-140; head -8 $O/hbm_traffic_pmc.txt | cut -c1-140; cat $O/hbm_traffic.json | head -12

@@ -337,3 +337,33 @@ def test_n_sample_2_matches_reference_python():
         np.testing.assert_allclose([l2m, llm], [g["l2"].mean(), g["length"].mean()], rtol=1e-3)
     finally:
         model.engine.close()
+
+
+def test_blocks_without_alignments_fused_and_unfused():
+    """attention.py:436-452 when nobody asks for the alignments (`return_alignments=False`: the decoder's blocks too): the chain
+    launch that attends for its own 32 rows (engine option fuse_xattn) against the float64 oracle, LJ-sized model, ragged text and
+    mel lengths, 75 latent rows per utterance (row panels straddle two utterances with different lengths), and the same call in
+    the three-launch form; the fused form saves two launches per block."""
+    from oracle.vaenar_numpy import Oracle
+    hps = LJHPS
+    w = init_weights(hps, seed=4321, mode="synthetic")
+    b = make_batch(3, 61, 150, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
+                   temperature=1.0, text_step=17, mel_step=31)
+    rmel, _ = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+    model = VAENAR(hps, weights=w)
+    try:
+        launches, mels = {}, {}
+        for fuse in (1, 0):
+            model.engine.set_option("fuse_xattn", fuse)
+            for rep in range(2):                      # (second call: every lazily built panel exists, the count is the steady state)
+                n0 = model.engine.launch_count()
+                mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"],
+                                           return_alignments=False)
+                mels[fuse] = mel.numpy()
+                launches[fuse] = model.engine.launch_count() - n0
+            assert not ali
+            assert np.abs(mels[fuse] - rmel).max() < 2e-4
+        assert np.abs(mels[1] - mels[0]).max() < 2e-5
+        assert launches[0] - launches[1] >= 2 * 12, launches        # 12 prior blocks + 2 decoder blocks, two launches saved each
+    finally:
+        model.engine.close()

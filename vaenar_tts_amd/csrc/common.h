@@ -314,6 +314,8 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
                                 int causal, float temperature, unsigned* amax_slot, hipStream_t s);
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, hipStream_t s);
+bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int rows, int D, float* dst, int lddst, float* dgamma,
+                       float* dbeta, hipStream_t s, hipError_t* err);
 hipError_t launch_act_bwd(float* d, const float* y, size_t n, int act, hipStream_t s);
 hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, int rows, int cols, int accumulate, hipStream_t s);
 hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream_t s);

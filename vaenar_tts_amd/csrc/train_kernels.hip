@@ -1049,7 +1049,7 @@ ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int
 // per lane per access and spent most of its 46 us per call in 30 dependent shuffles per row.
 template <int NJ>
 __global__ void __launch_bounds__(256)
-ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, float* dv, float* dgamma, float* dbeta) {
+ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, float* dv, int lddv, int accumulate, float* dgamma, float* dbeta) {
   constexpr int D = 64 * NJ;
   const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;           // 16 row groups of 16 lanes
   float4 ga[NJ], pg[NJ], pb[NJ];
@@ -1090,9 +1090,11 @@ ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, f
     s1 = red16(s1) * (1.f / (float)D); s2 = red16(s2) * (1.f / (float)D);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const float4 o = make_float4(rstd * (g[j].x - s1 - x[j].x * s2), rstd * (g[j].y - s1 - x[j].y * s2),
-                                   rstd * (g[j].z - s1 - x[j].z * s2), rstd * (g[j].w - s1 - x[j].w * s2));
-      *reinterpret_cast<float4*>(dv + (size_t)r * D + 64 * j + 4 * l16) = o;
+      float4 o = make_float4(rstd * (g[j].x - s1 - x[j].x * s2), rstd * (g[j].y - s1 - x[j].y * s2),
+                             rstd * (g[j].z - s1 - x[j].z * s2), rstd * (g[j].w - s1 - x[j].w * s2));
+      float4* dst = reinterpret_cast<float4*>(dv + (size_t)r * lddv + 64 * j + 4 * l16);
+      if (accumulate) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }      // straight into the input's gradient
+      *dst = o;
     }
   }
   // column partials: 16 row groups -> 1 through LDS (one [16][D] buffer, used for dgamma then for dbeta), then one atomic per
@@ -1112,6 +1114,19 @@ ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, f
     __syncthreads();
   }
 }
+// accumulate form: dx is ADDED to dst (rows of lddst floats) -- the input's gradient buffer -- instead of going through a temporary
+// and an axpby launch (48 of each per T1 step); false when the shape needs the first-generation kernel (the caller then does both)
+bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int rows, int D, float* dst, int lddst, float* dgamma,
+                       float* dbeta, hipStream_t s, hipError_t* err) {
+  static const bool off = getenv("VNR_LN_BWD_V1") != nullptr || getenv("VNR_LN_BWD_NOACC") != nullptr;      // A/B switches
+  const bool al = !(((size_t)v | (size_t)dy | (size_t)dst | (size_t)gamma) & 15) && !(lddst & 3);
+  if (off || !al || (D != 256 && D != 512)) return false;
+  int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
+  else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
+  *err = hipGetLastError();
+  return true;
+}
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma,
                          float* dbeta, hipStream_t s) {
   if (D > 512) return hipErrorInvalidValue;
@@ -1119,8 +1134,8 @@ hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, in
   const bool al = !(((size_t)v | (size_t)dy | (size_t)dv | (size_t)gamma) & 15);
   if (!v1 && al && (D == 256 || D == 512)) {
     int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
-    if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, dgamma, dbeta);
-    else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, dgamma, dbeta);
+    if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
+    else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
     return hipGetLastError();
   }
   int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;

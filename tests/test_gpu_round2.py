@@ -339,16 +339,19 @@ def test_n_sample_2_matches_reference_python():
         model.engine.close()
 
 
-def test_blocks_without_alignments_fused_and_unfused():
+@pytest.mark.parametrize("B,Tt,Tm,text_step", [(3, 61, 150, 17), (2, 20, 70, 9), (2, 96, 66, 30), (3, 100, 130, 3), (2, 128, 90, 64)],
+                         ids=["2-key-blocks", "1-block", "3-full-blocks", "4th-partial", "4-full-and-half"])
+def test_blocks_without_alignments_fused_and_unfused(B, Tt, Tm, text_step):
     """attention.py:436-452 when nobody asks for the alignments (`return_alignments=False`: the decoder's blocks too): the chain
     launch that attends for its own 32 rows (engine option fuse_xattn) against the float64 oracle, LJ-sized model, ragged text and
-    mel lengths, 75 latent rows per utterance (row panels straddle two utterances with different lengths), and the same call in
-    the three-launch form; the fused form saves two launches per block."""
+    mel lengths, latent rows per utterance that are not a multiple of 32 (row panels straddle two utterances with different
+    lengths), one to four key blocks with and without a partial last block, and the same call in the three-launch form; the fused
+    form saves two launches per block."""
     from oracle.vaenar_numpy import Oracle
     hps = LJHPS
     w = init_weights(hps, seed=4321, mode="synthetic")
-    b = make_batch(3, 61, 150, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
-                   temperature=1.0, text_step=17, mel_step=31)
+    b = make_batch(B, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
+                   temperature=1.0, text_step=text_step, mel_step=31, seed=Tt)
     rmel, _ = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
     model = VAENAR(hps, weights=w)
     try:

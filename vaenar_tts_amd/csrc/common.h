@@ -195,6 +195,7 @@ struct ChainStage {
   int dst;                  // destination panel or -1
   float scale;              // 2^-s of the pre-scaled weight image
   int lds_ln;               // (set by launch_panel_chain) LDS slot of gamma | beta for a LayerNorm stage, -1 otherwise
+  int sync_after;           // (set by launch_panel_chain) workgroup barrier at the end of the stage: only where a later stage needs it
 };
 struct ChainArgs {
   const float* in0; int ld0;   // panel 0 <- in0[M, D]

@@ -604,13 +604,15 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
     s->res = 0; s->gamma = k.ln2_g; s->beta = k.ln2_b; s->acc_mode = 0; s->out = nullptr; s->ldo = 0; s->dst = 0; s->scale = r_p2.scale;
     for (int ch = 0; ch < nchunks; ++ch) {                 // hidden columns [256*ch, 256*ch + w)
       const int c0 = ch * 256, w = (F - c0 < 256) ? F - c0 : 256;
-      s = &c.st[n++];                                      // h_ch = relu(o . W1[:, chunk] + b1[chunk])  -> panel 1
+      const int hp = (!h->chain_rows64 && (ch & 1)) ? 2 : 1;   // hidden chunks alternate between two panels (32-row workgroups have three):
+                                                           // chunk ch + 1 can be written while slower waves still read chunk ch
+      s = &c.st[n++];                                      // h_ch = relu(o . W1[:, chunk] + b1[chunk])  -> panel hp
       s->w = r_f1.opm + (size_t)(c0 / 32) * r_f1.kt_total * 4096; s->kt_total = r_f1.kt_total; s->kt0 = 0; s->nk = PT; s->n = w;
       s->a0 = 0; s->a1 = 0; s->asw = PT; s->bias = k.ffn1_b + c0; s->act = ACT_RELU; s->res = -1; s->gamma = nullptr; s->beta = nullptr; s->acc_mode = 0;
-      s->out = nullptr; s->ldo = 0; s->dst = 1; s->scale = r_f1.scale;
+      s->out = nullptr; s->ldo = 0; s->dst = hp; s->scale = r_f1.scale;
       s = &c.st[n++];                                      // acc += h_ch . W2[chunk, :]
       const bool last = ch == nchunks - 1;
-      s->w = r_f2.opm; s->kt_total = r_f2.kt_total; s->kt0 = c0 / 32; s->nk = w / 32; s->n = D; s->a0 = 1; s->a1 = 1; s->asw = w / 32;
+      s->w = r_f2.opm; s->kt_total = r_f2.kt_total; s->kt0 = c0 / 32; s->nk = w / 32; s->n = D; s->a0 = hp; s->a1 = hp; s->asw = w / 32;
       s->bias = last ? k.ffn2_b : nullptr; s->act = ACT_IDENTITY; s->res = last ? 0 : -1; s->gamma = last ? k.ffn_g : nullptr; s->beta = last ? k.ffn_b : nullptr;
       s->acc_mode = nchunks == 1 ? 0 : (ch == 0 ? 1 : (last ? 3 : 2));
       s->out = last ? out : nullptr; s->ldo = D; s->dst = last ? 0 : -1; s->scale = r_f2.scale;

@@ -24,13 +24,14 @@ typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 
 // LDS map of a workgroup with RT row tiles (ROWS = 32 RT activation rows):
 //   [0, 2048 RT)                LayerNorm exchange scratch [2][ROWS][8] fp32
-//   [.., + 2 x ROWS KiB)        two activation panels: ROWS rows x 8 k-tiles x 128 B
+//   [.., + 2 or 3 x ROWS KiB)   the activation panels: ROWS rows x 8 k-tiles x 128 B (three for 32-row workgroups)
 //   then                        bias of every stage [nstages][256] fp32, then (gamma | beta) [256 + 256] fp32 of every LayerNorm stage
 template <int RT> struct ChainLds {
   static constexpr int ROWS = 32 * RT;
   static constexpr int PANEL_BYTES = ROWS * 1024;
+  static constexpr int NPANELS = RT == 1 ? 3 : 2;        // (the third panel: hidden FFN chunks alternate between panels 1 and 2)
   static constexpr int P_OFF = 2048 * RT;
-  static constexpr int PRM_OFF = P_OFF + 2 * PANEL_BYTES;
+  static constexpr int PRM_OFF = P_OFF + NPANELS * PANEL_BYTES;
 };
 
 __device__ __forceinline__ float act3(float v, int act) {
@@ -390,7 +391,7 @@ panel_chain_kernel(const ChainArgs g) {
         for (int r = 0; r < 16; ++r) accF[rt][r] += acc[rt][r];
       }
     }
-    if (st.acc_mode == 1 || st.acc_mode == 2) { lds_barrier(); stamp(3 + 2 * si); continue; }   // the hidden panel may be rewritten next
+    if (st.acc_mode == 1 || st.acc_mode == 2) { if (st.sync_after) lds_barrier(); stamp(3 + 2 * si); continue; }   // (a barrier only if the hidden panel is rewritten next)
     // ---- fast path: a full-width hidden stage h = relu(x.W + b) -> other panel (FFN dense1 chunks, utils.py:49): no residual,
     //      no LayerNorm, no HBM output, no column masks -- a third of the stages of a block chain
     if (st.acc_mode == 0 && st.act == ACT_RELU && st.n == 256 && !st.pe && st.res < 0 && !st.gamma && !st.out && st.dst >= 0 &&
@@ -415,7 +416,8 @@ panel_chain_kernel(const ChainArgs g) {
         }
       }
       wstamp(si, 5);
-      lds_barrier(); stamp(3 + 2 * si); wstamp(si, 3);
+      if (st.sync_after) lds_barrier();
+      stamp(3 + 2 * si); wstamp(si, 3);
       continue;
     }
     if (vswap) {
@@ -439,7 +441,8 @@ panel_chain_kernel(const ChainArgs g) {
             *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
           }
       }
-      lds_barrier(); stamp(3 + 2 * si); wstamp(si, 3);
+      if (st.sync_after) lds_barrier();
+      stamp(3 + 2 * si); wstamp(si, 3);
       continue;
     }
     if (st.acc_mode == 3) {
@@ -617,7 +620,10 @@ panel_chain_kernel(const ChainArgs g) {
       }
     }
     wstamp(si, 5);                                                    // outputs issued
-    lds_barrier();                                                    // panels are complete / free before the next stage
+    // Stage boundaries are where this kernel loses its time: a barrier re-aligns the eight waves, and in phase they all block on the
+    // address unit together and then multiply together (tools/probes/chain_round_probe.hip: 527 clk per k-tile round free-running,
+    // 843 with a boundary every 8 rounds).  So the barrier is placed only where the launcher's hazard analysis needs one.
+    if (st.sync_after) lds_barrier();                                 // panels are complete / free before the next stage
     stamp(3 + 2 * si);
     wstamp(si, 3);
   }
@@ -668,6 +674,30 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     if (st.out_fmt != 0 && st.out_fmt != 1 && st.out_fmt != 4) return hipErrorInvalidValue;
     // LDS slot (float offset from the parameter area) of this stage's gamma | beta: behind the bias table
     st.lds_ln = (st.gamma && st.acc_mode != 1 && st.acc_mode != 2) ? g.nstages * 256 + 512 * nln++ : -1;
+  }
+  // where a stage boundary needs its workgroup barrier: (i) after a stage that wrote a panel (its columns come from all waves),
+  // (ii) in front of a stage whose epilogue overwrites a panel that an earlier stage read since the last barrier (a slower wave
+  // may still be in that stage's k-loop).  Stages that only read (FFN second layers accumulating in registers, the tails that go
+  // to HBM) need none, and with the hidden chunks alternating between panels 1 and 2 neither does the step from one chunk to the next.
+  {
+    const int npanels = g.rows64 ? 2 : 3;
+    bool rd[3] = {false, false, false};
+    for (int i = 0; i < g.nstages; ++i) {
+      ChainStage& st = g.st[i];
+      if (st.a0 < 0 || st.a0 >= npanels || st.a1 < 0 || st.a1 >= npanels || st.dst >= npanels || st.res >= npanels) return hipErrorInvalidValue;
+      if (g.att_stage > 0 && i == g.att_stage) {         // the fused attention: reads and rewrites panel 1 between its own barriers
+        if (rd[1] && i > 0) g.st[i - 1].sync_after = 1;
+        rd[0] = rd[1] = rd[2] = false;
+      }
+      if (st.dst >= 0 && rd[st.dst] && i > 0) { g.st[i - 1].sync_after = 1; rd[0] = rd[1] = rd[2] = false; }
+      rd[st.a0] = true;
+      if (st.asw < st.nk) rd[st.a1] = true;
+      if (st.res >= 0) rd[st.res] = true;
+      st.sync_after = 0;
+      if (st.dst >= 0) { st.sync_after = 1; rd[0] = rd[1] = rd[2] = false; }
+    }
+    static const bool all_sync = getenv("VNR_CHAIN_ALL_BARRIERS") != nullptr;      // A/B switch: a barrier after every stage (round 1 .. early round 2)
+    if (all_sync) for (int i = 0; i < g.nstages; ++i) g.st[i].sync_after = 1;
   }
   const int prm_bytes = (g.nstages * 256 + nln * 512) * 4;
   if (g.rows64) { if (g.att_stage > 0) return hipErrorInvalidValue; return launch_chain_rt<2>(g, ChainLds<2>::PRM_OFF + prm_bytes, s); }

@@ -123,6 +123,74 @@ __global__ void __launch_bounds__(512) kA2(const char* w, unsigned long long* ou
   if (keep == 1234.5f) sink[0] = keep;
 }
 
+// A2 with the two barriers of a stage boundary replaced by per-tile flags: wave w writes k-tile w of the next stage's input and then
+// publishes flag[w] = stage + 1; in the next stage it walks the k-tiles in the rotated order w, w + 1, ... and, before reading tile t,
+// waits until flag[t] > stage (checked one round ahead, so the flag read's latency hides under the products).  The write-after-read
+// hazard on the panel is covered by alternating between two panels (a wave can only be one stage ahead of the slowest one).
+__global__ void __launch_bounds__(512) kA3(const char* w, unsigned long long* out, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 panels][8 k-tiles][4 KiB] | flags [8]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 2 * 8 * 4096 / 4; i += 512) reinterpret_cast<float*>(smem)[i] = 0.001f * i;
+  volatile int* flags = reinterpret_cast<volatile int*>(smem + 2 * 8 * 4096);
+  if (threadIdx.x < 8) flags[threadIdx.x] = 0;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, 0x7fffffff, 0x00020000);
+  h8 wr[4][4];
+  int fk = 0;
+  auto fetch = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      wr[u][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(lane * 16), ((fk % IMG_TILES) * 8 + wave) * 4096 + i * 1024, 0));
+    ++fk;
+  };
+#pragma unroll
+  for (int u = 0; u < 4; ++u) fetch(u);
+  float keep = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int stage = 0; stage < NK / 8; ++stage) {
+    const char* pin = smem + (stage & 1) * 32768;
+    char* pout = smem + ((stage + 1) & 1) * 32768;
+    f16v acc; for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int fl = stage;                                      // own tile: already there
+#pragma unroll 1
+    for (int kb = 0; kb < 8; kb += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = (wave + kb + u) & 7, tn = (wave + kb + u + 1) & 7;
+        while (fl < stage) { __builtin_amdgcn_s_sleep(1); fl = flags[t]; }       // tile t published?  (stage 0: the initial fill)
+        const char* ap = pin + t * 4096 + lane * 16;
+        h8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const h8*>(ap + 1024 * i);
+        fl = (kb + u + 1 < 8) ? flags[tn] : stage;       // next round's flag, read one round ahead
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[u][2 * tt], a[2 * tt], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[u][2 * tt], a[2 * tt + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[u][2 * tt + 1], a[2 * tt], acc, 0, 0, 0);
+        }
+        fetch(u);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float x = fmaxf(acc[4 * q + e], 0.f); const _Float16 h = (_Float16)x; hi[e] = h; lo[e] = (_Float16)(x - (float)h); }
+      *reinterpret_cast<h4*>(pout + wave * 4096 + (q * 64 + lane) * 8 % 2048) = hi;
+      *reinterpret_cast<h4*>(pout + wave * 4096 + 2048 + (q * 64 + lane) * 8 % 2048) = lo;
+    }
+    keep += acc[0];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) flags[wave] = stage + 1;
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+  if (keep == 1234.5f) sink[0] = keep;
+}
+
 template <int DEPTH>
 __global__ void __launch_bounds__(512) kB(const char* w, unsigned long long* out, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [8 k-tiles][4 KiB] activations | ring [DEPTH][32 KiB]
@@ -208,6 +276,8 @@ int main() {
     report("A2 + s_setprio + stage descriptor from the kernarg segment", wgs);
     for (int rep = 0; rep < 3; ++rep) { kA2<4><<<wgs, 512, 8 * 4096>>>(w, out, sink, dd); hipDeviceSynchronize(); }
     report("A2 epilogues but NO barriers (hazards ignored)", wgs);
+    for (int rep = 0; rep < 3; ++rep) { kA3<<<wgs, 512, 2 * 8 * 4096 + 64>>>(w, out, sink); hipDeviceSynchronize(); }
+    report("A3 boundaries synchronised by per-tile flags, rotated k order", wgs);
     for (int rep = 0; rep < 3; ++rep) { kB<2><<<wgs, 512, 8 * 4096 + 2 * 32768>>>(w, out, sink); hipDeviceSynchronize(); }
     report("B  specialised, LDS ring depth 2 (96 KiB of LDS)", wgs);
     for (int rep = 0; rep < 3; ++rep) { kB<3><<<wgs, 512, 8 * 4096 + 3 * 32768>>>(w, out, sink); hipDeviceSynchronize(); }

@@ -135,6 +135,9 @@ def attention_ref(q, k, v, ql, kl, H, causal, tau):
     (3, 4, 400, 400, 1, 0, 1.0, True),    # S1-shaped causal self attention, multi-tile + skipping
     (3, 4, 400, 128, 0, 1, 1.0, True),    # S1-shaped decoder cross attention with alignments
     (2, 4, 130, 200, 0, 1, 1.0, True),    # Tk > 128 with alignments (two-pass path)
+    (3, 4, 400, 400, 1, 1, 1.0, True),    # the training step's causal self-attention with stored probabilities (Tk <= 512: 8-tile form)
+    (2, 2, 70, 300, 0, 1, 0.8, True),     # 5 tiles, partial last tile (Tk % 64 != 0), temperature
+    (1, 2, 40, 520, 0, 1, 1.0, True),     # Tk > 512 with alignments: the first-generation kernel
     (2, 1, 33, 129, 0, 0, 0.7, True),     # odd sizes, temperature != 1
     (1, 2, 64, 64, 1, 1, 1.0, False),     # causal with alignments requested
     (2, 4, 128, 128, 0, 0, 1.0, False),   # encoder-shaped, full lengths

@@ -60,7 +60,9 @@ __device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const 
 }
 }  // namespace
 
-template <bool ALI>
+// NT: 64-key tiles whose logits an alignment launch keeps in registers (2: Tk <= 128, the round-1 form; 4 / 8: Tk <= 256 / 512,
+// round 2 -- the stored probabilities of the training step's causal self-attention, which the first-generation kernel produced)
+template <bool ALI, int NT = 2>
 __global__ void __launch_bounds__(256, 2)
 attn2_kernel(const AttnArgs a, int nqb) {
   constexpr int KT = 64;
@@ -117,14 +119,14 @@ attn2_kernel(const AttnArgs a, int nqb) {
     k_off[x] = (unsigned)(((size_t)r * a.ldk + hd * 64 + 4 * (pc ^ (r & 15))) * 4);
     v_off[x] = (unsigned)(((size_t)r * a.ldv + hd * 64 + 4 * pc) * 4);
   }
-  auto issue_tile = [&](int kt, int slot) {
+  auto issue_tile = [&](int kt, int slot, bool do_k = true, bool do_v = true) {
     char* sb = smem + slot * SLOT;
     const unsigned ks = (unsigned)((size_t)kt * KT * a.ldk * 4), vs = (unsigned)((size_t)kt * KT * a.ldv * 4);
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const bool ok = kt * KT + t_row[x] < a.Tk;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(sb + (wave + 4 * x) * 1024), 16, ok ? k_off[x] + ks : kOob, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(sb + KT * 256 + (wave + 4 * x) * 1024), 16, ok ? v_off[x] + vs : kOob, 0, 0, 0);
+      if (do_k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr_t)(sb + (wave + 4 * x) * 1024), 16, ok ? k_off[x] + ks : kOob, 0, 0, 0);
+      if (do_v) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr_t)(sb + KT * 256 + (wave + 4 * x) * 1024), 16, ok ? v_off[x] + vs : kOob, 0, 0, 0);
     }
   };
 
@@ -277,6 +279,104 @@ attn2_kernel(const AttnArgs a, int nqb) {
       asm volatile("" ::: "memory");
       if (kt + 2 < ntiles) issue_tile(kt + 2, slot);
     }
+  } else if (NT > 2) {
+    // ---- alignments requested, Tk <= 64 NT (round 2): the logits of EVERY tile stay in registers (16 per tile and wave) -----------
+    // Phase 1 walks the K tiles through the ring (the V regions of the two slots already hold V tiles 0 and 1 from the prologue),
+    // phase 2 is the softmax over the whole row (statistics of the two key halves exchanged through LDS), phase 3 walks the V
+    // tiles, and the probabilities leave at the very end: no load is ever issued behind a store (vmcnt counts both, in order).
+    f32x16 st[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt < ntiles) {                                // (workgroup-uniform)
+        if (kt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // prologue tiles, the Q fragment
+        else if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K tile kt landed, K tile kt + 1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (wave_active) qk_block(smem + (kt & 1) * SLOT, kt, st[kt]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // everyone is done with this K slot
+        asm volatile("" ::: "memory");
+        if (kt + 2 < ntiles) issue_tile(kt + 2, kt & 1, true, false);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[t][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    float* xch = xarea;                               // [2 rounds][4 waves][32]
+    if (half == 0) xch[wave * 32 + l31] = mt;
+    __syncthreads();
+    m_run = fmaxf(fmaxf(mt, xch[(wave ^ 2) * 32 + l31]), -3.0e38f);
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float p = fast_exp(st[t][r] - m_run); st[t][r] = p; ps += p; }
+    ps += __shfl_xor(ps, 32, 64);
+    if (half == 0) xch[128 + wave * 32 + l31] = ps;
+    __syncthreads();
+    l_run = ps + xch[128 + (wave ^ 2) * 32 + l31];
+    {
+      const float linv = 1.0f / l_run;                // softmax, attention.py:242 (one true division per row, then products)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] *= linv;
+    }
+    // phase 3: O += P.V over the V tiles (tiles 0 and 1 are resident; tile kt + 2 replaces tile kt)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt < ntiles) {
+        if (kt >= 2) {
+          if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        if (wave_active) pv_block(smem + (kt & 1) * SLOT + KT * 256, st[kt]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // everyone is done with this V slot
+        asm volatile("" ::: "memory");
+        if (kt + 2 < ntiles) issue_tile(kt + 2, kt & 1, false, true);
+      }
+    }
+    // the probabilities: every 32 x 32 block through a wave-private LDS transpose (the K region of slot 0 is free now),
+    // 128-byte row pieces out; tiles this workgroup skipped carry weight exactly 0
+    if (wave_active) {
+      float* Pw = scratch + wave * 1024;              // [32 queries][32 keys], XOR-swizzled columns
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t < ntiles_all) {
+          const bool have = t < ntiles;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Pw[l31 * 32 + (frow(r, half) ^ l31)] = have ? st[t][r] : 0.f;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const int rr = 8 * x + (lane >> 3), kc = lane & 7;
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = Pw[rr * 32 + ((4 * kc + e) ^ rr)];
+            const int qrow = q0 + rr, key = t * KT + 32 * kh + 4 * kc;
+            if (qrow < a.Tq) {
+              float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
+              if (key + 3 < a.Tk && !(a.Tk & 3)) { f32x4 o4 = {v4[0], v4[1], v4[2], v4[3]}; *reinterpret_cast<f32x4*>(dst) = o4; }
+              else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (key + e < a.Tk) dst[e] = v4[e];
+            }
+          }
+        }
+      }
+    }
+    m_run = 0.f;                                       // partials already share one scale: merge = plain sum
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
   } else {
     // ---- alignments requested (Tk <= 128: at most two tiles, logits stay in registers) ------------------------------
     f32x16 st0, st1;
@@ -384,7 +484,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
 }
 
 bool attention2_supported(const AttnArgs& a) {
-  if (a.ali && a.Tk > 128) return false;
+  if (a.ali && a.Tk > 512) return false;
   const size_t lim = (size_t)1 << 31;
   if (((size_t)a.Tk * a.ldk + 256) * 4 >= lim || ((size_t)a.Tk * a.ldv + 256) * 4 >= lim) return false;
   return true;
@@ -402,7 +502,15 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
       FILE* f = fopen(p, "ab"); if (f) { int hdr[8] = {a->B, a->H, a->Tq, a->Tk, a->causal, a->ali ? 1 : 0, (int)(n / 8), nqb}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); } } } dump{ts_path, dts, nts, s, &a, nqb};
   const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
   dim3 grid(nqb * a.H * a.B);
-  if (a.ali) {
+  if (a.ali && a.Tk > 256) {
+    auto k = attn2_kernel<true, 8>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
+  } else if (a.ali && a.Tk > 128) {
+    auto k = attn2_kernel<true, 4>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
+  } else if (a.ali) {
     auto k = attn2_kernel<true>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     vnr_launch(k, grid, dim3(256), lds, s, a, nqb);

@@ -63,6 +63,26 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def start_watchdog(seconds, last_words=None, code=3):
+    """A daemon timer thread that ends THIS process with a non-zero code after `seconds` -- also while the main thread sits in a
+    ctypes call (ctypes releases the GIL; a SIGALRM handler would only run between bytecodes of the main thread).
+    `last_words()` may return one line that is written to stdout first.  Cancel with `.cancel()`."""
+    import threading
+
+    def _fire():
+        try:
+            line = last_words() if last_words else None
+            if line:
+                sys.stdout.write(line + "\n")
+                sys.stdout.flush()
+        finally:
+            os._exit(code)
+    t = threading.Timer(seconds, _fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 # ---- N-rank launcher (parent side; never loads the HIP library) ---------------------------------------------------------
 def _free_port():
     s = socket.socket()
@@ -341,21 +361,22 @@ def run_rank(args):
     if not args.no_train:
         for ln in lanes:
             ln["model"].engine.close()
+        wd = None
         if world > 1:
             # the data-parallel training block is an extra beside the headline: should its RCCL exchange ever stall on a node
-            # this session could not test on, the inference line must still come out -- a watchdog prints it and leaves
-            import signal
-
-            def _give_up(signum, frame):
+            # this session could not test on, the inference line must still come out.  A rank stalled in the exchange sits inside
+            # a ctypes call (hipStreamSynchronize) where Python runs no signal handlers, but ctypes releases the GIL: a daemon
+            # timer THREAD can still print the line and end the process -- with a non-zero code, so that the launcher reports
+            # the run as failed, and without ever replacing the process image
+            def _last_words():
                 if rank == 0:
                     out["training"] = {"error": "the multi-rank training block did not finish within %d s (watchdog)" % args.train_timeout}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-            signal.signal(signal.SIGALRM, _give_up)
-            signal.alarm(args.train_timeout)
+                    return json.dumps(out)
+                return None
+            wd = start_watchdog(args.train_timeout, _last_words)
         tr = training_block(args, hps, device, rank, world)
-        if world > 1:
-            signal.alarm(0)
+        if wd is not None:
+            wd.cancel()
         if rank == 0:
             out["training"] = tr
 

@@ -92,3 +92,21 @@ def test_launcher_propagates_a_failing_rank(tmp_path):
     t0 = __import__("time").time()
     rc, _ = bench.launch_ranks(2, [], worker=[sys.executable, str(worker)], timeout=60)
     assert rc == 7 and __import__("time").time() - t0 < 20      # the surviving rank was terminated, not waited for
+
+
+def test_watchdog_fires_while_the_main_thread_sits_in_a_ctypes_call(tmp_path):
+    """The training-block watchdog must end a rank that is blocked INSIDE a foreign call (a stalled RCCL exchange under
+    hipStreamSynchronize): a timer thread, not a Python signal handler; the headline line still comes out; exit code non-zero."""
+    worker = tmp_path / "blocked.py"
+    worker.write_text(
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "bench.start_watchdog(1.0, lambda: '{\"value\": 1, \"training\": {\"error\": \"watchdog\"}}')\n"
+        "ctypes.CDLL(None).sleep(60)\n"               # one blocking C call: no bytecode boundary for a signal handler
+        "print('not reached')\n" % ROOT)
+    t0 = __import__("time").time()
+    out = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=50)
+    assert __import__("time").time() - t0 < 30
+    assert out.returncode == 3
+    assert json.loads(out.stdout.strip().splitlines()[-1])["training"]["error"] == "watchdog" and "not reached" not in out.stdout

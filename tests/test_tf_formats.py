@@ -260,3 +260,67 @@ def test_checkpoint_manager_numeric_order_and_max_to_keep(tmp_path):
     assert os.path.basename(fresh.latest_checkpoint) == "ckpt-12" and fresh.next_counter() == 13
     assert tc.load_training_checkpoint(fresh.latest_checkpoint)["step"] == 11
     assert tc.CheckpointManager(str(tmp_path / "empty")).latest_checkpoint is None
+
+
+def test_bundle_written_atomically_and_truncated_leftovers_are_skipped(tmp_path):
+    """bundles are written under a temporary prefix and renamed into place (index last), and a restart that finds
+    no state file skips any `ckpt-N` whose table or data shard is not whole instead of dying in restore."""
+    from vaenar_tts_amd import tf_checkpoint as tc
+    hps, w, m, v = _tiny_state()
+    small = {k: w[k] for k in list(w)[:3]}
+    mgr = tc.CheckpointManager(str(tmp_path), max_to_keep=4)
+    for i in (1, 2):
+        mgr.save(lambda prefix, n: tc.save_training_checkpoint(prefix, small, {}, {}, iterations=i, step=i - 1, save_counter=n))
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]                  # nothing temporary is left behind
+    assert tc.bundle_is_complete(str(tmp_path / "ckpt-2"))
+    # a crash during the FIRST save of a run used to leave a truncated ckpt-3.index and no state file
+    idx = open(tmp_path / "ckpt-2.index", "rb").read()
+    open(tmp_path / "ckpt-3.index", "wb").write(idx[:len(idx) // 2])
+    open(tmp_path / "ckpt-3.data-00000-of-00001", "wb").write(b"\0" * 10)
+    # ... and a whole index whose data shard is short
+    open(tmp_path / "ckpt-4.index", "wb").write(idx)
+    open(tmp_path / "ckpt-4.data-00000-of-00001", "wb").write(b"\0" * 10)
+    os.remove(tmp_path / "checkpoint")
+    assert not tc.bundle_is_complete(str(tmp_path / "ckpt-3")) and not tc.bundle_is_complete(str(tmp_path / "ckpt-4"))
+    fresh = tc.CheckpointManager(str(tmp_path))
+    assert os.path.basename(fresh.latest_checkpoint) == "ckpt-2"
+    assert tc.load_training_checkpoint(fresh.latest_checkpoint)["step"] == 1
+
+
+def test_restore_refuses_a_bundle_that_does_not_match(tmp_path):
+    """restore_checkpoint used strict=False and dropped the missing / mis-shaped lists."""
+    import pytest
+    import warnings
+    from vaenar_tts_amd import tf_checkpoint as tc
+    hps, w, m, v = _tiny_state()
+    good = str(tmp_path / "ckpt-1")
+    tc.save_training_checkpoint(good, w, m, v, iterations=5, step=2, save_counter=1)
+    weights, opt = tc.check_training_checkpoint(tc.load_training_checkpoint(good), hps, good)
+    assert set(weights) == set(w) and opt is not None and opt[2] == 5 and set(opt[0]) == set(m)
+    k0 = "decoder/pre_projection/kernel"
+    # (i) a variable missing, (ii) a variable of another shape
+    part = str(tmp_path / "ckpt-2")
+    tc.save_training_checkpoint(part, {k: a for k, a in w.items() if k != k0}, {}, {}, iterations=5, step=2, save_counter=2)
+    with pytest.raises(KeyError, match="missing"):
+        tc.check_training_checkpoint(tc.load_training_checkpoint(part), hps, part)
+    w2 = dict(w); w2[k0] = np.zeros((3, 5), np.float32)
+    other = str(tmp_path / "ckpt-3")
+    tc.save_training_checkpoint(other, w2, {}, {}, iterations=5, step=2, save_counter=3)
+    with pytest.raises(KeyError, match="mis-shaped"):
+        tc.check_training_checkpoint(tc.load_training_checkpoint(other), hps, other)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        weights, opt = tc.check_training_checkpoint(tc.load_training_checkpoint(other), hps, other, strict=False)
+    assert k0 not in weights and opt is None and any("mis-shaped" in str(r.message) for r in rec)
+    # (iii) only the `m` slots: never half an optimizer
+    half = str(tmp_path / "ckpt-4")
+    tc.save_training_checkpoint(half, w, m, {}, iterations=5, step=2, save_counter=4)
+    with pytest.raises(KeyError, match="incomplete optimizer state"):
+        tc.check_training_checkpoint(tc.load_training_checkpoint(half), hps, half)
+    # (iv) a model-only bundle restores, and says that Adam restarts
+    mo = str(tmp_path / "ckpt-5")
+    tc.save_model_weights(mo, w)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        weights, opt = tc.check_training_checkpoint(tc.load_training_checkpoint(mo), hps, mo)
+    assert opt is None and set(weights) == set(w) and any("no optimizer slots" in str(r.message) for r in rec)

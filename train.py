@@ -40,6 +40,9 @@ def synthetic_batches(hps, n_batches, batch_size, t_text, t_mel, seed):
     return out
 
 
+NOISE_STRIDE = 1 << 26          # Philox counter blocks (4 normals each) reserved per training iteration: 2.7e8 draws
+
+
 def get_reduction_factor(hps, ep):                          # train.py:236-243
     intervals, rfs = hps.Train.reduce_interval, hps.Train.reduction_factors
     i = 0
@@ -114,6 +117,7 @@ def main():
 
     if not latest:                                            # train.py:256-267
         b = train[0]
+        model.prior.seed(seed * world + rank)                 # (the initial step draws from counter range 0)
         model.init(text_inputs=b["ids"], mel_lengths=b["mel_lengths"], text_lengths=b["text_lengths"], dropout_seed=seed)
         if world > 1:
             model.engine.comm_broadcast_weights()             # ActNorm init and BN statistics of rank 0 everywhere
@@ -126,6 +130,10 @@ def main():
             print('Initial step: total {:.6f}, mel-l2 {:.6f}, kl {:.3f}, len-l2 {:.3f}'.format(*out))
 
     it = model.engine.get_optimizer_step()                    # Adam iterations so far: dropout seeds continue after a restart
+    # reparameterisation noise (posterior.py:35, tf.random.normal): one device stream per rank, keyed by (seed, rank); iteration
+    # `it` owns the counter range [it * NOISE_STRIDE, (it + 1) * NOISE_STRIDE), so the shards of a data-parallel step see
+    # independent noise and a restarted run continues the stream instead of replaying it from offset 0
+    model.prior.seed(seed * world + rank)
     for epoch in range(step + 1, args.epochs + 1):            # train.py:269-306
         kw = kw_init + kw_step * epoch if epoch <= kw_epochs else kw_end
         rf = get_reduction_factor(hps, epoch)
@@ -136,6 +144,7 @@ def main():
         for s, b in enumerate(train):                         # train_one_epoch, train.py:181-204
             ts = time.time()
             it += 1
+            model.prior.noise_offset = it * NOISE_STRIDE
             out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw, rf,
                                    dropout_seed=(seed + 7919 * it) * world + rank)
             out = [vdist.mean_over_ranks(x) for x in out]

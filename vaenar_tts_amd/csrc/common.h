@@ -19,6 +19,16 @@ namespace vnr {
 struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; bool armed = false, used = false; };
 inline thread_local ProfSlot g_prof_slot;
 #if defined(__HIPCC__)
+// Opt-in to more than 48 KiB of dynamic LDS.  The attribute belongs to the CURRENT DEVICE's copy of the function, so the
+// "already done" record is kept per device (a second engine handle on another device of the same process must opt in too).
+// `done` is the call site's own `static int done[kMaxDevices]` (largest size granted so far per device).
+constexpr int kMaxDevices = 32;
+inline void opt_in_dynamic_lds(const void* fn, int lds, int (&done)[kMaxDevices]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); return; }
+  if (done[dev] < lds) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); done[dev] = lds; }
+}
+
 template <typename... KArgs, typename Tuple, size_t... I>
 inline void vnr_launch_ext(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, Tuple& t, std::index_sequence<I...>) {
   void* ptrs[] = {static_cast<void*>(&std::get<I>(t))..., nullptr};

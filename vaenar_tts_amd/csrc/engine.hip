@@ -1870,12 +1870,13 @@ int vnr_op_kernel_grad(vnr_handle h, const float* d_x, int ldx, const float* d_d
   HIP_TRY(h, hipSetDevice(h->device));
   unsigned* amax = nullptr;
   HIP_TRY(h, hipMalloc(&amax, sizeof(unsigned)));
-  HIP_TRY(h, hipMemsetAsync(amax, 0, sizeof(unsigned), h->stream));
-  HIP_TRY(h, hipMemsetAsync(d_dw, 0, (size_t)K * N * sizeof(float), h->stream));
-  HIP_TRY(h, launch_absmax2d(d_dy, lddy, M, N, amax, h->stream));
-  HIP_TRY(h, launch_gemm_tn_scaled(d_x, ldx, d_dy, lddy, d_dw, N, M, K, N, T > 0 ? T : M, shift, amax, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipFree(amax));
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned), h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_dw, 0, (size_t)K * N * sizeof(float), h->stream);
+  if (e == hipSuccess) e = launch_absmax2d(d_dy, lddy, M, N, amax, h->stream);
+  if (e == hipSuccess) e = launch_gemm_tn_scaled(d_x, ldx, d_dy, lddy, d_dw, N, M, K, N, T > 0 ? T : M, shift, amax, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(amax);                                    // on every path: the scratch word must not leak when a launch fails
+  HIP_TRY(h, e);
   return VNR_OK;
 }
 

@@ -631,11 +631,8 @@ panel_chain_kernel(const ChainArgs g) {
 
 template <int RT>
 static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
-  static int attr_set = 0;
-  if (attr_set < lds) {
-    (void)hipFuncSetAttribute((const void*)panel_chain_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = lds;
-  }
+  static int attr_set[kMaxDevices] = {0};
+  opt_in_dynamic_lds((const void*)panel_chain_kernel<RT>, lds, attr_set);
   constexpr int ROWS = 32 * RT;
   const int wgs = (g.M + ROWS - 1) / ROWS;
   static const char* ts_path = getenv("VNR_CHAIN_TS");

@@ -565,8 +565,8 @@ static hipError_t launch_tn_cfg(const float* A, int lda, const float* B, int ldb
   int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
   splits = (M + rps - 1) / rps;
   const size_t lds = (size_t)2 * 2 * (KW + NW) * 40 * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) { (void)hipFuncSetAttribute((const void*)gemm_tn_split_kernel<TK, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  static int attr_done[kMaxDevices] = {0};
+  if (lds > 48 * 1024) opt_in_dynamic_lds((const void*)gemm_tn_split_kernel<TK, TN>, (int)lds, attr_done);
   vnr_launch(gemm_tn_split_kernel<TK, TN>, dim3(tk, tn, splits), dim3(256), (unsigned)lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
   return hipGetLastError();
 }
@@ -596,8 +596,8 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
     int rps = ((M + splits - 1) / splits + 127) / 128 * 128;          // whole groups of four 32-row tiles
     splits = (M + rps - 1) / rps;
     const unsigned lds = 2 * 4 * 4 * (2048 + 64);
-    static bool attr3 = false;
-    if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_tn3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+    static int attr3[kMaxDevices] = {0};
+    opt_in_dynamic_lds((const void*)gemm_tn3_kernel, (int)lds, attr3);
     static const int dbg_out = getenv("VNR_GEMM_TN3_OUT") ? atoi(getenv("VNR_GEMM_TN3_OUT")) : 0;   // measurement knob: 1 plain stores, 2 none
     static const char* ts_path = getenv("VNR_GEMM_TN3_TS");        // measurement only: s_memtime stamps of every wave appended to this file
     if (ts_path) {
@@ -1571,8 +1571,8 @@ hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float*
   for (int i = 0; i < n; ++i) { b.W[i] = W[i]; b.Winv[i] = Winv[i]; b.WinvT[i] = WinvT[i]; b.lad[i] = lad[i]; }
   b.n = n;
   const size_t lds = (size_t)C * C * sizeof(double);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8); attr = true; }
+  static int attr[kMaxDevices] = {0};
+  opt_in_dynamic_lds((const void*)invert_kernel, 128 * 128 * 8, attr);
   vnr_launch(invert_kernel, dim3(n), dim3(256), lds, s, b, C);
   return hipGetLastError();
 }

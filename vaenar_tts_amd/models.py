@@ -294,14 +294,18 @@ class VAENAR:
                                  learning_rate=self.hps.Train.learning_rate)
         return prefix
 
-    def restore_checkpoint(self, prefix):
+    def restore_checkpoint(self, prefix, strict=True):
         """``checkpoint.restore(manager.latest_checkpoint)`` of train.py:249: variables, optimizer slots and counters.
-        Returns the stored epoch counter ``step`` (train.py:252); bundles without optimizer entries restore the model only."""
-        from .tf_checkpoint import load_training_checkpoint
+        Returns the stored epoch counter ``step`` (train.py:252).  The MODEL variables must all be there with the shapes of
+        this configuration (a bundle of another config / dataset, or a truncated one, raises instead of leaving variables at
+        their random initial values; ``strict=False`` downgrades that to a warning).  Bundles without optimizer entries restore
+        the model only -- and say so, because Adam then restarts its moments and bias correction."""
+        from .tf_checkpoint import load_training_checkpoint, check_training_checkpoint
         ck = load_training_checkpoint(prefix, self.hps, strict=False)
-        self.engine.load_weights(ck["weights"])
-        if ck["m"] and ck["v"]:
-            self.set_optimizer_state(ck["m"], ck["v"], ck["iterations"] or 0)
+        weights, opt = check_training_checkpoint(ck, self.hps, prefix, strict)
+        self.engine.load_weights(weights)
+        if opt is not None:
+            self.set_optimizer_state(*opt)
         self._len_cache = {}
         return ck["step"] or 0
 

@@ -249,9 +249,13 @@ def _write_table(path, items, block_size=4096):
 
 def write_checkpoint(prefix, tensors):
     """Write ``{key: ndarray}`` as a one-shard tensor bundle (see the module docstring for what it is good for)."""
+    import os
     items = [(b"", _field(1, 0, _varint(1)) + _ld(3, _field(1, 0, _varint(1))))]      # num_shards = 1, version.producer = 1
     off = 0
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
+    # both files are written under a temporary prefix and renamed into place, the index LAST (TensorFlow's BundleWriter does the
+    # same): a process that dies mid-save leaves no `<prefix>.index`, so nothing ever points a restart at a truncated bundle
+    tmp = "%s.tmp%d" % (prefix, os.getpid())
+    with open(tmp + ".data-00000-of-00001", "wb") as f:
         for key in sorted(tensors, key=lambda s: s.encode()):
             if isinstance(tensors[key], (bytes, bytearray)):       # DT_STRING scalar: [varint64 length][masked crc of the length][bytes]
                 val = bytes(tensors[key])
@@ -277,7 +281,28 @@ def write_checkpoint(prefix, tensors):
             entry += _field(5, 0, _varint(len(raw))) + _field(6, 5, struct.pack("<I", _mask(crc32c(raw))))
             items.append((key.encode(), entry))
             off += len(raw)
-    _write_table(prefix + ".index", items)
+        f.flush()
+        os.fsync(f.fileno())
+    _write_table(tmp + ".index", items)
+    os.replace(tmp + ".data-00000-of-00001", prefix + ".data-00000-of-00001")
+    os.replace(tmp + ".index", prefix + ".index")
+
+
+def bundle_is_complete(prefix):
+    """True when ``<prefix>.index`` is a whole table (footer magic, every block checksum) and every data shard it names is
+    there with at least the bytes the entries address -- what a restart checks before it trusts a file it merely found."""
+    import os
+    try:
+        entries = read_index(prefix + ".index", verify=True)
+        need = 0
+        for k, v in entries.items():
+            if k == b"":
+                continue
+            e = _parse_entry(v)
+            need = max(need, e["offset"] + e["size"])
+        return os.path.getsize(prefix + ".data-00000-of-00001") >= need
+    except Exception:
+        return False
 
 
 OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
@@ -403,6 +428,41 @@ def load_training_checkpoint(prefix, hps=None, root="model", strict=True):
     return out
 
 
+def check_training_checkpoint(ck, hps, prefix="", strict=True):
+    """What ``VAENAR.restore_checkpoint`` may load from ``ck`` (a ``load_training_checkpoint`` result): (weights, (m, v,
+    iterations) or None).  Every MODEL variable of the configuration must be there with its shape -- a bundle of another config /
+    dataset or a partially written one raises (``strict=False``: warns and drops the mis-shaped ones) instead of silently leaving
+    variables at their random initial values.  The optimizer state is all or nothing: a bundle without any slot restores the
+    model only (with a warning: Adam restarts its moments and bias correction); one with only part of it raises / warns."""
+    import warnings
+    from .weights import weight_spec, is_trainable
+    spec = weight_spec(hps)
+    weights = dict(ck["weights"])
+    missing = [p for p in spec if p not in weights]
+    bad = [p for p in spec if p in weights and tuple(weights[p].shape) != tuple(spec[p])]
+    if missing or bad:
+        msg = "checkpoint %s does not match this configuration: %d variables missing %s, %d mis-shaped %s" % (
+            prefix, len(missing), missing[:8], len(bad), bad[:8])
+        if strict:
+            raise KeyError(msg)
+        warnings.warn(msg)
+        for p in bad:
+            del weights[p]
+    trainable = [p for p in spec if is_trainable(p)]
+    ok = {slot: [p for p in trainable if p in ck[slot] and tuple(ck[slot][p].shape) == tuple(spec[p])] for slot in ("m", "v")}
+    if len(ok["m"]) == len(trainable) and len(ok["v"]) == len(trainable) and ck["iterations"] is not None:
+        return weights, ({p: ck["m"][p] for p in trainable}, {p: ck["v"][p] for p in trainable}, int(ck["iterations"]))
+    if not ck["m"] and not ck["v"]:
+        warnings.warn("checkpoint %s holds no optimizer slots: model variables restored, Adam restarts from zero moments" % prefix)
+        return weights, None
+    msg = "checkpoint %s: incomplete optimizer state (m: %d, v: %d of %d slots, optimizer/iter %s)" % (
+        prefix, len(ok["m"]), len(ok["v"]), len(trainable), "present" if ck["iterations"] is not None else "absent")
+    if strict:
+        raise KeyError(msg)
+    warnings.warn(msg + " -- optimizer state NOT restored, Adam restarts from zero moments")
+    return weights, None
+
+
 class CheckpointManager:
     """tf.train.CheckpointManager(checkpoint, directory, max_to_keep=20) as train.py:248 uses it: files ``ckpt-<save_counter>``,
     a ``checkpoint`` state file (text-format CheckpointState: ``model_checkpoint_path`` + ``all_model_checkpoint_paths``) that
@@ -432,6 +492,7 @@ class CheckpointManager:
             pat = re.compile(r"^%s-(\d+)\.index$" % re.escape(self.name))
             nums = sorted(int(m.group(1)) for m in (pat.match(f) for f in os.listdir(self.directory)) if m)
             found = ["%s-%d" % (self.name, n) for n in nums]
+            found = [n for n in found if bundle_is_complete(os.path.join(self.directory, n))]      # (skip truncated leftovers)
         return [os.path.basename(n) for n in found]
 
     @property

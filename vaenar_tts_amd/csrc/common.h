@@ -19,6 +19,21 @@ namespace vnr {
 struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; bool armed = false, used = false; };
 inline thread_local ProfSlot g_prof_slot;
 #if defined(__HIPCC__)
+#ifdef __HIPCC__
+// tanh for the epilogues (PostNet: tf.nn.tanh, modules/utils.py:104): (e - 1) / (e + 1) with e = 2^(2 log2(e) |x|) on the
+// transcendental unit (v_exp_f32, v_rcp_f32: 1 ulp each) and the odd Taylor polynomial below |x| = 1/8, where the quotient would
+// cancel.  Absolute error <= 1.2e-7 everywhere (libm's tanhf: 6e-8) -- the 64x128 PostNet tiles spent as long in ocml's tanhf
+// (~40 instructions per value, 32 values per lane) as in half their k-loop.
+__device__ __forceinline__ float fast_tanhf(float x) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(fminf(ax, 20.f) * 2.88539008177792681472f);
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = ax * ax;
+  const float small = ax * (1.f + x2 * (-0.333333333333f + x2 * (0.133333333333f + x2 * -0.0539682539683f)));
+  return copysignf(ax < 0.125f ? small : big, x);
+}
+#endif
+
 // Opt-in to more than 48 KiB of dynamic LDS.  The attribute belongs to the CURRENT DEVICE's copy of the function, so the
 // "already done" record is kept per device (a second engine handle on another device of the same process must opt in too).
 // `done` is the call site's own `static int done[kMaxDevices]` (largest size granted so far per device).

@@ -26,7 +26,7 @@ constexpr unsigned kOobOffset = 0x80000000u;   // beyond any descriptor we build
 
 __device__ __forceinline__ float act2(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
-  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_TANH) return fast_tanhf(v);
   return v;
 }
 
@@ -48,13 +48,20 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 
 // SPLIT: 0 = fp32 MFMA; 1 = split-fp16 weights, fp32 activations split in registers; 2 = split-fp16 weights AND activations
 // already stored as split rows (GemmArgs::a_split): the k-loop is ds_read + MFMA only
-template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, int SPLIT>
-__global__ void __launch_bounds__(WM* WN * 64)
+// LW > 0 (round 3): LW extra LOADER waves issue every LDS-DMA piece of the ring; the WM x WN multiplier waves only read fragments
+// and multiply.  One 1-KiB DMA piece costs the issuing wave 60..185 cycles (MI355X_MICROARCH.md, per-instruction constants) -- with
+// 64x64 tiles every multiplier wave paid four of them per k-tile beside 192 cycles of MFMA, and with one wave per SIMD nothing ran
+// meanwhile.  A loader wave shares its SIMD with one multiplier wave and takes those stalls (and the conv tap walker's address
+// arithmetic) off the matrix pipe's critical path.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, int SPLIT, int LW = 0>
+__global__ void __launch_bounds__((WM * WN + LW) * 64)
 gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;
+  constexpr int DW = LW ? LW : NW;                                   // waves that issue the DMA
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int AQ = BM / 8 / NW, BQ = BN / 8 / NW, LPW = AQ + BQ;   // DMA instructions per wave per stage
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "stage rows must split evenly over the waves");
+  constexpr int AQ = BM / 8 / DW, BQ = BN / 8 / DW, LPW = AQ + BQ;   // DMA instructions per issuing wave per stage
+  static_assert(BM % (8 * DW) == 0 && BN % (8 * DW) == 0, "stage rows must split evenly over the issuing waves");
+  static_assert(!LW || (SPLIT && !LN), "loader waves: split-fp16 path without the LayerNorm epilogue (it synchronises the whole workgroup)");
   static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -73,7 +80,9 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   if (ts && tid == 0) { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ts[6] = hwid; ts[7] = xcc; }
-  const int wm = wave / WN, wn = wave - wm * WN;
+  const bool is_loader = LW && wave >= NW;
+  const int dwave = LW ? (is_loader ? wave - NW : 0) : wave;       // index among the issuing waves
+  const int wm = is_loader ? 0 : wave / WN, wn = is_loader ? 0 : wave - wm * WN;
   const int half = lane >> 5, l31 = lane & 31;
 
   // ---- buffer descriptors (wave-uniform: built from kernel arguments only) ---------------------------
@@ -102,7 +111,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   bool a_ok[AQ];
 #pragma unroll
   for (int x = 0; x < AQ; ++x) {
-    const int r = 8 * (wave + NW * x) + (lane >> 3);
+    const int r = 8 * (dwave + DW * x) + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int m = m0 + r;
     a_ok[x] = m < g.M;
@@ -125,7 +134,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   int b_c4[BQ];
 #pragma unroll
   for (int x = 0; x < BQ; ++x) {
-    const int r = 8 * (wave + NW * x) + (lane >> 3);     // row inside the B tile
+    const int r = 8 * (dwave + DW * x) + (lane >> 3);     // row inside the B tile
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int n = n0 + r;
     b_c4[x] = 4 * c;
@@ -140,7 +149,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     char* sbase = smem + slot * STAGE_BYTES;
     if (d < AQ) {
       const int x = d;
-      lds_ptr_t dst = (lds_ptr_t)(sbase + (wave + NW * x) * 1024);
+      lds_ptr_t dst = (lds_ptr_t)(sbase + (dwave + DW * x) * 1024);
       if (MODE == 0) {
         const bool second = k0 >= g.K1;                  // tile-uniform: K1 % 32 == 0 (checked by the launcher)
         const int lim = second ? g.K : g.K1;
@@ -161,7 +170,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
       unsigned off = b_off[x];
       if (!SPLIT && k0 + b_c4[x] >= g.K) off = kOobOffset;   // (the split image is zero padded to whole k-tiles)
       if (SPLIT && k0 >= g.K) off = kOobOffset;
-      lds_ptr_t dst = (lds_ptr_t)(sbase + BM * 128 + (wave + NW * x) * 1024);
+      lds_ptr_t dst = (lds_ptr_t)(sbase + BM * 128 + (dwave + DW * x) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, off, k0 * 4, 0, 0);
     }
   };
@@ -186,26 +195,32 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 
   // ---- epilogue parameters are fetched NOW so that their latency hides under the main loop ------------------
   const bool vec_ok = !(g.N & 3) && !(g.ldc & 3) && (!g.residual || !(g.ldr & 3));
+  // (big tiles -- four accumulator blocks per wave -- fetch them AFTER the loop instead: 96 more live registers through the loop
+  // spilled, and their one exposed latency is small beside 40 k-tiles)
+  constexpr bool PRM_LATE = MI * NI >= 4;
   float4 p_bias[NI][4], p_sc[NI][4], p_sh[NI][4];     // per-lane column groups: col = .. + j*32 + 8q + 4*half
+  auto load_params = [&]() {
 #pragma unroll
-  for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = (LN ? 0 : n0) + wn * TN + j * 32 + 8 * q + 4 * half;
-      p_bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      p_sc[j][q] = make_float4(1.f, 1.f, 1.f, 1.f);
-      p_sh[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vec_ok && col < g.N) {
-        if (g.bias) p_bias[j][q] = *reinterpret_cast<const float4*>(g.bias + col);
-        if (LN) {
-          p_sc[j][q] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
-          p_sh[j][q] = *reinterpret_cast<const float4*>(g.ln_beta + col);
-        } else if (g.bn_scale) {
-          p_sc[j][q] = *reinterpret_cast<const float4*>(g.bn_scale + col);
-          p_sh[j][q] = *reinterpret_cast<const float4*>(g.bn_shift + col);
+      for (int q = 0; q < 4; ++q) {
+        const int col = (LN ? 0 : n0) + wn * TN + j * 32 + 8 * q + 4 * half;
+        p_bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        p_sc[j][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        p_sh[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec_ok && col < g.N && !is_loader) {
+          if (g.bias) p_bias[j][q] = *reinterpret_cast<const float4*>(g.bias + col);
+          if (LN) {
+            p_sc[j][q] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
+            p_sh[j][q] = *reinterpret_cast<const float4*>(g.ln_beta + col);
+          } else if (g.bn_scale) {
+            p_sc[j][q] = *reinterpret_cast<const float4*>(g.bn_scale + col);
+            p_sh[j][q] = *reinterpret_cast<const float4*>(g.bn_shift + col);
+          }
         }
       }
-    }
+  };
+  if (!PRM_LATE) load_params();
 
   // Software pipeline over k-tiles (32 k each = four 8-k groups G0..G3):
   //   * the DMA of tile kt+NSTAGE-1 is issued in EVERY iteration, one instruction per MFMA issue gap of G0
@@ -227,8 +242,10 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     else if (g.aoi.mode == 4) vtile = n0 >= 2 * g.aoi.D;
     if (n0 + BN > g.N) vtile = false;                 // (ragged last tile: generic path)
   }
+  if (!LW || is_loader) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+    for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  }
   // LayerNorm row panels: the residual tile [32][N] is fetched NOW by LDS-DMA into a staging region behind the
   // ring (16-byte chunks XOR-swizzled by row so the row-per-lane ds_read_b128 of the epilogue is conflict-free);
   // it lands under the main loop.  The same region later holds the normalised rows, which leave as whole
@@ -338,6 +355,26 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         for (; d < LPW; ++d) issue_one(kt_dma, ns, d);
     };
     stamp(1);
+    if (LW && is_loader) {
+      // ---- loader wave: the whole DMA stream of this workgroup's ring.  Same barrier sequence as the multipliers (one before the
+      // loop, one per k-tile): at barrier kt the tile kt+1 has landed (counted vmcnt wait) and every multiplier has finished its
+      // reads of tile kt-1 (lgkmcnt(0) on their side), whose slot the next iteration refills.
+      wait_vmcnt<(NSTAGE - 2) * LPW>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int slot = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        int ns = slot + NSTAGE - 1; if (ns >= NSTAGE) ns -= NSTAGE;
+        int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;
+        issue(kt + NSTAGE - 1, ns);
+        wait_vmcnt<(NSTAGE - 2) * LPW>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = nx;
+      }
+      wait_vmcnt<0>();                                  // the dummy tail tiles must not land in LDS after the workgroup is gone
+      return;                                           // (the epilogue of a non-LayerNorm tile has no workgroup barrier)
+    }
     wait_vmcnt<(NSTAGE - 2) * LPW>();                  // (with a staged residual in flight this also drains tile 1: conservative)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -351,9 +388,10 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         int nx = slot + 1; if (nx >= NSTAGE) nx -= NSTAGE;
         __builtin_amdgcn_sched_barrier(0);
         fragS(As, Bs, 1, 1);                               // second k16 step of this tile
-        mfmaS(vt_tag, 0, kt + NSTAGE - 1, ns, true);       // first step + DMA of tile kt+NSTAGE-1
+        mfmaS(vt_tag, 0, kt + NSTAGE - 1, ns, LW == 0);    // first step + DMA of tile kt+NSTAGE-1 (the loader waves' job when LW > 0)
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");
+        if (LW) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSTAGE - 2) * LPW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         mfmaS(vt_tag, 1, 0, 0, false);
@@ -424,6 +462,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
       slot = nx;
     }
 }
+  if (PRM_LATE) load_params();
   wait_vmcnt<0>();                                    // drain the dummy tail tiles before LDS is reused / exit
 
   // Result layout (operands swapped, D^T): lane (l31, half) owns output ROW m = .. + l31 and, per 32x32 block,
@@ -660,11 +699,11 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, int SPLIT = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LN, int SPLIT = 0, int LW = 0>
 static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = LN ? 1 : (g.N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 128 + (LN ? (size_t)32 * BN * 4 : 0);
-  const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+  const dim3 grid(tiles_m * tiles_n), block((WM * WN + LW) * 64);
   static const char* ts_path = getenv("VNR_GEMM_TS");
   if (ts_path) {   // measurement only: synchronous launch + dump of the per-workgroup stamps
     GemmArgs gg = g;
@@ -674,11 +713,11 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
     const int mode = g.taps > 0 ? 1 : 0;
-    if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (mode) { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT, LW>;
+      if (lds > 48 * 1024) { static int done[kMaxDevices] = {0}; opt_in_dynamic_lds((const void*)k, (int)lds, done); }
       vnr_launch(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
-    else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
-      if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else { auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT, LW>;
+      if (lds > 48 * 1024) { static int done[kMaxDevices] = {0}; opt_in_dynamic_lds((const void*)k, (int)lds, done); }
       vnr_launch(k, grid, block, lds, s, gg, tiles_m, tiles_n); }
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> h(n);
@@ -690,12 +729,12 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   }
   if (g.taps > 0) {
     if (LN) return hipErrorInvalidValue;
-    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 1, false, SPLIT, LW>;
+    if (lds > 48 * 1024) { static int done[kMaxDevices] = {0}; opt_in_dynamic_lds((const void*)k, (int)lds, done); }
     vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   } else {
-    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto k = gemm2_kernel<BM, BN, WM, WN, NSTAGE, 0, LN, SPLIT, LW>;
+    if (lds > 48 * 1024) { static int done[kMaxDevices] = {0}; opt_in_dynamic_lds((const void*)k, (int)lds, done); }
     vnr_launch(k, grid, block, lds, s, g, tiles_m, tiles_n);
   }
   return hipGetLastError();
@@ -733,10 +772,36 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // (M = 12800, K = 5*256): there the 64x128 tile halves the activation re-reads (53 -> 40 us per layer, tools/sweep_split_tiles.sh).
     // With several batches in flight (wide_tiles) the 64x128 tile wins everywhere: +4 % aggregate throughput (tools/ab_tiles.sh)
     if (t < 0) t = ((g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128)) ? 1 : 2;
-    if (ns < 0) ns = 3;
-    if (g.a_split) {                                                       // activations arrive as split rows (64x64 / 64x128 tiles, 3 stages)
+    // Ring depth by how many workgroups share a CU.  A k-tile of a 64x64 workgroup is 16 KB and arrives ~2 kcyc after its DMA was
+    // issued: with three stages (two tiles in flight) ONE workgroup per CU streams 32 KB per latency -- a quarter of what the
+    // CU's vector-memory path delivers (64 B/clk) -- so its k-loop runs at the memory latency, not at any bandwidth.  Co-resident
+    // workgroups hide that for each other (3 x 48 KB of LDS), a launch of <= 256 workgroups has nobody to hide behind: it gets
+    // six stages (96 KB), two per CU get four (2 x 64 KB).  VNR_SPLIT_STAGES pins the depth for A/B runs.
+    static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    if (ns < 0) {
+      const int bm = t == 0 ? 128 : 64, bn = t == 2 ? 64 : 128;
+      const long wgs = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+      ns = (t == 2) ? (wgs <= ncu ? 6 : wgs <= 2 * ncu ? 4 : 3) : (t == 1 && wgs <= ncu) ? 4 : 3;
+    }
+    // Loader-wave variant (LW = 4, see the kernel) of the 64x64 tile: only for launches of at most two workgroups per CU.  Measured
+    // (profiles/r03_experiments.txt): the k-loops of the encoder's M = 2048 GEMMs run 10-25 % shorter (conv 58 -> 51 kcyc, N = 1024
+    // 17.9 -> 12.9), but with three or more co-resident 4-wave workgroups per CU -- every training GEMM, the cross K|V panel -- the
+    // neighbours already hide each other's DMA stalls and the 8-wave workgroups only lower the residency (T1 step 33.8 -> 35.6 ms);
+    // 128x128 tiles with loader waves reach 61 % MFMA issue in the loop but four accumulator blocks per wave make the epilogue
+    // (tanh + BatchNorm + split stores by 4 of 8 waves) as long as the loop saved.  VNR_GEMM_LW=0 restores the round-2 kernels.
+    static const int lw_on = getenv("VNR_GEMM_LW") ? atoi(getenv("VNR_GEMM_LW")) : 1;
+    if (lw_on && t == 2 && stile < 0 && (!g.a_split || (!(g.K & 31) && !(g.K1 & 31) && !(g.taps > 0 && (g.conv_C & 31)) && !g.a_absmax))) {
+      const long w64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+      if (w64 <= 2 * ncu) {
+        const int ns64 = sstages > 0 ? sstages : (w64 <= ncu ? 6 : 4);
+        if (g.a_split) return ns64 >= 6 ? launch2<64, 64, 2, 2, 6, false, 2, 4>(g, s) : launch2<64, 64, 2, 2, 4, false, 2, 4>(g, s);
+        return ns64 >= 6 ? launch2<64, 64, 2, 2, 6, false, 1, 4>(g, s) : launch2<64, 64, 2, 2, 4, false, 1, 4>(g, s);
+      }
+    }
+    if (g.a_split) {                                                       // activations arrive as split rows (64x64 / 64x128 tiles)
       if ((g.K & 31) || (g.K1 & 31) || (g.taps > 0 && (g.conv_C & 31)) || g.a_absmax) return hipErrorInvalidValue;
-      return t == 1 ? launch2<64, 128, 2, 2, 3, false, 2>(g, s) : launch2<64, 64, 2, 2, 3, false, 2>(g, s);
+      if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, 2>(g, s) : launch2<64, 128, 2, 2, 3, false, 2>(g, s);
+      return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, 2>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, 2>(g, s) : launch2<64, 64, 2, 2, 3, false, 2>(g, s);
     }
     if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, 1>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, 1>(g, s) : launch2<128, 128, 2, 2, 3, false, 1>(g, s);
     if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, 1>(g, s) : launch2<64, 128, 2, 2, 3, false, 1>(g, s);

@@ -36,7 +36,7 @@ template <int RT> struct ChainLds {
 
 __device__ __forceinline__ float act3(float v, int act) {
   if (act == ACT_RELU) return fmaxf(v, 0.f);
-  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_TANH) return fast_tanhf(v);
   return v;
 }
 // workgroup barrier that orders LDS traffic only: global stores stay in flight (a __syncthreads() would drain vmcnt
@@ -479,7 +479,7 @@ panel_chain_kernel(const ChainArgs g) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[rt][r] = tanhf(v[rt][r]);
+        for (int r = 0; r < 16; ++r) v[rt][r] = fast_tanhf(v[rt][r]);
     }
     wstamp(si, 4);                                       // accumulators drained, bias / activation applied
 #pragma unroll

@@ -162,6 +162,7 @@ struct GemmArgs {
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]
   AoiDesc aoi;                      // mode != 0: C is written as an attention operand image (attention3.hip) instead of fp32
   int wide_tiles = 0;               // split path: prefer 64x128 workgroup tiles (fewer, denser workgroups; engine option "gemm_wide_tiles")
+  int no_loader_waves = 0;          // the training step: its GEMMs share the GPU with the kernel-gradient stream, where 8-wave workgroups only cost residency
   // "split rows": an activation matrix [M][C] (C % 32 == 0) stored, per row and per 32-channel tile, as 32 x fp16 hi | 32 x fp16 lo
   // (x = hi + lo) -- the SAME 128 bytes per (row, tile) as fp32, so every address of the LDS-DMA (plain and conv tap walker) is
   // unchanged, but the consumer's k-loop needs no fp32 -> (hi, lo) conversion (which outweighed the MFMAs: the same element is
@@ -240,6 +241,7 @@ struct ChainArgs {
   int att_lds;                                 // (set by launch_panel_chain) byte offset of the merge scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
+  int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage
   ChainStage st[kMaxChainStages];
 };
 hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);
@@ -322,6 +324,7 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s);
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s);
 hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
+hipError_t launch_col_sum_grad_act(float* dy, const float* y, int act, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s);
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
                                   float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s);

@@ -121,6 +121,7 @@ struct vnr_context {
   bool split_enabled = true;     // engine option "split_fp16"
   bool chain_enabled = true;     // engine option "chain": fused row-panel chains (gemm3.hip)
   bool op_attn_presplit = false; // engine option "op_attn_presplit": vnr_op_attention takes the attention3 path (tests / micro-benchmarks)
+  bool in_train_step = false;    // set by vnr_train_step around its launches (GemmArgs::no_loader_waves)
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
@@ -227,6 +228,7 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
     }
   }
   g.wide_tiles = h->gemm_wide_tiles ? 1 : 0;
+  g.no_loader_waves = h->in_train_step ? 1 : 0;
   if ((g.a_split || g.c_split) && !g.Wsplit) return fail(h, VNR_ERR_STATE, "split-row activations need the split-fp16 weight image of the layer");
   ProfScope ps(h, g.Wsplit ? CLS_GEMM : CLS_GEMM_F32, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
@@ -1656,9 +1658,10 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
   const bool saved_split = h->split_scope, saved_training = h->training;
   h->split_scope = false;            // exact fp32 GEMMs throughout the training step
   h->training = true;
+  h->in_train_step = true;
   const int rc = train_step_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps,
                                  kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
-  h->split_scope = saved_split; h->training = saved_training;
+  h->split_scope = saved_split; h->training = saved_training; h->in_train_step = false;
   if (rc == VNR_OK && !h->packed_stale) TRY(refresh_bn_affine(h));      // moving statistics moved
   return rc;
 }

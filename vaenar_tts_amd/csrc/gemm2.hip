@@ -790,7 +790,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // 128x128 tiles with loader waves reach 61 % MFMA issue in the loop but four accumulator blocks per wave make the epilogue
     // (tanh + BatchNorm + split stores by 4 of 8 waves) as long as the loop saved.  VNR_GEMM_LW=0 restores the round-2 kernels.
     static const int lw_on = getenv("VNR_GEMM_LW") ? atoi(getenv("VNR_GEMM_LW")) : 1;
-    if (lw_on && t == 2 && stile < 0 && (!g.a_split || (!(g.K & 31) && !(g.K1 & 31) && !(g.taps > 0 && (g.conv_C & 31)) && !g.a_absmax))) {
+    if (lw_on && !g.no_loader_waves && t == 2 && stile < 0 && (!g.a_split || (!(g.K & 31) && !(g.K1 & 31) && !(g.taps > 0 && (g.conv_C & 31)) && !g.a_absmax))) {
       const long w64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
       if (w64 <= 2 * ncu) {
         const int ns64 = sstages > 0 ? sstages : (w64 <= ncu ? 6 : 4);

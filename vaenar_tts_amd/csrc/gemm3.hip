@@ -78,7 +78,7 @@ panel_chain_kernel(const ChainArgs g) {
   // the second-dispatched half of the workgroup (waves 4..7) loses the per-SIMD issue arbitration against its older partner
   // on every phase (it leaves each k-loop ~1 kcyc later: profiles/r02_chain_rows32_timeline.txt); one static priority bump
   // for that half evens the pair out (MI355X_MICROARCH.md, "static priority for the younger half")
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (g.prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // ---- the weight stream --------------------------------------------------------------------------------------------
   // Every stage's weights sit in an operand-major image: block (column block, k-tile) = 4 x 1 KiB pieces, piece
@@ -352,6 +352,10 @@ panel_chain_kernel(const ChainArgs g) {
       if (MODE != 2) read_a(0, 0);
 #pragma unroll 1
       for (int kb = 0; kb < npad; kb += PF) {
+        if (g.prio_mode >= 2) {            // experiment: the two waves of a SIMD take turns at the issue arbiter
+          const int turn = g.prio_mode == 2 ? (kb / PF) : si;
+          if ((turn ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
           if (MODE != 2) {
@@ -660,6 +664,8 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
 
 hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
   ChainArgs g = g_in;
+  static const int prio_mode = getenv("VNR_CHAIN_PRIO") ? atoi(getenv("VNR_CHAIN_PRIO")) : 1;
+  g.prio_mode = prio_mode;
   if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
   int nln = 0;
   for (int i = 0; i < g.nstages; ++i) {

@@ -526,7 +526,9 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
 }
 // Same sums with 16-byte loads: a lane owns 4 consecutive columns (C, ld multiples of 4, x 16-byte aligned), a wave covers 256
 // columns of a row, the block's 4 waves take rows m, m+1, m+2, m+3 of a stride-(4 gridDim.y) walk with two loads in flight.
-__global__ void col_sum4_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout) {
+// yact != null: x is a gradient dy and yact the OUTPUT of an activation (act_bwd_kernel's job folded into this pass: dy *= act'(y) is
+// written back in place before it enters the sums) -- one launch and one pass over dy less per activated Dense / Conv1D layer.
+__global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act) {
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   const int rg = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -545,12 +547,35 @@ __global__ void col_sum4_kernel(const float* x, int M, int C, int ld, const doub
         acc[e] += mean ? d * d : (double)xv[e];
       }
     };
+    auto dact = [&](float4& v, const float4& y) {
+      if (act == ACT_RELU) { v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f; }
+      else if (act == ACT_TANH) { v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y; v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w; }
+    };
+    if (yact) {                                                // (the activation output is a contiguous [M][C] block)
+      for (; m + step < M; m += 2 * step) {
+        float4* p0 = reinterpret_cast<float4*>(x + (size_t)m * ld + c);
+        float4* p1 = reinterpret_cast<float4*>(x + (size_t)(m + step) * ld + c);
+        float4 v0 = *p0, v1 = *p1;
+        const float4 y0 = *reinterpret_cast<const float4*>(yact + (size_t)m * C + c), y1 = *reinterpret_cast<const float4*>(yact + (size_t)(m + step) * C + c);
+        dact(v0, y0); dact(v1, y1);
+        *p0 = v0; *p1 = v1;
+        add(v0); add(v1);
+      }
+      for (; m < M; m += step) {
+        float4* p0 = reinterpret_cast<float4*>(x + (size_t)m * ld + c);
+        float4 v0 = *p0;
+        dact(v0, *reinterpret_cast<const float4*>(yact + (size_t)m * C + c));
+        *p0 = v0;
+        add(v0);
+      }
+    } else {
     for (; m + step < M; m += 2 * step) {
       const float4 v0 = *reinterpret_cast<const float4*>(x + (size_t)m * ld + c);
       const float4 v1 = *reinterpret_cast<const float4*>(x + (size_t)(m + step) * ld + c);
       add(v0); add(v1);
     }
     for (; m < M; m += step) add(*reinterpret_cast<const float4*>(x + (size_t)m * ld + c));
+    }
   }
   __shared__ double part[4][256];
 #pragma unroll
@@ -567,15 +592,24 @@ __global__ void col_sum4_kernel(const float* x, int M, int C, int ld, const doub
     else atomicAdd(&out[cc], t);
   }
 }
-static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, hipStream_t s) {
-  int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
+static bool col_sum4_ok(const float* x, int C, int ld) {
   static const bool v1 = getenv("VNR_COLSUM_V1") != nullptr;           // A/B switch
-  if (!v1 && !(C & 3) && !(ld & 3) && !((size_t)x & 15)) {
-    // (64 row groups at most: every workgroup ends in one atomic per column, and 256 groups contending for the same 256 words
-    //  cost more than the longer per-thread loops)
-    int rb4 = (M + 63) / 64; if (rb4 > 64) rb4 = 64; if (rb4 < 1) rb4 = 1;
-    vnr_launch(col_sum4_kernel, dim3((C + 255) / 256, rb4), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
+  return !v1 && !(C & 3) && !(ld & 3) && !((size_t)x & 15);
+}
+static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, hipStream_t s,
+                                     const float* yact = nullptr, int act = ACT_IDENTITY) {
+  int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
+  if (col_sum4_ok(x, C, ld) && (!yact || !((size_t)yact & 15))) {
+    // every workgroup ends in one atomic per column: 256 groups contending for the same 256 words cost more than the longer
+    // per-thread loops, 64 groups of a 256-column matrix leave three quarters of the CUs without work -- about 256 workgroups
+    // per launch, between 32 and 128 row groups (VNR_COLSUM_GROUPS pins the count)
+    static const int forced = getenv("VNR_COLSUM_GROUPS") ? atoi(getenv("VNR_COLSUM_GROUPS")) : 0;
+    const int cb = (C + 255) / 256;
+    int rb4 = forced > 0 ? forced : 256 / cb; if (!forced) { if (rb4 > 128) rb4 = 128; if (rb4 < 32) rb4 = 32; }
+    const int rmax = (M + 63) / 64; if (rb4 > rmax) rb4 = rmax; if (rb4 < 1) rb4 = 1;
+    vnr_launch(col_sum4_kernel, dim3(cb, rb4), dim3(256), 0, s, const_cast<float*>(x), M, C, ld, mean, out, amax, fout, yact, act);
   } else {
+    if (yact) return hipErrorInvalidValue;
     vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
   }
   return hipGetLastError();
@@ -586,6 +620,13 @@ hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const doubl
 // grad[c] += sum_m x[m][c]  (bias gradients), optional abs-max by-product
 hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s) {
   return launch_col_sum_any(x, M, C, ld, nullptr, nullptr, amax, grad, s);
+}
+// bias gradient of an ACTIVATED layer: dy *= act'(y) in place (y = the layer's output, contiguous [M][C]), then as above.
+// Returns hipErrorNotSupported when the 16-byte kernel cannot take the operands (the caller then runs the two passes).
+hipError_t launch_col_sum_grad_act(float* dy, const float* y, int act, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s) {
+  if (act == ACT_IDENTITY) return launch_col_sum_any(dy, M, C, ld, nullptr, nullptr, amax, grad, s);
+  if (!col_sum4_ok(dy, C, ld) || ((size_t)y & 15)) return hipErrorNotSupported;
+  return launch_col_sum_any(dy, M, C, ld, nullptr, nullptr, amax, grad, s, y, act);
 }
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
   return launch_col_sum_amax(x, M, C, ld, mean, out, nullptr, s);

@@ -257,7 +257,10 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * fp16 hi|lo rows (same bytes as fp32) so that the consumers' k-loops run without fp32 -> (hi, lo) conversions.
  * "fuse_xattn" (default 1): a CrossAttentionBLK (attention.py:436-452) whose alignments are not requested runs its query
  * projection, the cross-attention over the text and everything after it as ONE chain launch (the workgroup attends for its own
- * 32 rows); 0 = three launches (chain, attention kernel, chain).  Blocks whose alignments are returned are never fused. */
+ * 32 rows); 0 = three launches (chain, attention kernel, chain).  Blocks whose alignments are returned are never fused.
+ * "attn_bwd_recompute" (default 0): vnr_train_step keeps no attention probabilities -- the forward leaves the softmax row
+ * statistics and the backward kernels rebuild P from Q and K (2 x 82 MB less workspace per causal self-attention at B = 32,
+ * T = 400); measured slower than the stored form on the T1 step (35.3 vs 32.1 ms), hence off. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,

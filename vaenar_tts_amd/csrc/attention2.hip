@@ -467,6 +467,12 @@ attn2_kernel(const AttnArgs a, int nqb) {
       sa = fast_exp(m_run - m_f);                      // floor - finite -> 0 when this half saw no key
       sb = fast_exp(m_o - m_f);
       linv = 1.0f / (l_run * sa + l_o * sb);
+      // row statistics for the recomputing backward pass of the training step (one wave of the pair, one lane half)
+      if (a.row_max && kh == 0 && half == 0 && q0 + l31 < a.Tq) {
+        const size_t ri = ((size_t)b * a.H + hd) * a.Tq + q0 + l31;
+        a.row_max[ri] = m_f;
+        a.row_linv[ri] = linv;
+      }
     }
     const int nb = kh;
     float* ob = a.ctx + (size_t)b * a.o_bs + hd * 64 + nb * 32 + l31;

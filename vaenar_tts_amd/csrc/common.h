@@ -185,6 +185,10 @@ struct AttnArgs {
   // batch strides in floats (rows * ld by default); allow K/V shared panels
   long long q_bs, k_bs, v_bs, o_bs;
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [wgs][8]
+  // softmax row statistics for a recomputing backward pass (training step, calls without alignments): [B][H][Tq] each,
+  // P_ij = exp(s_ij - row_max[i]) * row_linv[i] with s the masked, scaled logit exactly as the kernel formed it; or null
+  float* row_max = nullptr;
+  float* row_linv = nullptr;
 };
 
 // ---- row-panel chain kernel (gemm3.hip) ---------------------------------------------------------------------------
@@ -338,6 +342,13 @@ hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                                  int shift, const unsigned* b_absmax, hipStream_t s);
+// recomputing ("flash-style") backward: no stored probabilities, no dS in HBM -- P is rebuilt from Q, K and the row statistics
+// the forward call left in row_max / row_linv (AttnArgs), dS lives in registers.  rowdot_ws: scratch [B][H][Tq].
+hipError_t launch_attention_bwd_recompute(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                                          const float* dO, int lddo, const float* row_max, const float* row_linv, float* rowdot_ws,
+                                          float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const int32_t* q_len,
+                                          const int32_t* k_len, int B, int H, int Tq, int Tk, int causal, float temperature,
+                                          unsigned* amax_slot, hipStream_t s);
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,

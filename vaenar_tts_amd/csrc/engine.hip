@@ -125,6 +125,7 @@ struct vnr_context {
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
+  bool attn_bwd_recompute = false;   // engine option "attn_bwd_recompute" (train.inc: attn)
   bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
   bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
@@ -1958,6 +1959,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
+  if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_encoder")) { h->split_encoder = value != 0; return VNR_OK; }

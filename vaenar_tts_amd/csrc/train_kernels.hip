@@ -994,6 +994,309 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
   return hipGetLastError();
 }
 
+// ---- attention backward, third generation (round 3): recomputing -------------------------------------------------------------
+// The second generation read the stored probabilities twice (82 MB per causal self-attention at B = 32, T = 400) and passed dS from
+// kernel A to kernel B through HBM (another 82 MB written and read): ~330 MB of traffic against ~31 GFLOP of f16 MFMA work, 150 us
+// per attention.  Here nothing of size Tq x Tk exists in memory: the forward call leaves the softmax row statistics (row maximum
+// and reciprocal row sum, AttnArgs::row_max / row_linv), both kernels rebuild P = exp(s - max) / sum from Q and K with the same
+// 3-term products and the same masking as the forward kernel (attention2.hip: logits * 0.125 (/ tau), fill value on masked
+// positions, padded query rows uniform over all Tk keys), and dS = P (dP - dO.O) stays in registers.
+//   kernel A (128-query blocks x H x B; lane <-> query): per 32-key tile  S^T = K.Q^T, dP^T = V.dO^T, dS, dQ^T += K^T.dS^T; it also
+//            leaves dO.O (scaled like dO) per query for kernel B
+//   kernel B (128-key blocks x H x B; lane <-> key): per 32-query tile  S = Q.K^T, dP = dO.V^T, P, dS, dV^T += dO^T.P, dK^T += Q^T.dS
+// Key tiles (A) / query tiles (B) whose every position is masked for valid rows are skipped when all rows concerned are valid.
+struct AttnBwd2Args {
+  const float *Q, *K, *V, *O, *dO, *rmax, *rlinv;
+  float *dQ, *dK, *dV, *rowdot;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  const int32_t *q_len, *k_len;
+  int B, H, Tq, Tk, causal;
+  float tau;
+};
+// exp(x), x <= 0: the forward kernel's function (attention2.hip: fast_exp), so that the rebuilt probabilities are its probabilities
+__device__ __forceinline__ float fast_exp_t(float x) {
+  const float L2E = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+  const float t = x * L2E;
+  float e = __builtin_fmaf(x, L2E, -t);
+  e = __builtin_fmaf(x, L2E_LO, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return (x < -87.0f) ? 0.0f : __builtin_fmaf(r, e * LN2, r);
+}
+__global__ void __launch_bounds__(256)
+attn_bwd2_dq_kernel(const AttnBwd2Args a, const unsigned* amax) {
+  constexpr int RS = 72, KS = 40;                           // LDS row strides in halfs (16-byte aligned, bank-spread)
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * RS], Vl[32 * RS], Krh[32 * RS], Krl[32 * RS];   // V, K tiles [key][d]
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[64 * KS], Kl[64 * KS];                                // K tile transposed [d][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + l31;         // this lane's query
+  const bool qin = q < a.Tq;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  h16x8_t doh[4], dol[4], qh[4], ql[4];
+  float rowdot = 0.f;
+  {
+    const size_t qr = (size_t)b * a.Tq + (qin ? q : 0);
+    const float* dp = a.dO + qr * a.lddo + hd * 64 + 8 * half;
+    const float* op = a.O + qr * a.ldo + hd * 64 + 8 * half;
+    const float* qp = a.Q + qr * a.ldq + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8], y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = qin ? dp[16 * t + e] * sc : 0.f; rowdot += qin ? x[e] * op[16 * t + e] : 0.f; y[e] = qin ? qp[16 * t + e] : 0.f; }
+      split8_t(x, doh[t], dol[t]);
+      split8_t(y, qh[t], ql[t]);
+    }
+    rowdot += __shfl_xor(rowdot, 32, 64);
+  }
+  const size_t si = ((size_t)b * a.H + hd) * a.Tq + (qin ? q : 0);
+  if (qin && half == 0) a.rowdot[si] = rowdot;
+  const float mq = qin ? a.rmax[si] : 0.f, lq = qin ? a.rlinv[si] : 0.f;
+  const bool use_tau = a.tau != 1.0f;
+  f32x16 accq[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accq[nb][r] = 0.f;
+  int jend = a.Tk;
+  {
+    int qb1 = blockIdx.x * 128 + 128; if (qb1 > a.Tq) qb1 = a.Tq;
+    if (qb1 <= qlen && klen > 0) {                          // every query of this workgroup is valid: masked keys have weight exactly 0
+      int kmax = klen;
+      if (a.causal && qb1 < kmax) kmax = qb1;
+      if (kmax < jend) jend = kmax;
+    }
+  }
+  for (int j0 = 0; j0 < jend; j0 += 32) {
+    __syncthreads();
+    {   // stage V and K [key][d] (thread: key = tid>>3, 8 d) and K^T [d][key] (thread: d = tid&63, 8 keys), split once
+      const int key = tid >> 3, d8 = (tid & 7) * 8;
+      float x[8], y[8];
+      const bool ok = j0 + key < a.Tk;
+      const float* vp = a.V + ((size_t)b * a.Tk + j0 + key) * a.ldv + hd * 64 + d8;
+      const float* kp = a.K + ((size_t)b * a.Tk + j0 + key) * a.ldk + hd * 64 + d8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = ok ? vp[e] : 0.f; y[e] = ok ? kp[e] : 0.f; }
+      h16x8_t hi, lo; split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Vh[key * RS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Vl[key * RS + d8]) = lo;
+      split8_t(y, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Krh[key * RS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Krl[key * RS + d8]) = lo;
+      const int d = tid & 63, rg = tid >> 6;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int kk = j0 + 8 * rg + e; x[e] = kk < a.Tk ? a.K[((size_t)b * a.Tk + kk) * a.ldk + hd * 64 + d] : 0.f; }
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Kh[d * KS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Kl[d * KS + 8 * rg]) = lo;
+    }
+    __syncthreads();
+    // S^T[key][q] = sum_d K[key][d] Q[q][d]  and  dP^T[key][q] = sum_d V[key][d] dO[q][d]
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = l31 * RS + 16 * t + 8 * half;
+      const h16x8_t kh = *reinterpret_cast<const h16x8_t*>(&Krh[o]), kl = *reinterpret_cast<const h16x8_t*>(&Krl[o]);
+      const h16x8_t vh = *reinterpret_cast<const h16x8_t*>(&Vh[o]), vl = *reinterpret_cast<const h16x8_t*>(&Vl[o]);
+      st = mfma3_t(kh, kl, qh[t], ql[t], st);
+      dpt = mfma3_t(vh, vl, doh[t], dol[t], dpt);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = j0 + frow_t(r, half);
+      const bool valid = qin && q < qlen && kk < klen && kk < a.Tk && (!a.causal || kk <= q);
+      float sv = st[r] * 0.125f;
+      if (use_tau) sv = sv / a.tau;
+      sv = valid ? sv : kMaskFill;                          // attention.py:240
+      const float p = (kk < a.Tk) ? fast_exp_t(sv - mq) * lq : 0.f;
+      ds[r] = valid ? p * (dpt[r] - rowdot) : 0.f;
+    }
+    // dQ^T[d][q] += sum_key K[key][d] dS[q][key]   (k-slot (t', half, e) carries key frow(8t'+e, half): dS registers as they are)
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      h16x8_t dsh, dsl;
+      split8_t(&ds[8 * tp], dsh, dsl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int row = (32 * nb + l31) * KS;
+        h16x8_t kh, kl;
+        const int c0 = 16 * tp + 4 * half, c1 = 16 * tp + 8 + 4 * half;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 a0 = *reinterpret_cast<const h4*>(&Kh[row + c0]), a1 = *reinterpret_cast<const h4*>(&Kh[row + c1]);
+        const h4 b0 = *reinterpret_cast<const h4*>(&Kl[row + c0]), b1 = *reinterpret_cast<const h4*>(&Kl[row + c1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kh[e] = a0[e]; kh[4 + e] = a1[e]; kl[e] = b0[e]; kl[4 + e] = b1[e]; }
+        accq[nb] = mfma3_t(kh, kl, dsh, dsl, accq[nb]);
+      }
+    }
+  }
+  if (qin) {
+    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
+    const float f = 0.125f / a.tau * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) =
+            make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
+  }
+}
+__global__ void __launch_bounds__(256)
+attn_bwd2_dkv_kernel(const AttnBwd2Args a, const unsigned* amax) {
+  constexpr int TS = 40, RS = 72;
+  __shared__ __attribute__((aligned(16))) _Float16 Oh[64 * TS], Ol[64 * TS], Qh[64 * TS], Ql[64 * TS];        // dO^T, Q^T [d][32 queries]
+  __shared__ __attribute__((aligned(16))) _Float16 Orh[32 * RS], Orl[32 * RS], Qrh[32 * RS], Qrl[32 * RS];    // dO, Q    [query][d]
+  __shared__ float st_m[32], st_l[32], st_d[32];                                                              // row statistics of the tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int kb0 = blockIdx.x * 128;
+  const int key = kb0 + wave * 32 + l31;                     // this lane's key
+  const bool kin = key < a.Tk;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  const bool use_tau = a.tau != 1.0f;
+  h16x8_t kh[4], kl[4], vh[4], vl[4];                        // B operands of S and dP: column = this lane's key, k = d
+  {
+    const float* kp = a.K + ((size_t)b * a.Tk + (kin ? key : 0)) * a.ldk + hd * 64 + 8 * half;
+    const float* vp = a.V + ((size_t)b * a.Tk + (kin ? key : 0)) * a.ldv + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8], y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = kin ? kp[16 * t + e] : 0.f; y[e] = kin ? vp[16 * t + e] : 0.f; }
+      split8_t(x, kh[t], kl[t]);
+      split8_t(y, vh[t], vl[t]);
+    }
+  }
+  f32x16 accv[2], acck[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accv[nb][r] = 0.f; acck[nb][r] = 0.f; }
+  const float* rmax = a.rmax + ((size_t)b * a.H + hd) * a.Tq;
+  const float* rlinv = a.rlinv + ((size_t)b * a.H + hd) * a.Tq;
+  const float* rdot = a.rowdot + ((size_t)b * a.H + hd) * a.Tq;
+  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
+    // a tile of 32 VALID queries gives no weight to this workgroup's keys when they all lie behind the causal diagonal or beyond
+    // the key length (padded query rows are uniform over every key and are never skipped)
+    if (q0 + 32 <= qlen && q0 + 32 <= a.Tq && ((a.causal && q0 + 31 < kb0) || kb0 >= klen)) continue;   // (workgroup-uniform)
+    __syncthreads();
+    {
+      const int d = tid & 63, rg = tid >> 6;                  // transposed tiles: thread d, queries 8 rg .. + 7
+      float x[8], y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qq = q0 + 8 * rg + e;
+        const bool ok = qq < a.Tq;
+        x[e] = ok ? a.dO[((size_t)b * a.Tq + qq) * a.lddo + hd * 64 + d] * sc : 0.f;
+        y[e] = ok ? a.Q[((size_t)b * a.Tq + qq) * a.ldq + hd * 64 + d] : 0.f;
+      }
+      h16x8_t hi, lo;
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Oh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ol[d * TS + 8 * rg]) = lo;
+      split8_t(y, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Qh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ql[d * TS + 8 * rg]) = lo;
+      const int qi = tid >> 3, d8 = (tid & 7) * 8;            // row-major tiles: thread query qi, 8 d
+      const int qq = q0 + qi;
+      const bool ok = qq < a.Tq;
+      const float* dp = a.dO + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.lddo + hd * 64 + d8;
+      const float* qp = a.Q + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.ldq + hd * 64 + d8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = ok ? dp[e] * sc : 0.f; y[e] = ok ? qp[e] : 0.f; }
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Orh[qi * RS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Orl[qi * RS + d8]) = lo;
+      split8_t(y, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Qrh[qi * RS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Qrl[qi * RS + d8]) = lo;
+      if (tid < 32) {
+        const int qs = q0 + tid;
+        const bool oks = qs < a.Tq;
+        st_m[tid] = oks ? rmax[qs] : 0.f; st_l[tid] = oks ? rlinv[qs] : 0.f; st_d[tid] = oks ? rdot[qs] : 0.f;
+      }
+    }
+    __syncthreads();
+    // S[q][key] = sum_d Q[q][d] K[key][d]  and  dP[q][key] = sum_d dO[q][d] V[key][d]   (lane <-> key, register r <-> query frow(r, half))
+    f32x16 sv, dpv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dpv[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int o = l31 * RS + 16 * t + 8 * half;
+      const h16x8_t qa = *reinterpret_cast<const h16x8_t*>(&Qrh[o]), qb = *reinterpret_cast<const h16x8_t*>(&Qrl[o]);
+      const h16x8_t oa = *reinterpret_cast<const h16x8_t*>(&Orh[o]), ob = *reinterpret_cast<const h16x8_t*>(&Orl[o]);
+      sv = mfma3_t(qa, qb, kh[t], kl[t], sv);
+      dpv = mfma3_t(oa, ob, vh[t], vl[t], dpv);
+    }
+    float p[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = frow_t(r, half), qq = q0 + i;
+      const bool valid = kin && qq < qlen && qq < a.Tq && key < klen && (!a.causal || key <= qq);
+      float s = sv[r] * 0.125f;
+      if (use_tau) s = s / a.tau;
+      s = valid ? s : kMaskFill;                              // attention.py:240
+      const float pr = (kin && qq < a.Tq) ? fast_exp_t(s - st_m[i]) * st_l[i] : 0.f;
+      p[r] = pr;
+      ds[r] = valid ? pr * (dpv[r] - st_d[i]) : 0.f;
+    }
+    // dV^T[d][key] += sum_q dO[q][d] P[q][key] ; dK^T[d][key] += sum_q Q[q][d] dS[q][key]: k-slot (t', half, e) <-> query frow(8t'+e, half),
+    // i.e. the registers of P / dS as they are; the A operands gather the matching two runs of 4 queries from the [d][query] tiles
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      h16x8_t ph, pl, sh, sl;
+      split8_t(&p[8 * tp], ph, pl);
+      split8_t(&ds[8 * tp], sh, sl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int row = (32 * nb + l31) * TS;
+        const int c0 = 16 * tp + 4 * half, c1 = 16 * tp + 8 + 4 * half;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 o0 = *reinterpret_cast<const h4*>(&Oh[row + c0]), o1 = *reinterpret_cast<const h4*>(&Oh[row + c1]);
+        const h4 o2 = *reinterpret_cast<const h4*>(&Ol[row + c0]), o3 = *reinterpret_cast<const h4*>(&Ol[row + c1]);
+        const h4 q0v = *reinterpret_cast<const h4*>(&Qh[row + c0]), q1v = *reinterpret_cast<const h4*>(&Qh[row + c1]);
+        const h4 q2v = *reinterpret_cast<const h4*>(&Ql[row + c0]), q3v = *reinterpret_cast<const h4*>(&Ql[row + c1]);
+        h16x8_t oh, ol, qh, ql;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { oh[e] = o0[e]; oh[4 + e] = o1[e]; ol[e] = o2[e]; ol[4 + e] = o3[e]; qh[e] = q0v[e]; qh[4 + e] = q1v[e]; ql[e] = q2v[e]; ql[4 + e] = q3v[e]; }
+        accv[nb] = mfma3_t(oh, ol, ph, pl, accv[nb]);
+        acck[nb] = mfma3_t(qh, ql, sh, sl, acck[nb]);
+      }
+    }
+  }
+  if (kin) {
+    float* pvd = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64;
+    float* pkd = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64;
+    const float fk = 0.125f / a.tau * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = 32 * nb + 8 * g4 + 4 * half;
+        *reinterpret_cast<float4*>(pvd + d) = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
+        *reinterpret_cast<float4*>(pkd + d) = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
+      }
+  }
+}
+hipError_t launch_attention_bwd_recompute(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
+                                          const float* dO, int lddo, const float* row_max, const float* row_linv, float* rowdot_ws,
+                                          float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv, const int32_t* q_len,
+                                          const int32_t* k_len, int B, int H, int Tq, int Tk, int causal, float temperature,
+                                          unsigned* amax_slot, hipStream_t s) {
+  if (!row_max || !row_linv || !rowdot_ws || !amax_slot || (lddq & 3) || (lddk & 3) || (lddv & 3)) return hipErrorInvalidValue;
+  AttnBwd2Args a;
+  a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.rmax = row_max; a.rlinv = row_linv; a.rowdot = rowdot_ws;
+  a.dQ = dQ; a.dK = dK; a.dV = dV;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.q_len = q_len; a.k_len = k_len; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.tau = temperature;
+  hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
+  if (e != hipSuccess) return e;
+  vnr_launch(attn_bwd2_dq_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  vnr_launch(attn_bwd2_dkv_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  return hipGetLastError();
+}
+
 // ---- LayerNormalization backward (eps 1e-3, population variance) ---------------------------------------------------------
 // y = (v - mu) * rstd * gamma + beta.  dv = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy.   One wave per row, D <= 512.
@@ -1121,7 +1424,10 @@ bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int 
   static const bool off = getenv("VNR_LN_BWD_V1") != nullptr || getenv("VNR_LN_BWD_NOACC") != nullptr;      // A/B switches
   const bool al = !(((size_t)v | (size_t)dy | (size_t)dst | (size_t)gamma) & 15) && !(lddst & 3);
   if (off || !al || (D != 256 && D != 512)) return false;
-  int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  // (every workgroup ends in 2 D float atomics on the same 2 D words: 800 workgroups of one 16-row trip each spent most of the
+  //  launch queueing there -- at most ~256 workgroups, several trips each; VNR_LN_BWD_BLOCKS pins the count)
+  static const int maxb = getenv("VNR_LN_BWD_BLOCKS") ? atoi(getenv("VNR_LN_BWD_BLOCKS")) : 256;
+  int blocks = (rows + 15) / 16; if (blocks > maxb) blocks = maxb; if (blocks < 1) blocks = 1;
   if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
   else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
   *err = hipGetLastError();
@@ -1133,7 +1439,8 @@ hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, in
   static const bool v1 = getenv("VNR_LN_BWD_V1") != nullptr;          // A/B switch: the first-generation wave-per-row kernel
   const bool al = !(((size_t)v | (size_t)dy | (size_t)dv | (size_t)gamma) & 15);
   if (!v1 && al && (D == 256 || D == 512)) {
-    int blocks = (rows + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    static const int maxb = getenv("VNR_LN_BWD_BLOCKS") ? atoi(getenv("VNR_LN_BWD_BLOCKS")) : 256;
+    int blocks = (rows + 15) / 16; if (blocks > maxb) blocks = maxb; if (blocks < 1) blocks = 1;
     if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
     else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
     return hipGetLastError();

@@ -352,7 +352,8 @@ hipError_t launch_attention_bwd_recompute(const float* Q, int ldq, const float* 
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
-                                int causal, float temperature, unsigned* amax_slot, hipStream_t s);
+                                int causal, float temperature, unsigned* amax_slot, hipStream_t s, unsigned* amax_dq = nullptr,
+                                unsigned* amax_dk = nullptr, unsigned* amax_dv = nullptr);   // amax_d*: optional by-products (MFMA kernels only)
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, hipStream_t s);
 bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int rows, int D, float* dst, int lddst, float* dgamma,
                        float* dbeta, hipStream_t s, hipError_t* err);

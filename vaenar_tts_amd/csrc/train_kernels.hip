@@ -635,7 +635,15 @@ struct AttnBwdArgs {
   const int32_t *q_len, *k_len;
   int B, H, Tq, Tk, causal;
   float scale;                             // 1 / sqrt(64) / tau
+  unsigned *amax_dq = nullptr, *amax_dk = nullptr, *amax_dv = nullptr;   // optional: bits of max |dQ|, |dK|, |dV| (atomicMax; zero on entry)
 };
+// max over the wave of a non-negative value -> one atomicMax on its float bits (unsigned order = float order for x >= 0)
+__device__ __forceinline__ void wave_amax_to(unsigned* dst, float m) {
+  if (!dst) return;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dst, __float_as_uint(m));
+}
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const AttnBwdArgs a) {
   __shared__ float dOs[32][65], Ks[64][65], Vs[64][65], dSs[32][65];
@@ -884,16 +892,20 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       }
     }
   }
+  float mxq = 0.f;
   if (qin) {
     float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
     const float f = a.scale * inv;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) =
-            make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 o4 = make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
+        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) = o4;
+        mxq = fmaxf(mxq, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
+      }
   }
+  wave_amax_to(a.amax_dq, mxq);                            // by-product: max |dQ| for the query projection's gradient GEMMs
 }
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
@@ -957,6 +969,7 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       }
     }
   }
+  float mxv = 0.f, mxk = 0.f;
   if (kin) {
     float* pvd = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64;
     float* pkd = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64;
@@ -966,16 +979,24 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d = 32 * nb + 8 * g4 + 4 * half;
-        *reinterpret_cast<float4*>(pvd + d) = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
-        *reinterpret_cast<float4*>(pkd + d) = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
+        const float4 v4 = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
+        const float4 k4 = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
+        *reinterpret_cast<float4*>(pvd + d) = v4;
+        *reinterpret_cast<float4*>(pkd + d) = k4;
+        mxv = fmaxf(mxv, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
+        mxk = fmaxf(mxk, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
       }
   }
+  wave_amax_to(a.amax_dv, mxv);
+  wave_amax_to(a.amax_dk, mxk);
 }
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
-                                int causal, float temperature, unsigned* amax_slot, hipStream_t s) {
+                                int causal, float temperature, unsigned* amax_slot, hipStream_t s, unsigned* amax_dq, unsigned* amax_dk,
+                                unsigned* amax_dv) {
   AttnBwdArgs a;
+  a.amax_dq = amax_dq; a.amax_dk = amax_dk; a.amax_dv = amax_dv;
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.P = P; a.dQ = dQ; a.dK = dK; a.dV = dV; a.dS = dS;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.q_len = q_len; a.k_len = k_len; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal;

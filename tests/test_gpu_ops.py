@@ -75,6 +75,33 @@ def test_dense_concat_residual_layernorm(eng, m, k1, k2, n):
     np.testing.assert_allclose(got, ref, atol=3e-5, rtol=1e-5)
 
 
+def test_dense_concat_panels_further_apart_than_one_descriptor(eng):
+    """concat(x, ctx) -> Dense with the two row panels more than 2 GiB apart (two arena chunks of a long run): round 3 retired the
+    first-generation GEMM that used to take this case; the DMA kernel now gives each panel its own buffer descriptor."""
+    r = rng(77)
+    m, k1, k2, n = 333, 256, 256, 256
+    a1, a2 = r.standard_normal((m, k1)), r.standard_normal((m, k2))
+    w, b = r.standard_normal((k1 + k2, n)) / np.sqrt(k1 + k2), r.standard_normal(n) * 0.1
+    spacer = eng.empty((9 << 26,))                       # one 2.25 GiB allocation: x at its start, ctx 2.2 GiB further on
+    d1 = _lib.DeviceArray(eng, a1.shape, np.float32, ptr=int(spacer.ptr), owner=spacer).copy_from(a1.astype(np.float32))
+    d2 = _lib.DeviceArray(eng, a2.shape, np.float32, ptr=int(spacer.ptr) + (2252 << 20), owner=spacer).copy_from(a2.astype(np.float32))
+    assert int(d2.ptr) - int(d1.ptr) >= (1 << 31)
+    dw, db = eng.to_device(w.astype(np.float32)), eng.to_device(b.astype(np.float32))
+    out = eng.empty((m, n))
+    d = _lib.vnr_dense_desc()
+    d.d_a1, d.lda1, d.k1, d.d_a2, d.lda2, d.k2 = d1.ptr, k1, k1, d2.ptr, k2, k2
+    d.d_w, d.d_bias, d.activation = dw.ptr, db.ptr, _lib.ACT[None]
+    d.d_c, d.ldc, d.m, d.n = out.ptr, n, m, n
+    for opt in (0, 1):                                   # exact fp32 MFMA and the split-fp16 kernel
+        eng.set_option("op_dense_split", opt)
+        _lib.check(eng.lib.vnr_op_dense(eng.handle, C.byref(d)), eng.handle)
+        f = lambda x: np.asarray(x, np.float32).astype(np.float64)
+        ref = O.dense(np.concatenate([f(a1), f(a2)], -1), f(w), f(b))
+        np.testing.assert_allclose(out.numpy(), ref, atol=3e-5, rtol=1e-5)
+    eng.set_option("op_dense_split", 0)
+    del spacer
+
+
 def test_dense_pe_epilogue(eng):
     r = rng(5)
     T, B, k, n = 13, 3, 64, 128
@@ -137,7 +164,9 @@ def attention_ref(q, k, v, ql, kl, H, causal, tau):
     (2, 4, 130, 200, 0, 1, 1.0, True),    # Tk > 128 with alignments (two-pass path)
     (3, 4, 400, 400, 1, 1, 1.0, True),    # the training step's causal self-attention with stored probabilities (Tk <= 512: 8-tile form)
     (2, 2, 70, 300, 0, 1, 0.8, True),     # 5 tiles, partial last tile (Tk % 64 != 0), temperature
-    (1, 2, 40, 520, 0, 1, 1.0, True),     # Tk > 512 with alignments: the first-generation kernel
+    (1, 2, 40, 520, 0, 1, 1.0, True),     # Tk > 512 with alignments: two passes (context + row statistics, then the probabilities)
+    (2, 2, 70, 520, 0, 1, 0.9, True),     # ... ragged: padded query rows exactly uniform, temperature
+    (2, 2, 530, 530, 1, 1, 1.0, True),    # ... causal self-attention beyond 512 keys
     (2, 1, 33, 129, 0, 0, 0.7, True),     # odd sizes, temperature != 1
     (1, 2, 64, 64, 1, 1, 1.0, False),     # causal with alignments requested
     (2, 4, 128, 128, 0, 0, 1.0, False),   # encoder-shaped, full lengths

@@ -1,7 +1,10 @@
-// Fused attention core, second generation (gfx950, fp32 MFMA 32x32x2): balanced, DMA-fed.
+// Fused attention core on fp32 operands (gfx950, 3-term split-fp16 MFMA): balanced, DMA-fed.
 //
-// Same contract as attention.hip (reference modules/attention.py:221-246) -- this kernel is the fast path
-// for every call without alignments and for alignment calls with Tk <= 128 (the decoder cross-attention).
+// Reference modules/attention.py:221-246 (scale, key ^ query (^ causal) mask with the -2^32 fill, softmax, .V, optional
+// alignments) for every caller that holds Q, K, V as fp32 rows: vnr_op_attention, the training step, and inference calls the
+// operand-image kernels (attention3.hip) do not cover.  (Round 1's first-generation kernel, attention.hip, was retired in round 3:
+// alignments with Tk > 512 are now a two-pass form -- this kernel without alignments leaves the softmax row statistics, a small
+// kernel rebuilds the probabilities from Q, K and those.)
 //
 // Decomposition.  grid = (ceil(Tq/64), H, B); a workgroup = 4 waves = one 64-row query block.
 //   wave w : query tile  qt = w & 1  (rows Q0 + 32*qt .. +31)
@@ -16,7 +19,7 @@
 // chunk XOR swizzle (source side) so the S^T = K.Q^T operand reads (ds_read_b128 down a column of chunks) are
 // conflict-free; V rows are linear (the P.V operand read is 32 consecutive floats per half-wave).
 //
-// Operand mapping as in attention.hip: S^T puts one query per lane (softmax reductions in-lane + one
+// Operand mapping: S^T puts one query per lane (softmax reductions in-lane + one
 // cross-half shuffle) and leaves P in A-operand position for O = P.V.
 #include "common.h"
 #include <math.h>
@@ -489,8 +492,40 @@ attn2_kernel(const AttnArgs a, int nqb) {
   if (ts) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); if (tid == 0) { ts[5] = ntiles; unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); ts[7] = xcc; } }
 }
 
+// Alignments of a call with more than 512 keys (no BASELINE configuration has one): P[b][h][q][:] = exp(s - max) / sum rebuilt from
+// Q, K and the row statistics the alignment-free pass left, with the masking of qk_block above.  One wave per query row, plain fp32
+// dot products (a fallback shape: 1e-6 of the 3-term products of the main kernel).
+__global__ void __launch_bounds__(256)
+attn_probs_kernel(const AttnArgs a) {
+  __shared__ float qs[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + wave, hd = blockIdx.y, b = blockIdx.z;
+  if (q >= a.Tq) return;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  qs[wave][lane] = a.Q[(size_t)b * a.q_bs + (size_t)q * a.ldq + hd * 64 + lane];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave-private row: the wave's own lanes are its only readers)
+  const size_t ri = ((size_t)b * a.H + hd) * a.Tq + q;
+  const float m = a.row_max[ri], linv = a.row_linv[ri];
+  const bool use_tau = a.temperature != 1.0f;
+  float* out = a.ali + ri * a.Tk;
+  for (int j = lane; j < a.Tk; j += 64) {
+    const float* kp = a.K + (size_t)b * a.k_bs + (size_t)j * a.ldk + hd * 64;
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4) {
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + d);
+      dot += (kv[0] * qs[wave][d] + kv[1] * qs[wave][d + 1]) + (kv[2] * qs[wave][d + 2] + kv[3] * qs[wave][d + 3]);
+    }
+    float sv = dot * 0.125f;
+    if (use_tau) sv = sv / a.temperature;
+    const bool ok = q < qlen && j < klen && (!a.causal || j <= q);
+    sv = ok ? sv : kMaskFill;                                   // attention.py:240
+    out[j] = fast_exp(sv - m) * linv;
+  }
+}
+
+// operands inside the 2 GiB offset range of the K / V buffer descriptors
 bool attention2_supported(const AttnArgs& a) {
-  if (a.ali && a.Tk > 512) return false;
   const size_t lim = (size_t)1 << 31;
   if (((size_t)a.Tk * a.ldk + 256) * 4 >= lim || ((size_t)a.Tk * a.ldv + 256) * 4 >= lim) return false;
   return true;
@@ -526,6 +561,23 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
     vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
   }
   return hipGetLastError();
+}
+
+// entry point of every attention call on fp32 operands (common.h)
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return hipErrorInvalidValue;
+  if ((a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3)) return hipErrorInvalidValue;
+  if (!attention2_supported(a)) return hipErrorInvalidValue;
+  if (a.ali && a.Tk > 512) {                           // two passes: context + row statistics, then the probabilities
+    if (!a.row_max || !a.row_linv) return hipErrorInvalidValue;
+    AttnArgs f = a;
+    f.ali = nullptr;
+    const hipError_t e = launch_attention2(f, s);
+    if (e != hipSuccess) return e;
+    vnr_launch(attn_probs_kernel, dim3((a.Tq + 3) / 4, a.H, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
+  return launch_attention2(a, s);
 }
 
 }  // namespace vnr

@@ -137,7 +137,6 @@ __device__ __forceinline__ void aoi_store4(const AoiDesc& a, int row, int col, c
 //   plain   : k <  K1 -> A1[m*lda1 + k] ; k >= K1 -> A2[m*lda2 + k-K1]     (tf.concat, K8)
 //   conv    : taps > 0, K = taps*conv_C, k = j*conv_C + c ->
 //             A1[(b*T + t + j - taps/2)*lda1 + c] or 0 outside [0,T)        ('same' Conv1D, K2)
-//   gather  : row index is looked up in gather_ids first (Embedding, K1)
 // Epilogue order: +bias -> act -> *bn_scale+bn_shift -> +pe_w*pe[m % pe_T] -> +residual
 //                 -> (optional, separate pass) LayerNorm.
 struct GemmArgs {
@@ -156,7 +155,6 @@ struct GemmArgs {
   float* C = nullptr; int ldc = 0;
   int M = 0, N = 0, K = 0;
   int taps = 0, conv_T = 1, conv_C = 0;
-  const int32_t* gather_ids = nullptr;
   // fused LayerNorm epilogue (row-panel kernel, requires N <= 256; wider rows use launch_layer_norm)
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
   unsigned long long* dbg_ts = nullptr;   // measurement-only: per-workgroup s_memtime stamps [tiles][8]

@@ -214,7 +214,7 @@ struct ProfScope {
 
 int run_gemm(vnr_handle h, const GemmArgs& g_in) {
   GemmArgs g = g_in;
-  if (h->split_enabled && h->split_scope && !g.gather_ids && g.M >= 64) {
+  if (h->split_enabled && h->split_scope && g.M >= 64) {
     // the fp32 panel that contains g.Wt (sub-panels start on a row boundary and keep the row length K)
     auto it = h->split_panels.upper_bound(g.Wt);
     if (it != h->split_panels.begin()) {
@@ -292,7 +292,13 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   return VNR_OK;
 }
 
-int run_attention(vnr_handle h, const AttnArgs& a, bool cross) {
+int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
+  AttnArgs a = a_in;
+  if (a.ali && a.Tk > 512 && !a.row_max) {             // two-pass alignment form (attention2.hip): scratch for the row statistics
+    const size_t n = (size_t)a.B * a.H * a.Tq;
+    a.row_max = ws_alloc(h, n); a.row_linv = ws_alloc(h, n);
+    if (!a.row_max || !a.row_linv) return fail(h, VNR_ERR_NOMEM, "attention row statistics");
+  }
   const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
                     (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
   const double fl = 4.0 * (double)a.B * a.H * a.Tq * (double)a.Tk * 64;
@@ -472,8 +478,7 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
 
 // self-attention Q|K|V as attention operand images (three images of img_bytes each instead of the fp32 [M, 3D] panel)
 bool self_aoi_on(vnr_handle h, int D, int heads) {
-  static const bool v1 = getenv("VNR_GEMM_V1") != nullptr;
-  return h->aoi_enabled && h->aoi_self && !v1 && D > 0 && D == heads * 64;
+  return h->aoi_enabled && h->aoi_self && D > 0 && D == heads * 64;
 }
 long long aoi_img_bytes(int B, int T, int D) { return (long long)B * (D / 64) * ((T + 31) / 32) * kAoiTile; }
 size_t qkv_floats(bool aoi, int B, int T, int D) { return aoi ? (size_t)(3 * aoi_img_bytes(B, T, D) / 4) : (size_t)B * T * 3 * D; }
@@ -732,7 +737,7 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
   g.A1 = x; g.lda1 = c.cin; g.K1 = c.k * c.cin; g.K = c.k * c.cin; g.Wt = c.wt; g.ldw = c.k * c.cin;
   g.bias = c.bias; g.act = act; g.bn_scale = c.bn_scale; g.bn_shift = c.bn_shift; g.bn_first = bn_first;
   g.C = y; g.ldc = c.cout; g.M = B * T; g.N = c.cout; g.taps = c.k; g.conv_T = T; g.conv_C = c.cin;
-  g.gather_ids = gather;
+  if (gather) return fail(h, VNR_ERR_ARG, "run_conv: the row gather is a separate kernel (launch_gather_rows)");
   if (!h->training) return run_gemm(h, g);
   // training=True (utils.py:76-85): conv -> act -> BatchNormalization on BATCH statistics (all B*T rows, padding
   // included; moving statistics updated, momentum 0.99) -> Dropout
@@ -756,8 +761,6 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
 // layer has its weight image and the channel counts are whole 32-channel tiles (option "split_rows", default 1)
 bool split_rows_ok(vnr_handle h, const std::vector<ConvL>& convs, int M) {
   if (!h->split_rows || h->training || !h->split_enabled || !h->split_scope || convs.empty() || M < 64) return false;      // (run_gemm takes the split path from 64 rows)
-  static const bool v1 = getenv("VNR_GEMM_V1") != nullptr;
-  if (v1) return false;
   for (const ConvL& c : convs) {
     SplitRef r;
     if ((c.cout & 31) || !split_lookup(h, c.wt, c.k * c.cin, c.cout, r)) return false;
@@ -780,8 +783,7 @@ int refresh_bn_affine(vnr_handle h) {
 int run_kv(vnr_handle h, const float* text_embd, int B, int Tt, int mem, const float* panel, int n, float* out, int D) {
   GemmArgs g;
   g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = B * Tt; g.N = n;
-  static const bool gemm_v1 = getenv("VNR_GEMM_V1") != nullptr;     // (the operand-image epilogue exists in gemm2 only)
-  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g) && !gemm_v1) {
+  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g)) {
     const int nblk = n / (2 * D), TT = (Tt + 31) / 32;
     const size_t blk_bytes = (size_t)B * (D / 64) * TT * kAoiTile;
     WS(img, 2 * nblk * blk_bytes / 4);

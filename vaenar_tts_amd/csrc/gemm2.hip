@@ -1,7 +1,13 @@
-// fp32-MFMA GEMM, second generation: LDS-DMA (buffer_load ... lds) multi-stage ring.
+// The tiled GEMM of the path: LDS-DMA (buffer_load ... lds) multi-stage ring, fp32 MFMA or the 3-term split-fp16 products.
 //
-// Same contract as gemm.hip (GemmArgs: Dense / concat-Dense / Conv1D implicit GEMM + fused epilogues,
-// optional fused LayerNorm for row panels) but the global->LDS traffic never passes through VGPRs and is
+// One kernel template covers every dense contraction that is not a row-panel chain (gemm3.hip):
+//   tf.keras.layers.Dense                       (reference modules/attention.py:154-159,401,427,432,
+//                                                utils.py:44-45, decoder.py:164,174,179, transform.py:12-17,36)
+//   tf.concat([x, ctx], -1) -> Dense            (attention.py:410-412,440-449) as two K panels
+//   tf.keras.layers.Conv1D(k, 'same') + act + BN (utils.py:76-85) as an implicit GEMM over taps
+// with fused epilogues (bias / activation / folded BatchNorm / positional term / residual / LayerNorm for row panels / attention
+// operand images / split rows).  (Round 1's register-staged first generation, gemm.hip, was retired in round 3: this kernel now
+// also takes A panels that lie further apart than one 2 GiB buffer descriptor.)  The global->LDS traffic never passes through VGPRs and is
 // issued NSTAGE-1 k-tiles ahead with counted s_waitcnt vmcnt(N) and a raw s_barrier, so a single wave per
 // SIMD keeps the matrix pipe busy (the S1 GEMMs are mid-sized: 200..1800 workgroups, i.e. about one
 // workgroup per CU, where the register-staged kernel exposes the L2 latency of every k-tile).
@@ -86,15 +92,20 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   const int half = lane >> 5, l31 = lane & 31;
 
   // ---- buffer descriptors (wave-uniform: built from kernel arguments only) ---------------------------
-  // ONE descriptor covers both A panels (base = the lower of the two pointers; the launcher checks that
-  // the span fits the 2 GiB offset range), so the panel switch is an offset, not a different SRD.
+  // ONE descriptor covers both A panels when their span fits the 2 GiB offset range (base = the lower of the two pointers):
+  // the panel switch is then an offset, not a different SRD.
   const size_t a1_span = ((size_t)(g.M - 1) * g.lda1 + (MODE == 1 ? g.conv_C : g.K1)) * 4;
   const size_t a2_span = g.A2 ? ((size_t)(g.M - 1) * g.lda2 + (g.K - g.K1)) * 4 : 0;
   const char* abase = (g.A2 && (const char*)g.A2 < (const char*)g.A1) ? (const char*)g.A2 : (const char*)g.A1;
-  const unsigned delta1 = (unsigned)((const char*)g.A1 - abase);
-  const unsigned delta2 = g.A2 ? (unsigned)((const char*)g.A2 - abase) : 0u;
+  const size_t delta1 = (size_t)((const char*)g.A1 - abase);
+  const size_t delta2 = g.A2 ? (size_t)((const char*)g.A2 - abase) : 0;
   const size_t a_end = (delta1 + a1_span > delta2 + a2_span) ? delta1 + a1_span : delta2 + a2_span;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, (unsigned)a_end, 0x00020000);
+  // (two panels further apart than the 2 GiB offset range -- different arena chunks of a long run -- get a descriptor each; the
+  //  select is wave-uniform scalar work per DMA instruction)
+  const bool far = g.A2 && a_end >= ((size_t)1 << 31);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(far ? (const char*)g.A1 : abase), 0, (unsigned)(far ? a1_span : a_end), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)g.A2, 0, (unsigned)a2_span, 0x00020000);   // used when far
+  const unsigned d1 = far ? 0u : (unsigned)delta1, d2 = far ? 0u : (unsigned)delta2;
   // SPLIT: the weight panel is the pre-split fp16 image [N][ceil(K/32)][hi x32 | lo x32] (128 bytes per k-tile,
   // zero padded), i.e. the same bytes-per-row geometry as fp32 with K rounded up to 32.
   const int b_row_bytes = SPLIT ? ((g.K + 31) >> 5) * 128 : g.ldw * 4;
@@ -117,8 +128,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     a_ok[x] = m < g.M;
     a_c4[x] = 4 * c;
     if (MODE == 0) {
-      a_off1[x] = a_ok[x] ? delta1 + (unsigned)(((size_t)m * g.lda1 + 4 * c) * 4) : kOobOffset;
-      a_off2[x] = (a_ok[x] && g.A2) ? delta2 + (unsigned)(((size_t)m * g.lda2 + 4 * c) * 4) : kOobOffset;
+      a_off1[x] = a_ok[x] ? d1 + (unsigned)(((size_t)m * g.lda1 + 4 * c) * 4) : kOobOffset;
+      a_off2[x] = (a_ok[x] && g.A2) ? d2 + (unsigned)(((size_t)m * g.lda2 + 4 * c) * 4) : kOobOffset;
     } else {
       const int mm = a_ok[x] ? m : 0;
       const int b = mm / g.conv_T;
@@ -156,7 +167,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         const int soff = (second ? (k0 - g.K1) : k0) * 4;
         unsigned off = second ? a_off2[x] : a_off1[x];
         if (k0 + a_c4[x] >= lim) off = kOobOffset;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, soff, 0, 0);
+        if (far && second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, dst, 16, off, soff, 0, 0);     // (wave-uniform branch, never taken in the usual case)
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, soff, 0, 0);
       } else {
         const int tt = cv_t[x] + cv_j[x] - (g.taps >> 1);
         const bool ok = a_ok[x] && cv_j[x] < g.taps && tt >= 0 && tt < g.conv_T;
@@ -740,18 +752,12 @@ static hipError_t launch2(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
-// true when the DMA kernel can take this problem (otherwise gemm.hip's register-staged kernel runs)
+// true when the kernel can take this problem (operands inside the 2 GiB offset range of a buffer descriptor, epilogue combinations)
 bool gemm2_supported(const GemmArgs& g) {
-  if (g.gather_ids) return false;
   if (g.A2 && (g.K1 & 31)) return false;                                   // panel switch must be tile-uniform
   const size_t lim = (size_t)1 << 31;
   if (((size_t)g.M * g.lda1 + g.K) * 4 >= lim) return false;
-  if (g.A2) {
-    const char* lo = (const char*)g.A1 < (const char*)g.A2 ? (const char*)g.A1 : (const char*)g.A2;
-    const char* hi1 = (const char*)g.A1 + ((size_t)g.M * g.lda1 + g.K) * 4;
-    const char* hi2 = (const char*)g.A2 + ((size_t)g.M * g.lda2 + g.K) * 4;
-    if ((size_t)((hi1 > hi2 ? hi1 : hi2) - lo) >= lim) return false;     // both panels behind one descriptor
-  }
+  if (g.A2 && ((size_t)g.M * g.lda2 + g.K) * 4 >= lim) return false;       // (each panel behind its own descriptor when they lie far apart)
   if (((size_t)g.N * g.ldw + g.K) * 4 >= lim) return false;
   if (g.ln_gamma && (g.N > 256 || g.taps > 0 || g.bn_scale || g.pe)) return false;
   if (g.aoi.mode && (g.ln_gamma || (g.N & 3) || (g.ldc & 3) || (g.residual && (g.ldr & 3)))) return false;   // image stores: 4-column groups
@@ -821,6 +827,15 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     case 1: return launch2<64, 128, 2, 2, 3, false>(g, s);
     default: return st == 4 ? launch2<64, 64, 2, 2, 4, false>(g, s) : launch2<64, 64, 2, 2, 3, false>(g, s);
   }
+}
+
+// entry point of every tiled GEMM / convolution of the engine (common.h)
+hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipErrorInvalidValue;
+  if ((g.K & 3) || (g.K1 & 3) || (g.lda1 & 3) || (g.A2 && (g.lda2 & 3)) || (g.ldw & 3)) return hipErrorInvalidValue;
+  if (g.taps > 0 && ((g.conv_C & 3) || g.K != g.taps * g.conv_C)) return hipErrorInvalidValue;
+  if (!gemm2_supported(g)) return hipErrorInvalidValue;
+  return launch_gemm2(g, s);
 }
 
 }  // namespace vnr

@@ -150,6 +150,24 @@ def test_inference_long_text_and_ab_switches(opts):
         model.engine.close()
 
 
+def test_inference_beyond_512_latent_frames_and_200_tokens():
+    """Sizes past every tile limit of the fast paths (SURVEY 8c "maximum sizes"): T_text = 200 (two key blocks more than the
+    operand-image cross-attention takes), T_mel = 1200 -> T_z = 600 latent frames (causal self-attention over more than 512 keys,
+    19 row panels per utterance, the last one partial), ragged lengths, alignments returned [B, 4, 600, 200]."""
+    hps, model, oracle = _setup("tiny")
+    try:
+        b = make_batch(2, 200, 1200, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, temperature=1.0, text_step=37, mel_step=171)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        rmel, rali = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+        assert mel.shape == (2, 1200, hps.Audio.num_mels)
+        assert np.abs(mel.numpy() - rmel).max() < MEL_TOL
+        for k in rali:
+            np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
+    finally:
+        model.engine.close()
+
+
 @pytest.mark.parametrize("B,Tt,Tm,rows64", [
     (1, 32, 64, 0), (2, 33, 62, 1), (3, 127, 66, 0), (2, 128, 128, 1), (2, 129, 130, 0), (5, 5, 32, 1), (1, 64, 96, 1), (4, 31, 34, 0),
 ])

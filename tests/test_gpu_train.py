@@ -13,9 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(name):
-    hps = tiny_hps() if name == "tiny" else LJHPS
+    hps = tiny_hps() if name.startswith("tiny") else LJHPS
     w = init_weights(hps, seed=1234, mode="synthetic")
-    if name == "tiny":
+    if name == "tiny-long":      # T_z = 550 latent frames: probabilities beyond 512 keys (two-pass form), 18 query tiles
+        b = make_batch(2, 23, 1100, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, text_step=5, mel_step=211)
+    elif name == "tiny":
         b = make_batch(3, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
                        ragged=True, text_step=3, mel_step=7)
     else:
@@ -33,7 +36,8 @@ def _rel_err(a, b):
     return float(np.abs(a - b).max() / scale)
 
 
-@pytest.mark.parametrize("name,kw,recompute", [("tiny", 1.0, 0), ("tiny", 1e-5, 0), ("lj", 1.0, 0), ("tiny", 1.0, 1), ("lj", 1.0, 1)])
+@pytest.mark.parametrize("name,kw,recompute", [("tiny", 1.0, 0), ("tiny", 1e-5, 0), ("lj", 1.0, 0), ("tiny", 1.0, 1), ("lj", 1.0, 1),
+                                                  ("tiny-long", 1.0, 0), ("tiny-long", 1.0, 1)])
 def test_gradients_match_autograd(name, kw, recompute):
     """kl_weight = 1 makes the flow / posterior-entropy terms as visible as the L2 terms (the schedule value 1e-5 of
     train.py:236-243 is covered too).  recompute = 1: engine option "attn_bwd_recompute" -- the attention backward rebuilds the

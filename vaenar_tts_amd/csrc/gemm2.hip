@@ -778,6 +778,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // (M = 12800, K = 5*256): there the 64x128 tile halves the activation re-reads (53 -> 40 us per layer, tools/sweep_split_tiles.sh).
     // With several batches in flight (wide_tiles) the 64x128 tile wins everywhere: +4 % aggregate throughput (tools/ab_tiles.sh)
     if (t < 0) t = ((g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128)) ? 1 : 2;
+    if ((t == 3 || t == 4) && (g.M < 8192 || g.N < 128)) t = (g.taps > 0 && g.M >= 8192 && g.N >= 128) ? 1 : 2;   // (the 8-wave 128x128 experiment: large-M launches only)
     // Ring depth by how many workgroups share a CU.  A k-tile of a 64x64 workgroup is 16 KB and arrives ~2 kcyc after its DMA was
     // issued: with three stages (two tiles in flight) ONE workgroup per CU streams 32 KB per latency -- a quarter of what the
     // CU's vector-memory path delivers (64 B/clk) -- so its k-loop runs at the memory latency, not at any bandwidth.  Co-resident
@@ -804,11 +805,13 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
         return ns64 >= 6 ? launch2<64, 64, 2, 2, 6, false, 1, 4>(g, s) : launch2<64, 64, 2, 2, 4, false, 1, 4>(g, s);
       }
     }
-    if (g.a_split) {                                                       // activations arrive as split rows (64x64 / 64x128 tiles)
+    if (g.a_split && t != 3 && t != 4) {                                   // activations arrive as split rows (64x64 / 64x128 tiles)
       if ((g.K & 31) || (g.K1 & 31) || (g.taps > 0 && (g.conv_C & 31)) || g.a_absmax) return hipErrorInvalidValue;
       if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, 2>(g, s) : launch2<64, 128, 2, 2, 3, false, 2>(g, s);
       return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, 2>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, 2>(g, s) : launch2<64, 64, 2, 2, 3, false, 2>(g, s);
     }
+    if (t == 3) return g.a_split ? launch2<128, 128, 2, 4, 3, false, 2>(g, s) : launch2<128, 128, 2, 4, 3, false, 1>(g, s);   // experiment: 128x128, 8 waves of 64x32
+    if (t == 4) return g.a_split ? launch2<128, 128, 4, 2, 3, false, 2>(g, s) : launch2<128, 128, 4, 2, 3, false, 1>(g, s);   // experiment: 128x128, 8 waves of 32x64
     if (t == 0) return ns >= 5 ? launch2<128, 128, 2, 2, 5, false, 1>(g, s) : ns == 4 ? launch2<128, 128, 2, 2, 4, false, 1>(g, s) : launch2<128, 128, 2, 2, 3, false, 1>(g, s);
     if (t == 1) return ns >= 4 ? launch2<64, 128, 2, 2, 4, false, 1>(g, s) : launch2<64, 128, 2, 2, 3, false, 1>(g, s);
     return ns >= 6 ? launch2<64, 64, 2, 2, 6, false, 1>(g, s) : ns >= 4 ? launch2<64, 64, 2, 2, 4, false, 1>(g, s) : launch2<64, 64, 2, 2, 3, false, 1>(g, s);

@@ -214,6 +214,8 @@ struct ChainStage {
   const float* gamma; const float* beta;   // LayerNorm or null
   int acc_mode;             // 0: plain stage; 1/2/3: FFN second layer over hidden chunks (start / continue / finish+epilogue)
   float* out; int ldo;      // HBM output [M, n] or null
+  float* out_pre;           // LayerNorm stages: the value BEFORE normalisation (x + Dense(.)), fp32 [M, n] with row stride ldo, or null --
+                            // what the training step's LayerNorm backward needs (train.inc: xblk_chain)
   int out_fmt;              // 0: fp32; 1: `out` is a Q-type attention operand image (AoiDesc mode 1, D = n, n % 64 == 0);
                             // 4: this stage holds columns [aoi_c0, aoi_c0 + n) of a Q|K|V panel of 3*aoi_D columns whose three
                             //    images (aoi_img_bytes each) start at `out` (AoiDesc mode 4)
@@ -230,7 +232,9 @@ struct ChainArgs {
   const float* in1; int ld1;   // panel 1 <- in1[M, D] (or null)
   int M, D, nstages;
   int rows64;                  // 1: 64-row panels (M/64 workgroups), 0: 32-row panels -- see gemm3.hip
-  const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded
+  const float* prm;            // [nstages][bias | gamma | beta][256] fp32: the program's epilogue parameters, zero padded; null = the
+                               // kernel fetches bias / gamma / beta of every stage through their own pointers (training: the values
+                               // change every step, a cached packed copy would be stale)
   // Fused cross-attention (attention.py:445-447; round 2): before stage `att_stage` runs (<= 0 = none), the workgroup computes the
   // cross-attention of its 32 rows itself -- queries = panel 1 (left there by the query-projection stage), K / V = the block's
   // operand images (one 8 KiB tile per (batch, head, 32 keys), Tk <= 128) -- and writes the context into panel 1: chain B,
@@ -387,5 +391,7 @@ struct TransposeJobHost { const float* in; float* out; int rows, cols; };      /
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);
 struct SplitJobHost { const float* src; int rows, cols; char* dst; };            // same layout as the device-side job record
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
+struct OpmJobHost { const float* src; int N, K; char* dst; };          // same layout as the kernel's job record
+hipError_t launch_opmajor_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
 
 }  // namespace vnr

@@ -117,7 +117,7 @@ panel_chain_kernel(const ChainArgs g) {
   // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (no registers; read back with ds_read at the epilogues, so
   //      no vector-memory wait is ever needed there): stage s is copied by wave s mod 8 -- its bias (1 KiB) and, for a
   //      LayerNorm stage, gamma | beta (2 KiB, contiguous in the packed block) into the slot the host assigned (lds_ln)
-  {
+  if (g.prm) {
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
     for (int s_ = wave; s_ < g.nstages; s_ += 8) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + s_ * 1024), 16, (unsigned)(s_ * 3072 + lane * 16), 0, 0, 0);
@@ -125,6 +125,23 @@ panel_chain_kernel(const ChainArgs g) {
       if (lo >= 0) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + lo * 4), 16, (unsigned)(s_ * 3072 + 1024 + lane * 16), 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + PRM_OFF + lo * 4 + 1024), 16, (unsigned)(s_ * 3072 + 2048 + lane * 16), 0, 0, 0);
+      }
+    }
+  } else {
+    // no packed block (training step): every stage's parameters through their own pointers; a descriptor of exactly n floats zero-fills
+    // the slot's padding, one of zero records gives the all-zero bias of a stage without one
+    for (int s_ = wave; s_ < g.nstages; s_ += 8) {
+      const float* bp = g.st[s_].bias; const float* gp = g.st[s_].gamma; const float* ep = g.st[s_].beta;
+      const unsigned nb = (unsigned)g.st[s_].n * 4u;
+      const bool skip = g.st[s_].acc_mode == 1 || g.st[s_].acc_mode == 2;            // (no epilogue of their own: the slot must still be zero)
+      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp ? bp : g.in0), 0, (bp && !skip) ? nb : 0u, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds3_t)(smem + PRM_OFF + s_ * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+      const int lo = g.st[s_].lds_ln;
+      if (lo >= 0) {
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0, nb, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep ? ep : gp), 0, ep ? nb : 0u, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds3_t)(smem + PRM_OFF + lo * 4), 16, (unsigned)(lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (lds3_t)(smem + PRM_OFF + lo * 4 + 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
       }
     }
   }
@@ -515,6 +532,17 @@ panel_chain_kernel(const ChainArgs g) {
       for (int q = 0; q < 4; ++q)
         if (!cok[q]) v[rt][4 * q] = v[rt][4 * q + 1] = v[rt][4 * q + 2] = v[rt][4 * q + 3] = 0.f;
     }
+    if (st.gamma && st.out_pre) {                                       // training: x + Dense(.) before the normalisation
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = m0 + 32 * rt + l31;
+        if (row < g.M) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cok[q]) out_store4(st.out_pre + (size_t)row * st.ldo + 32 * wave + 8 * q + 4 * half, v[rt][4 * q], v[rt][4 * q + 1], v[rt][4 * q + 2], v[rt][4 * q + 3]);
+        }
+      }
+    }
     if (st.gamma) {
       // LayerNormalization (eps 1e-3).  ONE exchange: every wave reduces its own <= 32 columns of a row to (sum, M2 about its own
       // mean) -- two in-lane passes and two half-swaps, no LDS -- and the eight partials are merged exactly (Chan et al.):
@@ -666,7 +694,7 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
   ChainArgs g = g_in;
   static const int prio_mode = getenv("VNR_CHAIN_PRIO") ? atoi(getenv("VNR_CHAIN_PRIO")) : 1;
   g.prio_mode = prio_mode;
-  if (!g.prm || g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
+  if (g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
   int nln = 0;
   for (int i = 0; i < g.nstages; ++i) {
     ChainStage& st = g.st[i];

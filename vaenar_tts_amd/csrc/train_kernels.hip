@@ -2077,6 +2077,39 @@ split_batch_kernel(const SplitJob* jobs, float scale) {
     out[nk * 64 + 32 + p] = (_Float16)(w - (float)hi);
   }
 }
+// ---- batched operand-major image build (same image as misc.hip:opmajor_weights_kernel) for a table of transposed kernels [N][K]:
+//      the weight operands of the chain kernel (gemm3.hip) for the training step's forward pass, rebuilt after every update --------
+struct OpmJob { const float* src; int N, K; char* dst; };
+__global__ void __launch_bounds__(256)
+opmajor_batch_kernel(const OpmJob* jobs, float scale) {
+  const OpmJob j = jobs[blockIdx.y];
+  const int KT = (j.K + 31) >> 5, NB = (j.N + 31) >> 5;
+  const size_t total = (size_t)NB * KT * 128;                 // one thread per (column block, k-tile, k16 step, lane)
+  _Float16* out = reinterpret_cast<_Float16*>(j.dst);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int lane = (int)(idx & 63), t = (int)((idx >> 6) & 1);
+    const size_t blk = idx >> 7;
+    const int kt = (int)(blk % KT);
+    const size_t nb = blk / KT;
+    const int n = (int)nb * 32 + (lane & 31), k0 = kt * 32 + 16 * t + 8 * (lane >> 5);
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = (n < j.N && k0 + e < j.K) ? j.src[(size_t)n * j.K + k0 + e] * scale : 0.f;
+      const _Float16 hh = (_Float16)w;
+      hi[e] = hh; lo[e] = (_Float16)(w - (float)hh);
+    }
+    _Float16* ph = out + ((blk * 4 + 2 * t) * 512) + lane * 8;
+    *reinterpret_cast<h8*>(ph) = hi;
+    *reinterpret_cast<h8*>(ph + 512) = lo;
+  }
+}
+hipError_t launch_opmajor_batch(const void* jobs_device, int njobs, float scale, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  vnr_launch(opmajor_batch_kernel, dim3(16, njobs), dim3(256), 0, s, static_cast<const OpmJob*>(jobs_device), scale);
+  return hipGetLastError();
+}
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   vnr_launch(split_batch_kernel, dim3(32, njobs), dim3(256), 0, s, static_cast<const SplitJob*>(jobs_device), scale);

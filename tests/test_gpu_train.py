@@ -38,17 +38,19 @@ def _rel_err(a, b):
 
 @pytest.mark.parametrize("name,kw,recompute,chain", [("tiny", 1.0, 0, 1), ("tiny", 1e-5, 0, 1), ("lj", 1.0, 0, 1), ("tiny", 1.0, 1, 1), ("lj", 1.0, 1, 1),
                                                         ("tiny-long", 1.0, 0, 1), ("tiny-long", 1.0, 1, 1),
-                                                        ("lj", 1.0, 0, 0), ("lj", 1.0, 0, 2), ("lj", 1e-5, 0, 3)])
+                                                        ("lj", 1.0, 0, 0), ("lj", 1.0, 0, 2), ("lj", 1e-5, 0, 3), ("lj", 1.0, 0, 11), ("lj", 1e-5, 0, 12)])
 def test_gradients_match_autograd(name, kw, recompute, chain):
     """kl_weight = 1 makes the flow / posterior-entropy terms as visible as the L2 terms (the schedule value 1e-5 of
     train.py:236-243 is covered too).  recompute = 1: engine option "attn_bwd_recompute" -- the attention backward rebuilds the
     probabilities from Q, K and the forward's row statistics instead of reading stored ones (ragged lengths, causal and cross).
     chain: engine option "train_chain" -- the forward of every CrossAttentionBLK as two chain launches (1 = default, LJ-sized
-    blocks only; 2 / 3 = 64- / 32-row panels forced) or as separate GEMM / LayerNorm launches (0)."""
+    blocks only; 2 / 3 = 64- / 32-row panels forced) or as separate GEMM / LayerNorm launches (0); by default the backward of those
+    blocks runs as two backward-chain launches as well ("train_chain_bwd", gemm3b.hip; 11 / 12: forward chains, unfused backward)."""
     hps, w, b, mels, eps = _case(name)
     model = VAENAR(hps, weights=w)
     model.engine.set_option("attn_bwd_recompute", recompute)
-    model.engine.set_option("train_chain", chain)
+    model.engine.set_option("train_chain", chain % 10)          # (1x: forward chains with the unfused backward)
+    model.engine.set_option("train_chain_bwd", 0 if chain >= 10 else 1)
     try:
         loss, mel_l2, kl, len_l2 = model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], kw, 2, eps=eps,
                                                     dropout_seed=11, apply_update=False)

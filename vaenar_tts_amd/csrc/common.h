@@ -216,6 +216,7 @@ struct ChainStage {
   float* out; int ldo;      // HBM output [M, n] or null
   float* out_pre;           // LayerNorm stages: the value BEFORE normalisation (x + Dense(.)), fp32 [M, n] with row stride ldo, or null --
                             // what the training step's LayerNorm backward needs (train.inc: xblk_chain)
+  float* out_stats;         // LayerNorm stages: (mean, 1 / sqrt(var + eps)) of every row, [M][2] fp32, or null (the fused backward chain)
   int out_fmt;              // 0: fp32; 1: `out` is a Q-type attention operand image (AoiDesc mode 1, D = n, n % 64 == 0);
                             // 4: this stage holds columns [aoi_c0, aoi_c0 + n) of a Q|K|V panel of 3*aoi_D columns whose three
                             //    images (aoi_img_bytes each) start at `out` (AoiDesc mode 4)
@@ -355,7 +356,7 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
                                 int causal, float temperature, unsigned* amax_slot, hipStream_t s, unsigned* amax_dq = nullptr,
-                                unsigned* amax_dk = nullptr, unsigned* amax_dv = nullptr);   // amax_d*: optional by-products (MFMA kernels only)
+                                unsigned* amax_dk = nullptr, unsigned* amax_dv = nullptr, int amax_ready = 0);   // amax_d*: optional by-products (MFMA kernels only)
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, hipStream_t s);
 bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int rows, int D, float* dst, int lddst, float* dgamma,
                        float* dbeta, hipStream_t s, hipError_t* err);
@@ -391,6 +392,32 @@ struct TransposeJobHost { const float* in; float* out; int rows, cols; };      /
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);
 struct SplitJobHost { const float* src; int rows, cols; char* dst; };            // same layout as the device-side job record
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
+// ---- backward row-panel chains of a CrossAttentionBLK (gemm3b.hip; training step) ---------------------------------------------------
+// Every matrix is fp32 row-major with 256 columns unless a leading dimension is given; `*r` are operand-major split images (scale 256)
+// of Dense kernels AS STORED [K][N]; column-sum outputs (dg*, db*, dbias*) receive float atomics; amax* are optional device words
+// that receive the bits of max |value written| (atomicMax, zero on entry).
+struct BwdChainArgs {
+  int M;                                  // rows
+  int seg;                                // 0: LN3' -> dense2' -> relu' -> dense1' -> LN2' -> att_proj2' ; 1: LN1' -> att_proj1'
+  const unsigned* amax_in;                // bits of ~max |dy| (any value within a factor 2^8: it only centres the fp16 range)
+  const float* dy; int ld_dy;             // gradient of the segment's LayerNorm output (block output / y)
+  const float* vA; const float* stA; const float* gA;        // head LayerNorm: its input, (mean, rstd) per row [M][2], gamma
+  float* dvA; float* dgA; float* dbA; float* dbiasA; unsigned* amaxA;   // d(input), dgamma, dbeta, bias gradient of the Dense in front
+  const void* w2r; const void* w1r; int F;                   // seg 0: dense2 [F][256], dense1 [256][F] images, hidden width
+  const float* hdn; float* dh; float* dbias1; unsigned* amax_dh;        // hidden activations [M][F] and their gradient (before dense1)
+  const float* vB; const float* stB; const float* gB;        // seg 0: LayerNorm2
+  float* dvB; float* dgB; float* dbB; float* dbiasB; unsigned* amaxB;
+  const void* pr;                         // att_proj kernel image [512][256]
+  float* out0; int acc0;                  // d . W^T[:, 0:256] + d (the residual): gradient of the projection's first input; acc0: add to what is there
+  float* out1; unsigned* amax_out1;       // d . W^T[:, 256:512]: gradient of the attention context
+  // Column sums leave the kernel as one row of per-workgroup partials, partial[workgroup][pcols] (plain stores), in the order
+  // dgA | dbA | dbiasA (256 each) and, for seg 0, dbias1 (F) | dgB | dbB | dbiasB; launch_bwd_chain adds a small second kernel that sums
+  // the rows and adds the totals to the gradients.  (Float atomics from 200 workgroups onto the same 256 words -- the first version --
+  // serialised in the L2: 0.2 ms of the launch.)  Scratch of ceil(M / rows per workgroup) * pcols floats.
+  float* partial;
+};
+hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s);
+inline int bwd_chain_pcols(int seg, int F) { return seg == 0 ? 6 * 256 + F : 3 * 256; }
 struct OpmJobHost { const float* src; int N, K; char* dst; };          // same layout as the kernel's job record
 hipError_t launch_opmajor_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <map>
 #include <tuple>
 #include <utility>
@@ -125,6 +126,7 @@ struct vnr_context {
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
+  int train_chain_bwd = 1;           // engine option "train_chain_bwd": the backward of the same blocks as two backward-chain launches (gemm3b.hip)
   int train_chain = 1;               // engine option "train_chain" (train.inc: xblk_chain): 0 off, 1 auto, 2 / 3 force 64- / 32-row panels
   bool attn_bwd_recompute = false;   // engine option "attn_bwd_recompute" (train.inc: attn)
   bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
@@ -1963,6 +1965,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }
+  if (!strcmp(name, "train_chain_bwd")) { h->train_chain_bwd = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain")) { if (value < 0 || value > 3) return fail(h, VNR_ERR_ARG, "train_chain: 0..3"); h->train_chain = value; return VNR_OK; }
   if (!strcmp(name, "attn_presplit_self")) { h->aoi_self = value != 0; return VNR_OK; }
   if (!strcmp(name, "op_attn_presplit")) { h->op_attn_presplit = value != 0; return VNR_OK; }

@@ -589,6 +589,8 @@ panel_chain_kernel(const ChainArgs g) {
           var += mq[w] + (float)c * dm * dm;
         }
         const float rstd = 1.0f / sqrtf(var * rn + kLnEps);
+        if (st.out_stats && wave == 0 && half == 0 && m0 + 32 * rt + l31 < g.M)
+          *reinterpret_cast<float2*>(st.out_stats + 2 * (size_t)(m0 + 32 * rt + l31)) = make_float2(mu, rstd);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int col = 32 * wave + 8 * q + 4 * half;

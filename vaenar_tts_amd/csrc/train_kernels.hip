@@ -994,7 +994,7 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
                                 int causal, float temperature, unsigned* amax_slot, hipStream_t s, unsigned* amax_dq, unsigned* amax_dk,
-                                unsigned* amax_dv) {
+                                unsigned* amax_dv, int amax_ready) {
   AttnBwdArgs a;
   a.amax_dq = amax_dq; a.amax_dk = amax_dk; a.amax_dv = amax_dv;
   a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.P = P; a.dQ = dQ; a.dK = dK; a.dV = dV; a.dS = dS;
@@ -1008,8 +1008,10 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
     vnr_launch(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
     return hipGetLastError();
   }
-  hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
-  if (e != hipSuccess) return e;
+  if (!amax_ready) {                                 // (amax_ready: the producer of dO left max |dO| in *amax_slot -- the backward chain)
+    const hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
+    if (e != hipSuccess) return e;
+  }
   vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   vnr_launch(attn_bwd_dkv_mfma_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   return hipGetLastError();

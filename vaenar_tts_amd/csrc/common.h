@@ -401,6 +401,10 @@ struct BwdChainArgs {
   int seg;                                // 0: LN3' -> dense2' -> relu' -> dense1' -> LN2' -> att_proj2' ; 1: LN1' -> att_proj1'
   const unsigned* amax_in;                // bits of ~max |dy| (any value within a factor 2^8: it only centres the fp16 range)
   const float* dy; int ld_dy;             // gradient of the segment's LayerNorm output (block output / y)
+  // head: dy += sum_i pre_src[i] . W_i^T -- data gradients of Dense layers that READ the LayerNorm output (the next block's self Q, K, V
+  // projections of the block output; the cross query projection of y): pre_src[i] = d(their output) [M,256], pre_w[i] = image of their
+  // kernel [256][256], amax_pre[i] = bits of max |pre_src[i]| or null
+  int npre; const float* pre_src[3]; const void* pre_w[3]; const unsigned* amax_pre[3];
   const float* vA; const float* stA; const float* gA;        // head LayerNorm: its input, (mean, rstd) per row [M][2], gamma
   float* dvA; float* dgA; float* dbA; float* dbiasA; unsigned* amaxA;   // d(input), dgamma, dbeta, bias gradient of the Dense in front
   const void* w2r; const void* w1r; int F;                   // seg 0: dense2 [F][256], dense1 [256][F] images, hidden width
@@ -409,6 +413,7 @@ struct BwdChainArgs {
   float* dvB; float* dgB; float* dbB; float* dbiasB; unsigned* amaxB;
   const void* pr;                         // att_proj kernel image [512][256]
   float* out0; int acc0;                  // d . W^T[:, 0:256] + d (the residual): gradient of the projection's first input; acc0: add to what is there
+  unsigned* amax_out0;                    // by-product: max |out0 as written|
   float* out1; unsigned* amax_out1;       // d . W^T[:, 256:512]: gradient of the attention context
   // Column sums leave the kernel as one row of per-workgroup partials, partial[workgroup][pcols] (plain stores), in the order
   // dgA | dbA | dbiasA (256 each) and, for seg 0, dbias1 (F) | dgB | dbB | dbiasB; launch_bwd_chain adds a small second kernel that sums

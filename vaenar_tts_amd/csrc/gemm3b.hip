@@ -59,7 +59,10 @@ bwd_chain_kernel(const BwdChainArgs g) {
   // ---- scale of the gradients inside the kernel ---------------------------------------------------------------------------------
   float s0 = 1.f, inv0 = 1.f;
   {
-    const unsigned bits = g.amax_in ? *g.amax_in : 0u;
+    unsigned bits = g.amax_in ? *g.amax_in : 0u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < g.npre && g.amax_pre[i]) { const unsigned b2 = *g.amax_pre[i]; bits = b2 > bits ? b2 : bits; }      // (non-negative floats: integer order)
     const int e = (int)(bits >> 23) & 0xff;
     if (e > 0 && e < 255) {
       int sft = 6 - (e - 127);
@@ -72,14 +75,16 @@ bwd_chain_kernel(const BwdChainArgs g) {
 
   // ---- the weight stream: the GEMM stages of the segment as one flat sequence of k-tiles (eight per stage) ------------------------
   const int nch = g.seg == 0 ? g.F >> 8 : 0;
-  const int nstages = 2 * nch + 2;
+  const int npre = g.npre;
+  const int nstages = npre + 2 * nch + 2;
   h16x8 wreg[PF][4];
   int fs = 0, fk = 0;
   unsigned fvoff = kOobB;
   __amdgpu_buffer_rsrc_t frs;
   auto open_stage = [&](int s_) {
     const void* w; int kt_total, kt0, cb0;
-    if (s_ < 2 * nch) {
+    if (s_ < npre) { w = s_ == 0 ? g.pre_w[0] : s_ == 1 ? g.pre_w[1] : g.pre_w[2]; kt_total = 8; kt0 = 0; cb0 = 0; }                 // head: d(output of a reader of the LayerNorm output) . W^T
+    else if ((s_ -= npre) < 2 * nch) {
       const int ch = s_ >> 1;
       if (!(s_ & 1)) { w = g.w2r; kt_total = 8; kt0 = 0; cb0 = 8 * ch; }              // d(hidden chunk) = dv3 . W2^T[:, chunk]
       else { w = g.w1r; kt_total = g.F >> 5; kt0 = 8 * ch; cb0 = 0; }                  // d(o) += d(hidden chunk) . W1^T[chunk, :]
@@ -195,7 +200,7 @@ bwd_chain_kernel(const BwdChainArgs g) {
       }
     }
   };
-  float mxA = 0.f, mxH = 0.f, mxB = 0.f, mx1 = 0.f, mx_unused = 0.f;
+  float mxA = 0.f, mxH = 0.f, mxB = 0.f, mx1 = 0.f, mx0 = 0.f;
   // column sums over the workgroup's rows of a per-lane array (already summed over the row tiles): 32 lanes of a half -> lane 0 of it,
   // which stores them into this workgroup's row of the partial-sum matrix at column offset `off`
   const int pcols = g.seg == 0 ? 6 * 256 + g.F : 3 * 256;
@@ -271,11 +276,40 @@ bwd_chain_kernel(const BwdChainArgs g) {
 
   // ================= head: incoming gradient -> LayerNorm backward -> dvA ================================================================
   float d[RT][16];
-  load_rows(g.dy, g.ld_dy, 0, d);
+  if (npre > 0) {
+    f32x16 accP[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) d[rt][i] *= s0;
+      for (int r = 0; r < 16; ++r) accP[rt][r] = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < npre; ++i) {
+      load_rows(i == 0 ? g.pre_src[0] : i == 1 ? g.pre_src[1] : g.pre_src[2], 256, 0, d);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d[rt][j] *= s0;
+      store_panel(1, d);
+      lds_barrier_b();
+      kloop(panel_ptr(1));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accP[rt][r] += acc[rt][r];
+      lds_barrier_b();                                                   // panel 1 may be rewritten
+    }
+    load_rows(g.dy, g.ld_dy, 0, d);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[rt][i] = d[rt][i] * s0 + accP[rt][i] * wsc;
+  } else {
+    load_rows(g.dy, g.ld_dy, 0, d);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[rt][i] *= s0;
+  }
   ln_bwd(d, g.vA, g.stA, g.gA, 0, 256);
   store_rows(g.dvA, 256, 0, d, inv0, false, mxA);
   bias_sum(d, 512);
@@ -328,7 +362,7 @@ bwd_chain_kernel(const BwdChainArgs g) {
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[rt][i] += acc[rt][i] * wsc;
-  store_rows(g.out0, 256, 0, d, inv0, g.acc0 != 0, mx_unused);
+  store_rows(g.out0, 256, 0, d, inv0, g.acc0 != 0, mx0);
   kloop(panel_ptr(0));
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -337,20 +371,23 @@ bwd_chain_kernel(const BwdChainArgs g) {
   store_rows(g.out1, 256, 0, d, inv0, false, mx1);
   // ---- abs-max by-products: lanes -> wave -> workgroup (through the exchange array), one atomicMax per word ---------------------------
   {
-    float m4[4] = {mxA, mxH, mxB, mx1};
+    float m4[5] = {mxA, mxH, mxB, mx1, mx0};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) m4[i] = fmaxf(m4[i], __shfl_xor(m4[i], o, 64));
     }
     lds_barrier_b();                                                     // (the exchange arrays are idle: every LayerNorm stage is behind us)
-    if (lane == 0) { scr[wave * 4] = m4[0]; scr[wave * 4 + 1] = m4[1]; scr[wave * 4 + 2] = m4[2]; scr[wave * 4 + 3] = m4[3]; }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) scr[wave * 8 + i] = m4[i];
+    }
     lds_barrier_b();
-    if (tid < 4) {
+    if (tid < 5) {
       float m = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) m = fmaxf(m, scr[w * 4 + tid]);
-      unsigned* dst = tid == 0 ? g.amaxA : tid == 1 ? g.amax_dh : tid == 2 ? g.amaxB : g.amax_out1;
+      for (int w = 0; w < 8; ++w) m = fmaxf(m, scr[w * 8 + tid]);
+      unsigned* dst = tid == 0 ? g.amaxA : tid == 1 ? g.amax_dh : tid == 2 ? g.amaxB : tid == 3 ? g.amax_out1 : g.amax_out0;
       if (dst && m > 0.f) atomicMax(dst, __float_as_uint(m));
     }
   }
@@ -386,8 +423,9 @@ __global__ void __launch_bounds__(256) bwd_chain_colsum_kernel(const ColFinishAr
 
 hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s) {
   if (g.M <= 0 || (g.seg != 0 && g.seg != 1) || !g.dy || !g.vA || !g.stA || !g.gA || !g.dvA || !g.dgA || !g.dbA || !g.dbiasA || !g.pr ||
-      !g.out0 || !g.out1 || (g.ld_dy & 3) || !g.partial)
+      !g.out0 || !g.out1 || (g.ld_dy & 3) || !g.partial || g.npre < 0 || g.npre > 3)
     return hipErrorInvalidValue;
+  for (int i = 0; i < g.npre; ++i) if (!g.pre_src[i] || !g.pre_w[i]) return hipErrorInvalidValue;
   if (g.seg == 0 && (!g.w2r || !g.w1r || g.F <= 0 || (g.F & 255) || !g.hdn || !g.dh || !g.dbias1 || !g.vB || !g.stB || !g.gB || !g.dvB || !g.dgB ||
                      !g.dbB || !g.dbiasB))
     return hipErrorInvalidValue;

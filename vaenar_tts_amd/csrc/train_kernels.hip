@@ -816,44 +816,34 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   const bool vec4 = (a.Tk & 3) == 0;
-  // Software prefetch: the raw values of tile j0 + 32 (V row piece, K^T column piece, this lane's probabilities) are requested before
-  // tile j0 is multiplied, so their HBM latency hides under its MFMAs (the first form fetched, converted and multiplied strictly in
-  // turn: 13 exposed round trips per workgroup).
-  float nxv[8], nxk[8], np[16];
-  auto fetch_tile = [&](int j0) {
-    const int key = tid >> 3, d8 = (tid & 7) * 8;
-    const bool ok = j0 + key < a.Tk;
-    const float* vp = a.V + ((size_t)b * a.Tk + (ok ? j0 + key : 0)) * a.ldv + hd * 64 + d8;
+  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+    __syncthreads();
+    {   // stage V [key][d] (thread: key = tid>>3, 8 d) and K^T [d][key] (thread: d = tid&63, 8 keys), split once
+      const int key = tid >> 3, d8 = (tid & 7) * 8;
+      float x[8];
+      const bool ok = j0 + key < a.Tk;
+      const float* vp = a.V + ((size_t)b * a.Tk + j0 + key) * a.ldv + hd * 64 + d8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) nxv[e] = ok ? vp[e] : 0.f;
-    const int d = tid & 63, rg = tid >> 6;
+      for (int e = 0; e < 8; ++e) x[e] = ok ? vp[e] : 0.f;
+      h16x8_t hi, lo; split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Vh[key * VS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Vl[key * VS + d8]) = lo;
+      const int d = tid & 63, rg = tid >> 6;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const int kk = j0 + 8 * rg + e; nxk[e] = kk < a.Tk ? a.K[((size_t)b * a.Tk + kk) * a.ldk + hd * 64 + d] : 0.f; }
+      for (int e = 0; e < 8; ++e) { const int kk = j0 + 8 * rg + e; x[e] = kk < a.Tk ? a.K[((size_t)b * a.Tk + kk) * a.ldk + hd * 64 + d] : 0.f; }
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Kh[d * KS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Kl[d * KS + 8 * rg]) = lo;
+    }
+    // P[q][j0 + frow(r, half)] : four runs of 4 consecutive keys per lane
+    float p[16];
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int kk = j0 + 8 * g4 + 4 * half;
       const float* pp = Pb + (size_t)(qin ? q : 0) * a.Tk + kk;
-      if (qin && vec4 && kk + 3 < a.Tk) { const float4 v4 = *reinterpret_cast<const float4*>(pp); np[4 * g4] = v4.x; np[4 * g4 + 1] = v4.y; np[4 * g4 + 2] = v4.z; np[4 * g4 + 3] = v4.w; }
+      if (qin && vec4 && kk + 3 < a.Tk) { const float4 v4 = *reinterpret_cast<const float4*>(pp); p[4 * g4] = v4.x; p[4 * g4 + 1] = v4.y; p[4 * g4 + 2] = v4.z; p[4 * g4 + 3] = v4.w; }
       else
 #pragma unroll
-        for (int e = 0; e < 4; ++e) np[4 * g4 + e] = (qin && kk + e < a.Tk) ? pp[e] : 0.f;
+        for (int e = 0; e < 4; ++e) p[4 * g4 + e] = (qin && kk + e < a.Tk) ? pp[e] : 0.f;
     }
-  };
-  fetch_tile(0);
-  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
-    __syncthreads();
-    {   // V [key][d] (thread: key = tid>>3, 8 d) and K^T [d][key] (thread: d = tid&63, 8 keys) of THIS tile from the prefetched registers, split once
-      const int key = tid >> 3, d8 = (tid & 7) * 8;
-      h16x8_t hi, lo; split8_t(nxv, hi, lo);
-      *reinterpret_cast<h16x8_t*>(&Vh[key * VS + d8]) = hi; *reinterpret_cast<h16x8_t*>(&Vl[key * VS + d8]) = lo;
-      const int d = tid & 63, rg = tid >> 6;
-      split8_t(nxk, hi, lo);
-      *reinterpret_cast<h16x8_t*>(&Kh[d * KS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Kl[d * KS + 8 * rg]) = lo;
-    }
-    float p[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = np[r];
-    if (j0 + 32 < a.Tk) fetch_tile(j0 + 32);               // (workgroup-uniform)
     __syncthreads();
     // dP^T[key][q] = sum_d V[key][d] dO[q][d]
     f32x16 dpt;
@@ -934,46 +924,35 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
     for (int r = 0; r < 16; ++r) { accv[nb][r] = 0.f; acck[nb][r] = 0.f; }
   const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   const float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
-  // Software prefetch, as in the dQ kernel: the raw dO^T / Q^T pieces and this lane's P / dS entries of tile q0 + 32 are requested
-  // before tile q0 is multiplied.
-  float nx[8], ny[8], npv[2][8], nsv[2][8];
-  auto fetch_tile = [&](int q0) {
-    const int d = tid & 63, rg = tid >> 6;
+  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
+    __syncthreads();
+    {   // stage dO^T and Q^T [d][32 queries]: thread d = tid&63, queries 8*rg .. +7
+      const int d = tid & 63, rg = tid >> 6;
+      float x[8], y[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int qq = q0 + 8 * rg + e;
-      const bool ok = qq < a.Tq;
-      nx[e] = ok ? a.dO[((size_t)b * a.Tq + qq) * a.lddo + hd * 64 + d] * sc : 0.f;
-      ny[e] = ok ? a.Q[((size_t)b * a.Tq + qq) * a.ldq + hd * 64 + d] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int qq = q0 + 8 * rg + e;
+        const bool ok = qq < a.Tq;
+        x[e] = ok ? a.dO[((size_t)b * a.Tq + qq) * a.lddo + hd * 64 + d] * sc : 0.f;
+        y[e] = ok ? a.Q[((size_t)b * a.Tq + qq) * a.ldq + hd * 64 + d] : 0.f;
+      }
+      h16x8_t hi, lo;
+      split8_t(x, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Oh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ol[d * TS + 8 * rg]) = lo;
+      split8_t(y, hi, lo);
+      *reinterpret_cast<h16x8_t*>(&Qh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ql[d * TS + 8 * rg]) = lo;
     }
+    // B operands straight from HBM: P / dS [query slot][key = lane]: 8 consecutive queries per k16 step and lane half
+    float pv[2][8], sv[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int qq = q0 + 16 * t + 8 * half + e;
         const bool ok = kin && qq < a.Tq;
-        npv[t][e] = ok ? Pb[(size_t)qq * a.Tk + key] : 0.f;
-        nsv[t][e] = ok ? dSb[(size_t)qq * a.Tk + key] : 0.f;
+        pv[t][e] = ok ? Pb[(size_t)qq * a.Tk + key] : 0.f;
+        sv[t][e] = ok ? dSb[(size_t)qq * a.Tk + key] : 0.f;
       }
-  };
-  fetch_tile(0);
-  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
-    __syncthreads();
-    {   // dO^T and Q^T [d][32 queries] of THIS tile from the prefetched registers: thread d = tid&63, queries 8*rg .. +7
-      const int d = tid & 63, rg = tid >> 6;
-      h16x8_t hi, lo;
-      split8_t(nx, hi, lo);
-      *reinterpret_cast<h16x8_t*>(&Oh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ol[d * TS + 8 * rg]) = lo;
-      split8_t(ny, hi, lo);
-      *reinterpret_cast<h16x8_t*>(&Qh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ql[d * TS + 8 * rg]) = lo;
-    }
-    // B operands: P / dS [query slot][key = lane]: 8 consecutive queries per k16 step and lane half
-    float pv[2][8], sv[2][8];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { pv[t][e] = npv[t][e]; sv[t][e] = nsv[t][e]; }
-    if (q0 + 32 < a.Tq) fetch_tile(q0 + 32);               // (workgroup-uniform)
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

@@ -260,7 +260,13 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * 32 rows); 0 = three launches (chain, attention kernel, chain).  Blocks whose alignments are returned are never fused.
  * "attn_bwd_recompute" (default 0): vnr_train_step keeps no attention probabilities -- the forward leaves the softmax row
  * statistics and the backward kernels rebuild P from Q and K (2 x 82 MB less workspace per causal self-attention at B = 32,
- * T = 400); measured slower than the stored form on the T1 step (35.3 vs 32.1 ms), hence off. */
+ * T = 400); measured slower than the stored form on the T1 step (35.3 vs 32.1 ms), hence off.
+ * "train_chain" (default 1): vnr_train_step runs the forward of every CrossAttentionBLK (attention.py:436-452) over the latent
+ * frames as two row-panel chain launches that also store every intermediate the backward pass needs (0 = one GEMM / LayerNorm
+ * launch per layer; 2 / 3 = 64- / 32-row panels forced, 1 picks 64-row panels from 192 panels up).  "train_chain_bwd" (default 1,
+ * needs train_chain): the backward of those blocks between their attention cores -- LayerNorm', dense2', relu', dense1',
+ * LayerNorm', att_proj' with the bias / gamma / beta gradients and the abs-max words of the kernel-gradient GEMMs as by-products --
+ * as two backward-chain launches per block (0 = one launch per operation). */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,

@@ -46,11 +46,12 @@ def main():
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import kernel_source_digest
 
-        def gemm2_split(k):           # last template argument of gemm2_kernel: 0 = fp32 MFMA, 1 / 2 = split-fp16 (true / false in round 1)
+        def gemm2_split(k):           # the SPLIT template argument of gemm2_kernel: 0 = fp32 MFMA, 1 / 2 = split-fp16 (true / false in round 1)
             if "gemm2_kernel<" not in k:
                 return None
-            last = k[k.index("<") + 1:k.index(">")].split(",")[-1].strip()
-            return last in ("1", "2", "true")
+            targs = [x.strip() for x in k[k.index("<") + 1:k.index(">")].split(",")]
+            split = targs[7] if len(targs) >= 9 else targs[-1]       # (round 3 appended the loader-wave count behind SPLIT)
+            return split in ("1", "2", "true")
         out = {
             "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 "
                       "--profile-steps 1 --in-flight 0 --no-train --no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md "

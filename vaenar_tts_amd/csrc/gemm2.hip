@@ -785,6 +785,8 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // workgroups hide that for each other (3 x 48 KB of LDS), a launch of <= 256 workgroups has nobody to hide behind: it gets
     // six stages (96 KB), two per CU get four (2 x 64 KB).  VNR_SPLIT_STAGES pins the depth for A/B runs.
     static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    if (ns < 0 && g.wide_tiles) ns = 3;                   // several batches in flight (bench.py --streams / batches_in_flight): co-resident workgroups of the
+                                                          // other batches hide the latency; deeper rings and loader waves only cost residency there
     if (ns < 0) {
       const int bm = t == 0 ? 128 : 64, bn = t == 2 ? 64 : 128;
       const long wgs = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
@@ -797,7 +799,7 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // 128x128 tiles with loader waves reach 61 % MFMA issue in the loop but four accumulator blocks per wave make the epilogue
     // (tanh + BatchNorm + split stores by 4 of 8 waves) as long as the loop saved.  VNR_GEMM_LW=0 restores the round-2 kernels.
     static const int lw_on = getenv("VNR_GEMM_LW") ? atoi(getenv("VNR_GEMM_LW")) : 1;
-    if (lw_on && !g.no_loader_waves && t == 2 && stile < 0 && (!g.a_split || (!(g.K & 31) && !(g.K1 & 31) && !(g.taps > 0 && (g.conv_C & 31)) && !g.a_absmax))) {
+    if (lw_on && !g.no_loader_waves && !g.wide_tiles && t == 2 && stile < 0 && (!g.a_split || (!(g.K & 31) && !(g.K1 & 31) && !(g.taps > 0 && (g.conv_C & 31)) && !g.a_absmax))) {
       const long w64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
       if (w64 <= 2 * ncu) {
         const int ns64 = sstages > 0 ? sstages : (w64 <= ncu ? 6 : 4);

@@ -907,10 +907,17 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   }
   wave_amax_to(a.amax_dq, mxq);                            // by-product: max |dQ| for the query projection's gradient GEMMs
 }
+// WIDE (round 3; Tk % 4 == 0, 16-byte aligned rows): every global access of the q-tile loop is a 16-byte one.  The first form issued 48
+// four-byte loads per thread and tile (dO^T / Q^T column pieces, P / dS entries of the lane's key) -- at 60-130 clk of issue per
+// vector-memory instruction that was most of a tile's 8 kcyc.  Now dO / Q rows arrive as float4 and are transposed by the LDS stores,
+// the wave's 32 x 32 P and dS tiles arrive as float4 row pieces and are turned into operand order through a padded LDS tile.
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   constexpr int TS = 40;                                     // [d][32 queries] tiles, row stride in halfs
+  constexpr int PS = 36;                                     // WIDE: P / dS staging tile [32 queries][32 keys], row stride in floats
   __shared__ __attribute__((aligned(16))) _Float16 Oh[64 * TS], Ol[64 * TS], Qh[64 * TS], Ql[64 * TS];
+  __shared__ __attribute__((aligned(16))) float Pt[WIDE ? 4 * 2 * 32 * PS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int key = blockIdx.x * 128 + wave * 32 + l31;        // this lane's key
@@ -926,6 +933,60 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   const float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   for (int q0 = 0; q0 < a.Tq; q0 += 32) {
     __syncthreads();
+    float pv[2][8], sv[2][8];
+    if (WIDE) {
+      {   // dO and Q rows: thread query qi = tid>>3, 8 consecutive d; transposed into the [d][32 queries] tiles by scalar LDS stores
+        const int qi = tid >> 3, d8 = (tid & 7) * 8, qq = q0 + qi;
+        const bool ok = qq < a.Tq;
+        float x[8], y[8];
+        const float* dp = a.dO + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.lddo + hd * 64 + d8;
+        const float* qp = a.Q + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.ldq + hd * 64 + d8;
+        const float4 d0 = ok ? *reinterpret_cast<const float4*>(dp) : make_float4(0.f, 0.f, 0.f, 0.f), d1 = ok ? *reinterpret_cast<const float4*>(dp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g0 = ok ? *reinterpret_cast<const float4*>(qp) : make_float4(0.f, 0.f, 0.f, 0.f), g1 = ok ? *reinterpret_cast<const float4*>(qp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[0] = d0.x * sc; x[1] = d0.y * sc; x[2] = d0.z * sc; x[3] = d0.w * sc; x[4] = d1.x * sc; x[5] = d1.y * sc; x[6] = d1.z * sc; x[7] = d1.w * sc;
+        y[0] = g0.x; y[1] = g0.y; y[2] = g0.z; y[3] = g0.w; y[4] = g1.x; y[5] = g1.y; y[6] = g1.z; y[7] = g1.w;
+        h16x8_t xh, xl, yh, yl;
+        split8_t(x, xh, xl);
+        split8_t(y, yh, yl);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int o = (d8 + e) * TS + qi;
+          Oh[o] = xh[e]; Ol[o] = xl[e]; Qh[o] = yh[e]; Ql[o] = yl[e];
+        }
+      }
+      {   // this wave's P and dS tiles [32 queries][its 32 keys]: float4 row pieces -> LDS
+        const int c4 = (lane & 7) * 4, kc = blockIdx.x * 128 + wave * 32 + c4;
+        float* Pw = Pt + (wave * 2) * 32 * PS;
+        float* Sw = Pw + 32 * PS;
+#pragma unroll
+        for (int x4 = 0; x4 < 4; ++x4) {
+          const int row = 8 * x4 + (lane >> 3), qq = q0 + row;
+          float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), ss = pp;
+          if (qq < a.Tq && kc + 3 < a.Tk) {
+            pp = *reinterpret_cast<const float4*>(Pb + (size_t)qq * a.Tk + kc);
+            ss = *reinterpret_cast<const float4*>(dSb + (size_t)qq * a.Tk + kc);
+          } else if (qq < a.Tq) {
+            const float* pr = Pb + (size_t)qq * a.Tk + kc; const float* sr = dSb + (size_t)qq * a.Tk + kc;
+            if (kc < a.Tk) { pp.x = pr[0]; ss.x = sr[0]; } if (kc + 1 < a.Tk) { pp.y = pr[1]; ss.y = sr[1]; } if (kc + 2 < a.Tk) { pp.z = pr[2]; ss.z = sr[2]; }
+          }
+          *reinterpret_cast<float4*>(Pw + row * PS + c4) = pp;
+          *reinterpret_cast<float4*>(Sw + row * PS + c4) = ss;
+        }
+      }
+      __syncthreads();
+      {
+        const float* Pw = Pt + (wave * 2) * 32 * PS;
+        const float* Sw = Pw + 32 * PS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int row = 16 * t + 8 * half + e;
+            pv[t][e] = Pw[row * PS + l31];
+            sv[t][e] = Sw[row * PS + l31];
+          }
+      }
+    } else {
     {   // stage dO^T and Q^T [d][32 queries]: thread d = tid&63, queries 8*rg .. +7
       const int d = tid & 63, rg = tid >> 6;
       float x[8], y[8];
@@ -943,7 +1004,6 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       *reinterpret_cast<h16x8_t*>(&Qh[d * TS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Ql[d * TS + 8 * rg]) = lo;
     }
     // B operands straight from HBM: P / dS [query slot][key = lane]: 8 consecutive queries per k16 step and lane half
-    float pv[2][8], sv[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -954,6 +1014,7 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
         sv[t][e] = ok ? dSb[(size_t)qq * a.Tk + key] : 0.f;
       }
     __syncthreads();
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       h16x8_t ph, pl, sh, sl;
@@ -1013,7 +1074,10 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
     if (e != hipSuccess) return e;
   }
   vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
-  vnr_launch(attn_bwd_dkv_mfma_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  static const bool narrow = getenv("VNR_ATTN_BWD_NARROW") != nullptr;      // A/B switch: the round-2 access pattern of the dK / dV kernel
+  const bool wide = !narrow && !(Tk & 3) && !(ldq & 3) && !(lddo & 3) && !(((size_t)P | (size_t)dS | (size_t)Q | (size_t)dO) & 15);
+  if (wide) vnr_launch(attn_bwd_dkv_mfma_kernel<true>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  else vnr_launch(attn_bwd_dkv_mfma_kernel<false>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   return hipGetLastError();
 }
 

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Instruction histogram of one kernel in a device assembly file (hipcc -S --cuda-device-only): whole kernel and its innermost loops.
+usage: isa_hist.py file.s mangled-name-substring"""
+import re, sys, collections
+s = open(sys.argv[1]).read()
+m = re.search(r'\n(\S*%s\S*):' % re.escape(sys.argv[2]), s)
+i = m.start(); j = s.index('s_endpgm', i)
+lines = s[i:j].split('\n')
+def hist(a, b):
+    c = collections.Counter()
+    for l in lines[a:b]:
+        t = l.strip(); mm = re.match(r'([a-z_0-9]+)', t)
+        if mm and not t.endswith(':') and not t.startswith('.') and not t.startswith(';'): c[mm.group(1)] += 1
+    return sum(c.values()), ', '.join('%s %d' % kv for kv in c.most_common(40))
+print(m.group(1)); print('whole: %d  %s' % hist(0, len(lines)))
+lab = {}
+for n, l in enumerate(lines):
+    mm = re.match(r'(\.LBB\d+_\d+):', l.strip())
+    if mm: lab[mm.group(1)] = n
+for n, l in enumerate(lines):
+    mm = re.match(r'\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)', l)
+    if mm and mm.group(1) in lab and lab[mm.group(1)] < n:
+        print('loop %s lines %d-%d: %d  %s' % ((mm.group(1), lab[mm.group(1)], n) + hist(lab[mm.group(1)], n)))
+    mm = re.match(r'\s*s_branch\s+(\.LBB\d+_\d+)', l)
+    if mm and mm.group(1) in lab and lab[mm.group(1)] < n:
+        print('loop(b) %s lines %d-%d: %d  %s' % ((mm.group(1), lab[mm.group(1)], n) + hist(lab[mm.group(1)], n)))

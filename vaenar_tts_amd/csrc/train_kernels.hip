@@ -218,11 +218,11 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
 // Same contract as gemm_tn_split_kernel (conv-tap row shift inside an utterance, B pre-scaled by its launch-wide max, float
 // atomics over the row splits).  Needs 16-byte aligned rows (lda, ldb, K, N multiples of 4).
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
-typedef short s16x8_t __attribute__((__vector_size__(8 * sizeof(short))));
+typedef short trs4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short trs8_t __attribute__((__vector_size__(8 * sizeof(short))));
 __device__ __forceinline__ h16x8_t tn3_operand(const char* p) {
-  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 512));   // rows + 4: the next block
+  const trs4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) trs4_t*)(p));
+  const trs4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) trs4_t*)(p + 512));   // rows + 4: the next block
   return __builtin_bit_cast(h16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ void tn3_barrier() {           // LDS traffic of this wave complete, then the workgroup barrier
@@ -636,6 +636,8 @@ struct AttnBwdArgs {
   int B, H, Tq, Tk, causal;
   float scale;                             // 1 / sqrt(64) / tau
   unsigned *amax_dq = nullptr, *amax_dk = nullptr, *amax_dv = nullptr;   // optional: bits of max |dQ|, |dK|, |dV| (atomicMax; zero on entry)
+  int balance = 1;                         // causal launches: XCD- and CU-balanced block order (balanced_block)
+  float* rowdot = nullptr;                 // fused form (dS == nullptr): dO.O per query [B][H][Tq], scaled like dO; kernel A -> kernel B
 };
 // max over the wave of a non-negative value -> one atomicMax on its float bits (unsigned order = float order for x >= 0)
 __device__ __forceinline__ void wave_amax_to(unsigned* dst, float m) {
@@ -781,14 +783,31 @@ __device__ __forceinline__ void scale_from_absmax(const unsigned* amax, int targ
     inv = __uint_as_float((unsigned)(-sft + 127) << 23);
   }
 }
+// Causal attention backward: the work of a 128-row block grows (kernel A) or shrinks (kernel B) with its position, and a launch lasts
+// as long as its busiest CU.  Consecutive workgroup ids go round-robin to the 8 XCDs, so with the block index in blockIdx.x and four
+// blocks per (b, h) every XCD saw ONE block position only (two XCDs all the 13-tile blocks, two all the 1-tile ones).  This map
+// gives every XCD every position, and flips the position between the first and second fill of an XCD's 32 CUs so that a CU holds
+// a long and a short workgroup side by side.  (Bijective for any grid; falls back to the identity when B * H is not a multiple of 8.)
+__device__ __forceinline__ void balanced_block(int nblk, int H, int B, int& blk, int& hd, int& b) {
+  blk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z;
+  const int BH = H * B;
+  if (BH & 7) return;
+  const int n = blockIdx.x + nblk * (blockIdx.y + H * blockIdx.z);
+  const int xcd = n & 7, j = n >> 3, grp = j / nblk, per_fill = nblk >= 32 ? 1 : 32 / nblk;
+  blk = j - grp * nblk;
+  if ((grp / per_fill) & 1) blk = nblk - 1 - blk;
+  const int bh = grp * 8 + xcd;
+  hd = bh % H; b = bh / H;
+}
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   constexpr int VS = 72, KS = 40;                           // LDS row strides in halfs (16-byte aligned, bank-spread)
   __shared__ __attribute__((aligned(16))) _Float16 Vh[32 * VS], Vl[32 * VS];     // V tile  [key][d]
   __shared__ __attribute__((aligned(16))) _Float16 Kh[64 * KS], Kl[64 * KS];     // K tile, transposed [d][key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;         // this lane's query
+  int qblk, hd, b;
+  if (a.causal && a.balance) balanced_block(gridDim.x, a.H, a.B, qblk, hd, b); else { qblk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; }
+  const int q = qblk * 128 + wave * 32 + l31;               // this lane's query
   const bool qin = q < a.Tq;
   const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
   float sc, inv;
@@ -807,7 +826,11 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       split8_t(x, doh[t], dol[t]);
     }
     rowdot += __shfl_xor(rowdot, 32, 64);
+    if (a.rowdot && qin && half == 0) a.rowdot[((size_t)b * a.H + hd) * a.Tq + q] = rowdot;
   }
+  // fused form: dS is not handed to kernel B, so key tiles beyond the causal diagonal (dS = 0 on every row) are not visited at all
+  const int jend = (!a.dS && a.causal) ? min(a.Tk, qblk * 128 + 128) : a.Tk;
+  const int wq_last = qblk * 128 + wave * 32 + 31;           // the wave's last query: its tiles beyond the diagonal are staged only
   f32x16 accq[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -816,7 +839,7 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   const bool vec4 = (a.Tk & 3) == 0;
-  for (int j0 = 0; j0 < a.Tk; j0 += 32) {
+  for (int j0 = 0; j0 < jend; j0 += 32) {
     __syncthreads();
     {   // stage V [key][d] (thread: key = tid>>3, 8 d) and K^T [d][key] (thread: d = tid&63, 8 keys), split once
       const int key = tid >> 3, d8 = (tid & 7) * 8;
@@ -834,7 +857,9 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       *reinterpret_cast<h16x8_t*>(&Kh[d * KS + 8 * rg]) = hi; *reinterpret_cast<h16x8_t*>(&Kl[d * KS + 8 * rg]) = lo;
     }
     // P[q][j0 + frow(r, half)] : four runs of 4 consecutive keys per lane
+    const bool wave_dead = !a.dS && a.causal && j0 > wq_last;      // wave-uniform
     float p[16];
+    if (wave_dead) { __syncthreads(); continue; }
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int kk = j0 + 8 * g4 + 4 * half;
@@ -862,7 +887,7 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
       const bool valid = qin && q < qlen && kk < klen && kk < a.Tk && (!a.causal || kk <= q);
       ds[r] = valid ? p[r] * (dpt[r] - rowdot) : 0.f;
     }
-    if (qin) {
+    if (qin && a.dS) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int kk = j0 + 8 * g4 + 4 * half;
@@ -911,19 +936,49 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
 // four-byte loads per thread and tile (dO^T / Q^T column pieces, P / dS entries of the lane's key) -- at 60-130 clk of issue per
 // vector-memory instruction that was most of a tile's 8 kcyc.  Now dO / Q rows arrive as float4 and are transposed by the LDS stores,
 // the wave's 32 x 32 P and dS tiles arrive as float4 row pieces and are turned into operand order through a padded LDS tile.
-template <bool WIDE>
+// MODE 2 (FUSED; the default when WIDE applies): dS never exists in memory.  Kernel A leaves dO.O per query (a.rowdot) instead of the
+// Tq x Tk tensor, and this kernel rebuilds dS = P (dP - dO.O) from the stored probabilities with one more product per tile,
+// dP[q][key] = dO[q][:] . V[key][:] (V of the lane's key stays in registers; dO additionally staged [query][d]).  The product's
+// result layout (lane <-> key, registers <-> queries frow(r, half)) IS the B-operand layout of the two accumulating products when
+// their reduction index is permuted the same way, so the [d][query] tiles are stored with query bits 2 and 3 swapped and P is
+// picked from the staging tile in that order.  Half the Tq x Tk traffic of the attention backward is gone (no dS write, no dS
+// read), and for causal attention the query tiles in front of the key block (P = 0 on valid rows) are not visited.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
+  constexpr bool WIDE = MODE >= 1, FUSED = MODE == 2;
   constexpr int TS = 40;                                     // [d][32 queries] tiles, row stride in halfs
   constexpr int PS = 36;                                     // WIDE: P / dS staging tile [32 queries][32 keys], row stride in floats
+  constexpr int VS = 72;                                     // FUSED: dO tile [32 queries][d], row stride in halfs
   __shared__ __attribute__((aligned(16))) _Float16 Oh[64 * TS], Ol[64 * TS], Qh[64 * TS], Ql[64 * TS];
-  __shared__ __attribute__((aligned(16))) float Pt[WIDE ? 4 * 2 * 32 * PS : 4];
+  __shared__ __attribute__((aligned(16))) float Pt[WIDE ? 4 * (FUSED ? 1 : 2) * 32 * PS : 4];
+  __shared__ __attribute__((aligned(16))) _Float16 O2h[FUSED ? 32 * VS : 8], O2l[FUSED ? 32 * VS : 8];
+  __shared__ __attribute__((aligned(16))) float rds[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int key = blockIdx.x * 128 + wave * 32 + l31;        // this lane's key
+  int kblk, hd, b;
+  if (FUSED && a.causal && a.balance) balanced_block(gridDim.x, a.H, a.B, kblk, hd, b); else { kblk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; }
+  const int key = kblk * 128 + wave * 32 + l31;              // this lane's key
   const bool kin = key < a.Tk;
   float sc, inv;
   scale_from_absmax(amax, 10, sc, inv);
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  h16x8_t vh[FUSED ? 4 : 1], vl[FUSED ? 4 : 1];              // FUSED: V[key][16 t + 8 half ..], the B operand of dP
+  int q_first = 0;
+  if (FUSED) {
+    const float* vp = a.V + ((size_t)b * a.Tk + (kin ? key : 0)) * a.ldv + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8];
+      const float4 v0 = kin ? *reinterpret_cast<const float4*>(vp + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v1 = kin ? *reinterpret_cast<const float4*>(vp + 16 * t + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+      split8_t(x, vh[t], vl[t]);
+    }
+    // causal: a query tile that lies entirely in front of the key block and entirely inside the valid rows has P = 0 everywhere
+    // (valid rows of a causal attention see key 0 unless k_len = 0; masked logits are -2^32, their probabilities exactly 0)
+    if (a.causal && klen > 0) q_first = (min(min(kblk * 128, qlen), a.Tq) / 32) * 32;
+  }
+  const int wkey0 = kblk * 128 + wave * 32;
   f32x16 accv[2], acck[2];
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -931,10 +986,77 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
     for (int r = 0; r < 16; ++r) { accv[nb][r] = 0.f; acck[nb][r] = 0.f; }
   const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
   const float* dSb = a.dS + (((size_t)b * a.H + hd) * a.Tq) * a.Tk;
-  for (int q0 = 0; q0 < a.Tq; q0 += 32) {
+  for (int q0 = q_first; q0 < a.Tq; q0 += 32) {
     __syncthreads();
     float pv[2][8], sv[2][8];
-    if (WIDE) {
+    if (FUSED) {
+      {   // dO and Q rows: thread query qi = tid>>3, 8 consecutive d -> [d][slot(qi)] tiles (bits 2 and 3 of the query swapped) and dO [query][d]
+        const int qi = tid >> 3, d8 = (tid & 7) * 8, qq = q0 + qi;
+        const int slot = (qi & 0x13) | ((qi & 4) << 1) | ((qi & 8) >> 1);
+        const bool ok = qq < a.Tq;
+        float x[8], y[8];
+        const float* dp = a.dO + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.lddo + hd * 64 + d8;
+        const float* qp = a.Q + ((size_t)b * a.Tq + (ok ? qq : 0)) * a.ldq + hd * 64 + d8;
+        const float4 d0 = ok ? *reinterpret_cast<const float4*>(dp) : make_float4(0.f, 0.f, 0.f, 0.f), d1 = ok ? *reinterpret_cast<const float4*>(dp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g0 = ok ? *reinterpret_cast<const float4*>(qp) : make_float4(0.f, 0.f, 0.f, 0.f), g1 = ok ? *reinterpret_cast<const float4*>(qp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[0] = d0.x * sc; x[1] = d0.y * sc; x[2] = d0.z * sc; x[3] = d0.w * sc; x[4] = d1.x * sc; x[5] = d1.y * sc; x[6] = d1.z * sc; x[7] = d1.w * sc;
+        y[0] = g0.x; y[1] = g0.y; y[2] = g0.z; y[3] = g0.w; y[4] = g1.x; y[5] = g1.y; y[6] = g1.z; y[7] = g1.w;
+        h16x8_t xh, xl, yh, yl;
+        split8_t(x, xh, xl);
+        split8_t(y, yh, yl);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int o = (d8 + e) * TS + slot;
+          Oh[o] = xh[e]; Ol[o] = xl[e]; Qh[o] = yh[e]; Ql[o] = yl[e];
+        }
+        *reinterpret_cast<h16x8_t*>(&O2h[qi * VS + d8]) = xh; *reinterpret_cast<h16x8_t*>(&O2l[qi * VS + d8]) = xl;
+        if (tid < 32) rds[tid] = q0 + tid < a.Tq ? a.rowdot[((size_t)b * a.H + hd) * a.Tq + q0 + tid] : 0.f;
+      }
+      const bool wave_dead = a.causal && klen > 0 && q0 + 31 < wkey0 && q0 + 31 < qlen;      // wave-uniform: P = 0 on this wave's 32 x 32 tile
+      if (!wave_dead) {   // this wave's P tile [32 queries][its 32 keys]: float4 row pieces -> LDS
+        const int c4 = (lane & 7) * 4, kc = wkey0 + c4;
+        float* Pw = Pt + wave * 32 * PS;
+#pragma unroll
+        for (int x4 = 0; x4 < 4; ++x4) {
+          const int row = 8 * x4 + (lane >> 3), qq = q0 + row;
+          float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (qq < a.Tq && kc + 3 < a.Tk) pp = *reinterpret_cast<const float4*>(Pb + (size_t)qq * a.Tk + kc);
+          else if (qq < a.Tq) {
+            const float* pr = Pb + (size_t)qq * a.Tk + kc;
+            if (kc < a.Tk) pp.x = pr[0]; if (kc + 1 < a.Tk) pp.y = pr[1]; if (kc + 2 < a.Tk) pp.z = pr[2];
+          }
+          *reinterpret_cast<float4*>(Pw + row * PS + c4) = pp;
+        }
+      }
+      __syncthreads();
+      if (wave_dead) continue;
+      // dP[q][key] = sum_d dO[q][d] V[key][d]   (A rows = queries from the [query][d] tile, B = the lane's V row)
+      f32x16 dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const h16x8_t oh = *reinterpret_cast<const h16x8_t*>(&O2h[l31 * VS + 16 * t + 8 * half]);
+        const h16x8_t ol = *reinterpret_cast<const h16x8_t*>(&O2l[l31 * VS + 16 * t + 8 * half]);
+        dpt = mfma3_t(oh, ol, vh[t], vl[t], dpt);
+      }
+      {
+        const float* Pw = Pt + wave * 32 * PS;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 rd4 = *reinterpret_cast<const float4*>(&rds[8 * g4 + 4 * half]);
+          const float rdv[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g4 + e, row = 8 * g4 + 4 * half + e, qq = q0 + row;        // row = frow_t(r, half)
+            const float pr = Pw[row * PS + l31];
+            const bool valid = kin && qq < a.Tq && qq < qlen && key < klen && (!a.causal || key <= qq);
+            pv[r >> 3][r & 7] = pr;
+            sv[r >> 3][r & 7] = valid ? pr * (dpt[r] - rdv[e]) : 0.f;
+          }
+        }
+      }
+    } else if (WIDE) {
       {   // dO and Q rows: thread query qi = tid>>3, 8 consecutive d; transposed into the [d][32 queries] tiles by scalar LDS stores
         const int qi = tid >> 3, d8 = (tid & 7) * 8, qq = q0 + qi;
         const bool ok = qq < a.Tq;
@@ -955,7 +1077,7 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
         }
       }
       {   // this wave's P and dS tiles [32 queries][its 32 keys]: float4 row pieces -> LDS
-        const int c4 = (lane & 7) * 4, kc = blockIdx.x * 128 + wave * 32 + c4;
+        const int c4 = (lane & 7) * 4, kc = kblk * 128 + wave * 32 + c4;
         float* Pw = Pt + (wave * 2) * 32 * PS;
         float* Sw = Pw + 32 * PS;
 #pragma unroll
@@ -1051,6 +1173,194 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
   wave_amax_to(a.amax_dv, mxv);
   wave_amax_to(a.amax_dk, mxk);
 }
+// ---- dK / dV kernel, third form (round 3): built for instruction count -------------------------------------------------------------
+// The tile loop of the forms above issues ~600 (dS from HBM) / ~900 (dS rebuilt) instructions per wave and 32-query tile around 24 / 36
+// MFMAs: 32 two-byte LDS stores per thread to transpose dO and Q, a chain of branches around every guarded load, the validity mask
+// evaluated per element on every tile, 64 accumulator registers copied between the two register files at both ends of the loop.
+// With 2-3 waves per SIMD that instruction stream, not HBM, sets the 8 - 12 us a tile takes.  This form
+//   * stages dO and Q row-major ([query][d], fp16 hi / lo, four 16-byte LDS stores per thread) and lets the LDS transpose-read
+//     (ds_read_b64_tr_b16: a 16-lane group fetches a [4 queries][16 d] block, lane c receives column c) deliver the [d][query]
+//     operands of the two accumulating products; the same tiles, read along rows, are the A operand of dP = dO.V^T;
+//   * loads with clamped addresses and selects instead of branches, and prefetches the next tile into registers behind the barrier;
+//   * double-buffers the LDS tiles (one barrier per tile);
+//   * evaluates the validity mask only on tiles that touch the causal diagonal, the length limits or the tensor edge.
+// Requires Tk % 4 == 0 and 16-byte aligned rows (as WIDE).  dS never exists in memory (as MODE 2).
+__device__ __forceinline__ h16x8_t lds_tr8(const _Float16* p0, const _Float16* p1) {
+  typedef __attribute__((address_space(3))) trs4_t* lp_t;
+  const trs4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p0);
+  const trs4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)p1);
+  typedef short trs8_t __attribute__((ext_vector_type(8)));
+  const trs8_t c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(h16x8_t, c);
+}
+__device__ __forceinline__ void split8_m(const float* x, h16x8_t& hi, h16x8_t& lo) {      // lo through one mixed-precision fma per value
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)__builtin_fmaf((float)h, -1.f, x[e]); }
+}
+__global__ void __launch_bounds__(256, 2)
+attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
+  constexpr int VS = 72;                                     // dO / Q tiles [32 queries][d], row stride in halfs
+  constexpr int PS = 36;                                     // P staging tile [32 queries][32 keys] per wave, row stride in floats
+  __shared__ __attribute__((aligned(16))) _Float16 Th[2][4][32 * VS];          // [buffer][dO hi, dO lo, Q hi, Q lo]
+  __shared__ __attribute__((aligned(16))) float Pt[2][4][32 * PS];            // [buffer][wave]
+  __shared__ __attribute__((aligned(16))) float rds[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  int kblk, hd, b;
+  if (a.causal && a.balance) balanced_block(gridDim.x, a.H, a.B, kblk, hd, b); else { kblk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; }
+  const int wkey0 = kblk * 128 + wave * 32, key = wkey0 + l31;           // this lane's key
+  const bool kin = key < a.Tk;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  const int qmax = min(qlen, a.Tq);
+  const bool key_ok = kin && key < klen;
+  h16x8_t vh[4], vl[4];                                      // V[key][16 t + 8 half ..]: the B operand of dP
+  {
+    const float* vp = a.V + ((size_t)b * a.Tk + (kin ? key : 0)) * a.ldv + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(vp + 16 * t), v1 = *reinterpret_cast<const float4*>(vp + 16 * t + 4);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = kin ? x[e] : 0.f;
+      split8_m(x, vh[t], vl[t]);
+    }
+  }
+  // causal: a query tile entirely in front of the key block and entirely inside the valid rows has P = 0 everywhere
+  // (valid rows of a causal attention see key 0 unless k_len = 0; masked logits are -2^32, their probabilities exactly 0)
+  const bool skip_ok = a.causal && klen > 0;
+  const int q_first = skip_ok ? (min(min(kblk * 128, qlen), a.Tq) / 32) * 32 : 0;
+  f32x16 accv[2], acck[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accv[nb][r] = 0.f; acck[nb][r] = 0.f; }
+  // staging roles: dO / Q row qi, 8 consecutive d;  P rows 8 x4 + (lane >> 3), 4 consecutive keys of the wave's 32
+  const int qi = tid >> 3, d8 = (tid & 7) * 8;
+  const float* dOb = a.dO + (size_t)b * a.Tq * a.lddo + hd * 64 + d8;
+  const float* Qb = a.Q + (size_t)b * a.Tq * a.ldq + hd * 64 + d8;
+  const float* rdb = a.rowdot + ((size_t)b * a.H + hd) * a.Tq;
+  const int prow = lane >> 3, c4 = (lane & 7) * 4, kc = wkey0 + c4;
+  const bool kc_in = kc < a.Tk;                              // (Tk % 4 == 0: the whole 4-key piece is inside or outside)
+  const float* Pb = a.P + (((size_t)b * a.H + hd) * a.Tq) * a.Tk + (kc_in ? kc : 0);
+  // operand addresses inside a buffer (halfs): rows of dO for dP; transposed 4 x 16 blocks of dO / Q for the accumulating products
+  const int oA = l31 * VS + 8 * half;
+  const int oT = (4 * half + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 rO0, rO1, rQ0, rQ1, rP[4];
+  float rrd = 0.f;
+  auto wave_dead = [&](int q0) { return skip_ok && q0 + 31 < wkey0 && q0 + 31 < qlen; };      // wave-uniform: P = 0 on its 32 x 32 tile
+  auto fetch = [&](int q0) {
+    const int qq = min(q0 + qi, a.Tq - 1);
+    const float* dp = dOb + (size_t)qq * a.lddo;
+    const float* qp = Qb + (size_t)qq * a.ldq;
+    rO0 = *reinterpret_cast<const float4*>(dp); rO1 = *reinterpret_cast<const float4*>(dp + 4);
+    rQ0 = *reinterpret_cast<const float4*>(qp); rQ1 = *reinterpret_cast<const float4*>(qp + 4);
+    if (tid < 32) rrd = rdb[min(q0 + tid, a.Tq - 1)];
+    if (!wave_dead(q0)) {
+#pragma unroll
+      for (int x4 = 0; x4 < 4; ++x4) rP[x4] = *reinterpret_cast<const float4*>(Pb + (size_t)min(q0 + 8 * x4 + prow, a.Tq - 1) * a.Tk);
+    }
+  };
+  fetch(q_first);
+  int buf = 0;
+  for (int q0 = q_first; q0 < a.Tq; q0 += 32, buf ^= 1) {
+    const bool dead = wave_dead(q0);
+    {   // registers -> LDS tiles of this buffer
+      float x[8], y[8];
+      x[0] = rO0.x * sc; x[1] = rO0.y * sc; x[2] = rO0.z * sc; x[3] = rO0.w * sc; x[4] = rO1.x * sc; x[5] = rO1.y * sc; x[6] = rO1.z * sc; x[7] = rO1.w * sc;
+      y[0] = rQ0.x; y[1] = rQ0.y; y[2] = rQ0.z; y[3] = rQ0.w; y[4] = rQ1.x; y[5] = rQ1.y; y[6] = rQ1.z; y[7] = rQ1.w;
+      h16x8_t xh, xl, yh, yl;
+      split8_m(x, xh, xl);
+      split8_m(y, yh, yl);
+      const int o = qi * VS + d8;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][0][o]) = xh; *reinterpret_cast<h16x8_t*>(&Th[buf][1][o]) = xl;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][2][o]) = yh; *reinterpret_cast<h16x8_t*>(&Th[buf][3][o]) = yl;
+      if (tid < 32) rds[buf][tid] = rrd;
+      if (!dead) {
+        float* Pw = Pt[buf][wave];
+#pragma unroll
+        for (int x4 = 0; x4 < 4; ++x4) {
+          const bool ok = kc_in && q0 + 8 * x4 + prow < a.Tq;
+          const float4 pp = ok ? rP[x4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(Pw + (8 * x4 + prow) * PS + c4) = pp;
+        }
+      }
+    }
+    __syncthreads();
+    if (q0 + 32 < a.Tq) fetch(q0 + 32);                       // next tile: in flight behind this tile's products
+    if (dead) continue;
+    const _Float16* Oh = Th[buf][0]; const _Float16* Ol = Th[buf][1]; const _Float16* Qh = Th[buf][2]; const _Float16* Ql = Th[buf][3];
+    // dP[q][key] = sum_d dO[q][d] V[key][d]
+    f32x16 dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const h16x8_t oh = *reinterpret_cast<const h16x8_t*>(&Oh[oA + 16 * t]);
+      const h16x8_t ol = *reinterpret_cast<const h16x8_t*>(&Ol[oA + 16 * t]);
+      dpt = mfma3_t(oh, ol, vh[t], vl[t], dpt);
+    }
+    float pv[16], sv[16];                                    // register r <-> query q0 + frow_t(r, half), the lane's key
+    {
+      const float* Pw = Pt[buf][wave];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 rd4 = *reinterpret_cast<const float4*>(&rds[buf][8 * g4 + 4 * half]);
+        const float rdv[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pr = Pw[(8 * g4 + 4 * half + e) * PS + l31];
+          pv[4 * g4 + e] = pr;
+          sv[4 * g4 + e] = pr * (dpt[4 * g4 + e] - rdv[e]);
+        }
+      }
+    }
+    const bool full = q0 + 31 < qmax && wkey0 + 31 < min(a.Tk, klen) && (!a.causal || wkey0 + 31 <= q0);      // wave-uniform
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + frow_t(r, half);
+        const bool valid = key_ok && qq < qmax && (!a.causal || key <= qq);
+        sv[r] = valid ? sv[r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      h16x8_t ph, pl, sh, sl;
+      split8_m(&pv[8 * t], ph, pl);
+      split8_m(&sv[8 * t], sh, sl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int o0 = oT + (16 * t) * VS + 32 * nb, o1 = o0 + 8 * VS;
+        const h16x8_t oh = lds_tr8(&Oh[o0], &Oh[o1]), ol = lds_tr8(&Ol[o0], &Ol[o1]);
+        const h16x8_t qh = lds_tr8(&Qh[o0], &Qh[o1]), ql = lds_tr8(&Ql[o0], &Ql[o1]);
+        accv[nb] = mfma3_t(oh, ol, ph, pl, accv[nb]);        // dV^T[d][key] += dO[q][d] P[q][key]
+        acck[nb] = mfma3_t(qh, ql, sh, sl, acck[nb]);        // dK^T[d][key] += Q[q][d] dS[q][key]
+      }
+    }
+  }
+  float mxv = 0.f, mxk = 0.f;
+  if (kin) {
+    float* pvd = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64;
+    float* pkd = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64;
+    const float fk = a.scale * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = 32 * nb + 8 * g4 + 4 * half;
+        const float4 v4 = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
+        const float4 k4 = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
+        *reinterpret_cast<float4*>(pvd + d) = v4;
+        *reinterpret_cast<float4*>(pkd + d) = k4;
+        mxv = fmaxf(mxv, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
+        mxk = fmaxf(mxk, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
+      }
+  }
+  wave_amax_to(a.amax_dv, mxv);
+  wave_amax_to(a.amax_dk, mxk);
+}
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
@@ -1073,11 +1383,19 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
     const hipError_t e = launch_absmax2d(dO, lddo, B * Tq, H * 64, amax_slot, s);      // *amax_slot must be zero on entry
     if (e != hipSuccess) return e;
   }
-  vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   static const bool narrow = getenv("VNR_ATTN_BWD_NARROW") != nullptr;      // A/B switch: the round-2 access pattern of the dK / dV kernel
+  static const bool ds_hbm = getenv("VNR_ATTN_BWD_DS_HBM") != nullptr;      // A/B switch: dS handed from kernel A to kernel B through HBM
   const bool wide = !narrow && !(Tk & 3) && !(ldq & 3) && !(lddo & 3) && !(((size_t)P | (size_t)dS | (size_t)Q | (size_t)dO) & 15);
-  if (wide) vnr_launch(attn_bwd_dkv_mfma_kernel<true>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
-  else vnr_launch(attn_bwd_dkv_mfma_kernel<false>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  const bool fused = wide && !ds_hbm && !(ldv & 3) && !((size_t)V & 15) && (size_t)Tk >= 1;
+  static const bool no_balance = getenv("VNR_ATTN_BWD_NO_BALANCE") != nullptr;   // A/B switch: blockIdx order as launched
+  a.balance = no_balance ? 0 : 1;
+  if (fused) { a.rowdot = dS; a.dS = nullptr; }      // the head of the dS workspace carries dO.O ([B][H][Tq] <= [B][H][Tq][Tk])
+  vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  static const bool dkv2 = getenv("VNR_ATTN_BWD_DKV2") != nullptr;         // A/B switch: the first fused form
+  if (fused && !dkv2) vnr_launch(attn_bwd_dkv3_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  else if (fused) vnr_launch(attn_bwd_dkv_mfma_kernel<2>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  else if (wide) vnr_launch(attn_bwd_dkv_mfma_kernel<1>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  else vnr_launch(attn_bwd_dkv_mfma_kernel<0>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   return hipGetLastError();
 }
 

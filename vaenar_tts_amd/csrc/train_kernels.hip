@@ -1361,6 +1361,141 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
   wave_amax_to(a.amax_dv, mxv);
   wave_amax_to(a.amax_dk, mxk);
 }
+// ---- dQ kernel, third form (round 3): the same treatment -- K and V staged row-major ([key][d], four 16-byte LDS stores per thread instead of
+// eight 4-byte K^T loads), K^T operands by LDS transpose reads, clamped loads, the next tile prefetched into registers, double-buffered
+// tiles, masks on edge tiles only.  dS is not written (the dK / dV kernel rebuilds it); dO.O per query goes to a.rowdot.
+__global__ void __launch_bounds__(256, 2)
+attn_bwd_dq3_kernel(const AttnBwdArgs a, const unsigned* amax) {
+  constexpr int VS = 72;                                     // K / V tiles [32 keys][d], row stride in halfs
+  __shared__ __attribute__((aligned(16))) _Float16 Th[2][4][32 * VS];          // [buffer][V hi, V lo, K hi, K lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  int qblk, hd, b;
+  if (a.causal && a.balance) balanced_block(gridDim.x, a.H, a.B, qblk, hd, b); else { qblk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; }
+  const int wq0 = qblk * 128 + wave * 32, q = wq0 + l31;     // this lane's query
+  const bool qin = q < a.Tq;
+  const int qlen = a.q_len ? a.q_len[b] : a.Tq, klen = a.k_len ? a.k_len[b] : a.Tk;
+  const int kmax = min(klen, a.Tk);
+  const bool q_ok = qin && q < qlen;
+  float sc, inv;
+  scale_from_absmax(amax, 10, sc, inv);
+  h16x8_t doh[4], dol[4];                                    // dO[q][16 t + 8 half ..] (B operand of dP^T = V.dO^T)
+  float rowdot = 0.f;
+  {
+    const float* dp = a.dO + ((size_t)b * a.Tq + (qin ? q : 0)) * a.lddo + hd * 64 + 8 * half;
+    const float* op = a.O + ((size_t)b * a.Tq + (qin ? q : 0)) * a.ldo + hd * 64 + 8 * half;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = qin ? dp[16 * t + e] * sc : 0.f; rowdot += qin ? x[e] * op[16 * t + e] : 0.f; }
+      split8_m(x, doh[t], dol[t]);
+    }
+    rowdot += __shfl_xor(rowdot, 32, 64);
+    if (qin && half == 0) a.rowdot[((size_t)b * a.H + hd) * a.Tq + q] = rowdot;
+  }
+  f32x16 accq[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accq[nb][r] = 0.f;
+  const int jend = a.causal ? min(a.Tk, qblk * 128 + 128) : a.Tk;      // key tiles beyond the causal diagonal: dS = 0 on every row
+  const int wq_last = wq0 + 31;
+  const int ki = tid >> 3, d8 = (tid & 7) * 8;                // staging role: key row ki of the tile, 8 consecutive d
+  const float* Kb = a.K + (size_t)b * a.Tk * a.ldk + hd * 64 + d8;
+  const float* Vb = a.V + (size_t)b * a.Tk * a.ldv + hd * 64 + d8;
+  const float* Pq = a.P + (((size_t)b * a.H + hd) * a.Tq + (qin ? q : 0)) * a.Tk;
+  const int oA = l31 * VS + 8 * half;
+  const int oT = (4 * half + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  float4 rK0, rK1, rV0, rV1, rP[4];
+  auto wave_dead = [&](int j0) { return a.causal && j0 > wq_last; };
+  auto fetch = [&](int j0) {
+    const int kk = min(j0 + ki, a.Tk - 1);
+    const float* kp = Kb + (size_t)kk * a.ldk;
+    const float* vp = Vb + (size_t)kk * a.ldv;
+    rK0 = *reinterpret_cast<const float4*>(kp); rK1 = *reinterpret_cast<const float4*>(kp + 4);
+    rV0 = *reinterpret_cast<const float4*>(vp); rV1 = *reinterpret_cast<const float4*>(vp + 4);
+    if (!wave_dead(j0)) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) rP[g4] = *reinterpret_cast<const float4*>(Pq + min(j0 + 8 * g4 + 4 * half, a.Tk - 4));
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int j0 = 0; j0 < jend; j0 += 32, buf ^= 1) {
+    const bool dead = wave_dead(j0);
+    {
+      float x[8], y[8];
+      x[0] = rV0.x; x[1] = rV0.y; x[2] = rV0.z; x[3] = rV0.w; x[4] = rV1.x; x[5] = rV1.y; x[6] = rV1.z; x[7] = rV1.w;
+      y[0] = rK0.x; y[1] = rK0.y; y[2] = rK0.z; y[3] = rK0.w; y[4] = rK1.x; y[5] = rK1.y; y[6] = rK1.z; y[7] = rK1.w;
+      h16x8_t xh, xl, yh, yl;
+      split8_m(x, xh, xl);
+      split8_m(y, yh, yl);
+      const int o = ki * VS + d8;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][0][o]) = xh; *reinterpret_cast<h16x8_t*>(&Th[buf][1][o]) = xl;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][2][o]) = yh; *reinterpret_cast<h16x8_t*>(&Th[buf][3][o]) = yl;
+    }
+    float p[16];
+    if (!dead) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const bool ok = qin && j0 + 8 * g4 + 4 * half < a.Tk;        // (Tk % 4 == 0: the 4-key piece is inside or outside)
+        p[4 * g4] = ok ? rP[g4].x : 0.f; p[4 * g4 + 1] = ok ? rP[g4].y : 0.f; p[4 * g4 + 2] = ok ? rP[g4].z : 0.f; p[4 * g4 + 3] = ok ? rP[g4].w : 0.f;
+      }
+    }
+    __syncthreads();
+    if (j0 + 32 < jend) fetch(j0 + 32);
+    if (dead) continue;
+    const _Float16* Vh = Th[buf][0]; const _Float16* Vl = Th[buf][1]; const _Float16* Kh = Th[buf][2]; const _Float16* Kl = Th[buf][3];
+    // dP^T[key][q] = sum_d V[key][d] dO[q][d]
+    f32x16 dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const h16x8_t vh = *reinterpret_cast<const h16x8_t*>(&Vh[oA + 16 * t]);
+      const h16x8_t vl = *reinterpret_cast<const h16x8_t*>(&Vl[oA + 16 * t]);
+      dpt = mfma3_t(vh, vl, doh[t], dol[t], dpt);
+    }
+    float ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dpt[r] - rowdot);
+    const bool full = wq_last < min(qlen, a.Tq) && j0 + 31 < kmax && (!a.causal || j0 + 31 <= wq0);          // wave-uniform
+    if (!full) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = j0 + frow_t(r, half);
+        const bool valid = q_ok && kk < kmax && (!a.causal || kk <= q);
+        ds[r] = valid ? ds[r] : 0.f;
+      }
+    }
+    // dQ^T[d][q] += sum_key K[key][d] dS[q][key]   (k-slot (t', half, e) carries key frow(8 t' + e, half): dS registers as they are)
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp) {
+      h16x8_t dsh, dsl;
+      split8_m(&ds[8 * tp], dsh, dsl);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int o0 = oT + (16 * tp) * VS + 32 * nb, o1 = o0 + 8 * VS;
+        const h16x8_t kh = lds_tr8(&Kh[o0], &Kh[o1]), kl = lds_tr8(&Kl[o0], &Kl[o1]);
+        accq[nb] = mfma3_t(kh, kl, dsh, dsl, accq[nb]);
+      }
+    }
+  }
+  float mxq = 0.f;
+  if (qin) {
+    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
+    const float f = a.scale * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 o4 = make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
+        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) = o4;
+        mxq = fmaxf(mxq, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
+      }
+  }
+  wave_amax_to(a.amax_dq, mxq);
+}
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
                                 float* dV, int lddv, const int32_t* q_len, const int32_t* k_len, int B, int H, int Tq, int Tk,
@@ -1390,7 +1525,9 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
   static const bool no_balance = getenv("VNR_ATTN_BWD_NO_BALANCE") != nullptr;   // A/B switch: blockIdx order as launched
   a.balance = no_balance ? 0 : 1;
   if (fused) { a.rowdot = dS; a.dS = nullptr; }      // the head of the dS workspace carries dO.O ([B][H][Tq] <= [B][H][Tq][Tk])
-  vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  static const bool dq2 = getenv("VNR_ATTN_BWD_DQ2") != nullptr;           // A/B switch: the second-generation dQ kernel
+  if (fused && !dq2 && !(ldk & 3) && !(((size_t)K) & 15)) vnr_launch(attn_bwd_dq3_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  else vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   static const bool dkv2 = getenv("VNR_ATTN_BWD_DKV2") != nullptr;         // A/B switch: the first fused form
   if (fused && !dkv2) vnr_launch(attn_bwd_dkv3_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   else if (fused) vnr_launch(attn_bwd_dkv_mfma_kernel<2>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);

@@ -343,6 +343,8 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
 // training step: backward / optimizer kernels (train_kernels.hip)
 hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift, hipStream_t s);
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
+struct WordList { const unsigned* p[64]; int n; };
+hipError_t launch_max_words(const WordList& w, unsigned* out, hipStream_t s);      // *out = max(*out, max_i *w.p[i])
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                                  int shift, const unsigned* b_absmax, hipStream_t s);
 // recomputing ("flash-style") backward: no stored probabilities, no dS in HBM -- P is rebuilt from Q, K and the row statistics
@@ -390,7 +392,8 @@ hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
 struct TransposeJobHost { const float* in; float* out; int rows, cols; };      // same layout as the device-side job record
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);
-struct SplitJobHost { const float* src; int rows, cols; char* dst; };            // same layout as the device-side job record
+struct SplitJobHost { const float* src; int rows, cols; char* dst; int dst_kt = 0; };   // same layout as the device-side job record (dst_kt: k-tiles per row of the
+                                                                                       // destination image when the job fills a column band of a wider one; 0 = its own)
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);
 // ---- backward row-panel chains of a CrossAttentionBLK (gemm3b.hip; training step) ---------------------------------------------------
 // Every matrix is fp32 row-major with 256 columns unless a leading dimension is given; `*r` are operand-major split images (scale 256)

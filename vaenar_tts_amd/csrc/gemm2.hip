@@ -840,6 +840,14 @@ hipError_t launch_gemm(const GemmArgs& g, hipStream_t s) {
   if ((g.K & 3) || (g.K1 & 3) || (g.lda1 & 3) || (g.A2 && (g.lda2 & 3)) || (g.ldw & 3)) return hipErrorInvalidValue;
   if (g.taps > 0 && ((g.conv_C & 3) || g.K != g.taps * g.conv_C)) return hipErrorInvalidValue;
   if (!gemm2_supported(g)) return hipErrorInvalidValue;
+  static const char* log_path = getenv("VNR_GEMM_LOG");           // measurement only: one line per launch (shape and variant)
+  if (log_path) {
+    if (FILE* f = fopen(log_path, "a")) {
+      fprintf(f, "M %d N %d K %d taps %d split %d a_split %d c_split %d grad %d act %d ln %d res %d A2 %d\n", g.M, g.N, g.K, g.taps, g.Wsplit ? 1 : 0, g.a_split,
+              g.c_split, g.a_absmax ? 1 : 0, g.act, g.ln_gamma ? 1 : 0, g.residual ? 1 : 0, g.A2 ? 1 : 0);
+      fclose(f);
+    }
+  }
   return launch_gemm2(g, s);
 }
 

@@ -2579,7 +2579,7 @@ hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_
 }
 
 // ---- batched split-fp16 image build (same image as misc.hip:split_weights_kernel) for a table of panels ---------------------
-struct SplitJob { const float* src; int rows, cols; char* dst; };
+struct SplitJob { const float* src; int rows, cols; char* dst; int dst_kt; };
 __global__ void __launch_bounds__(256)
 split_batch_kernel(const SplitJob* jobs, float scale) {
   const SplitJob j = jobs[blockIdx.y];
@@ -2594,9 +2594,21 @@ split_batch_kernel(const SplitJob* jobs, float scale) {
     const int k = kt * 32 + p;
     const float w = k < j.cols ? j.src[r * j.cols + k] * scale : 0.f;
     const _Float16 hi = (_Float16)w;
-    out[nk * 64 + p] = hi;
-    out[nk * 64 + 32 + p] = (_Float16)(w - (float)hi);
+    const size_t o = (j.dst_kt ? r * (size_t)j.dst_kt + kt : nk) * 64;
+    out[o + p] = hi;
+    out[o + 32 + p] = (_Float16)(w - (float)hi);
   }
+}
+__global__ void max_words_kernel(const WordList w, unsigned* out) {
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < w.n; i += 64) m = max(m, *w.p[i]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if (threadIdx.x == 0 && m > *out) *out = m;
+}
+hipError_t launch_max_words(const WordList& w, unsigned* out, hipStream_t s) {
+  vnr_launch(max_words_kernel, dim3(1), dim3(64), 0, s, w, out);
+  return hipGetLastError();
 }
 // ---- batched operand-major image build (same image as misc.hip:opmajor_weights_kernel) for a table of transposed kernels [N][K]:
 //      the weight operands of the chain kernel (gemm3.hip) for the training step's forward pass, rebuilt after every update --------

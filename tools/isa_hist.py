@@ -17,10 +17,12 @@ lab = {}
 for n, l in enumerate(lines):
     mm = re.match(r'(\.LBB\d+_\d+):', l.strip())
     if mm: lab[mm.group(1)] = n
+loops = set()
 for n, l in enumerate(lines):
-    mm = re.match(r'\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)', l)
-    if mm and mm.group(1) in lab and lab[mm.group(1)] < n:
-        print('loop %s lines %d-%d: %d  %s' % ((mm.group(1), lab[mm.group(1)], n) + hist(lab[mm.group(1)], n)))
-    mm = re.match(r'\s*s_branch\s+(\.LBB\d+_\d+)', l)
-    if mm and mm.group(1) in lab and lab[mm.group(1)] < n:
-        print('loop(b) %s lines %d-%d: %d  %s' % ((mm.group(1), lab[mm.group(1)], n) + hist(lab[mm.group(1)], n)))
+    mm = re.match(r'\s*s_c?branch\w*\s+(\.LBB\d+_\d+)', l)
+    if mm and mm.group(1) in lab and lab[mm.group(1)] < n: loops.add((lab[mm.group(1)], n))
+# innermost loops only (no other loop strictly inside), largest bodies first
+inner = [lp for lp in loops if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in loops)]
+for a, b in sorted(inner, key=lambda x: x[0] - x[1])[:int(sys.argv[3]) if len(sys.argv) > 3 else 8]:
+    if b - a < 40: continue
+    print('innermost loop lines %d-%d: %d  %s' % ((a, b) + hist(a, b)))

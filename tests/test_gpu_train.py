@@ -18,6 +18,9 @@ def _case(name):
     if name == "tiny-long":      # T_z = 550 latent frames: probabilities beyond 512 keys (two-pass form), 18 query tiles
         b = make_batch(2, 23, 1100, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
                        ragged=True, text_step=5, mel_step=211)
+    elif name == "tiny-mid":     # T_z = 132, T_text = 12 (multiples of 4: the third-form attention backward on self- AND cross-attention; five
+        b = make_batch(2, 12, 264, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,   # query tiles, so the
+                       ragged=True, text_step=3, mel_step=62)                                                           # two-query-group dK / dV form runs)
     elif name == "tiny":
         b = make_batch(3, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
                        ragged=True, text_step=3, mel_step=7)
@@ -37,7 +40,7 @@ def _rel_err(a, b):
 
 
 @pytest.mark.parametrize("name,kw,recompute,chain", [("tiny", 1.0, 0, 1), ("tiny", 1e-5, 0, 1), ("lj", 1.0, 0, 1), ("tiny", 1.0, 1, 1), ("lj", 1.0, 1, 1),
-                                                        ("tiny-long", 1.0, 0, 1), ("tiny-long", 1.0, 1, 1),
+                                                        ("tiny-long", 1.0, 0, 1), ("tiny-long", 1.0, 1, 1), ("tiny-mid", 1.0, 0, 1),
                                                         ("lj", 1.0, 0, 0), ("lj", 1.0, 0, 2), ("lj", 1e-5, 0, 3), ("lj", 1.0, 0, 11), ("lj", 1e-5, 0, 12)])
 def test_gradients_match_autograd(name, kw, recompute, chain):
     """kl_weight = 1 makes the flow / posterior-entropy terms as visible as the L2 terms (the schedule value 1e-5 of

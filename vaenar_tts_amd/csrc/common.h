@@ -343,6 +343,16 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
 // training step: backward / optimizer kernels (train_kernels.hip)
 hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift, hipStream_t s);
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
+#if defined(__HIPCC__)
+// Publish a candidate maximum (bits of a non-negative float; the word is zero on entry and only grows).  Same-address atomics serialise at
+// ~15-20 ns each: one per wave was 1024-4096 per attention-backward launch, 6-25 us of a 40-90 us kernel (profiles/r03_experiments.txt).
+// A device-scope look at the word first keeps all but the first few candidates of a launch away from the atomic unit (a stale value only
+// costs an unnecessary atomic).
+__device__ __forceinline__ void amax_publish(unsigned* dst, float m) {
+  const unsigned bits = __float_as_uint(m);
+  if (m > 0.f && bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+}
+#endif
 struct WordList { const unsigned* p[64]; int n; };
 hipError_t launch_max_words(const WordList& w, unsigned* out, hipStream_t s);      // *out = max(*out, max_i *w.p[i])
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,

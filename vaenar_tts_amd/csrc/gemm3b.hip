@@ -388,7 +388,7 @@ bwd_chain_kernel(const BwdChainArgs g) {
 #pragma unroll
       for (int w = 0; w < 8; ++w) m = fmaxf(m, scr[w * 8 + tid]);
       unsigned* dst = tid == 0 ? g.amaxA : tid == 1 ? g.amax_dh : tid == 2 ? g.amaxB : tid == 3 ? g.amax_out1 : g.amax_out0;
-      if (dst && m > 0.f) atomicMax(dst, __float_as_uint(m));
+      if (dst) amax_publish(dst, m);
     }
   }
 }

@@ -263,10 +263,13 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned* _
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) amax_publish(out, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 hipError_t launch_absmax(const float* x, size_t n, unsigned* out, hipStream_t s) {
-  const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  const unsigned blocks = (unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256);
   vnr_launch(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n, out);
   return hipGetLastError();
 }
@@ -513,11 +516,13 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
   }
   __shared__ double part[4][64];
   part[rg][threadIdx.x & 63] = acc;
-  if (amax) {                                            // by-product: max |x| of the block (scale of the split-fp16 gradient GEMM)
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+  __shared__ float wmx[4];
+  if (amax) {                                            // by-product: max |x| of the block (scale of the split-fp16 gradient GEMM),
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));      // one candidate per workgroup (same-address atomics serialise)
+    if ((threadIdx.x & 63) == 0) wmx[rg] = mx;
   }
   __syncthreads();
+  if (amax && threadIdx.x == 0) amax_publish(amax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
   if (rg == 0 && c < C) {
     const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
     if (fout) atomicAdd(&fout[c], (float)t);             // straight into a float32 gradient (<= 128 block partials per column)
@@ -580,11 +585,13 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
   __shared__ double part[4][256];
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[rg][(threadIdx.x & 63) * 4 + e] = acc[e];
+  __shared__ float wmx[4];
   if (amax) {
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0) wmx[rg] = mx;
   }
   __syncthreads();
+  if (amax && threadIdx.x == 0) amax_publish(amax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
   const int cc = blockIdx.x * 256 + threadIdx.x;
   if (cc < C) {
     const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];

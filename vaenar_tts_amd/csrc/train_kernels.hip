@@ -504,7 +504,7 @@ __device__ __forceinline__ void amax_finish(float m, unsigned* out) {
   __syncthreads();
   if (t == 0) {
     const float r = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    if (r > 0.f) atomicMax(out, __float_as_uint(r));
+    amax_publish(out, r);
   }
 }
 __global__ void __launch_bounds__(256) absmax_flat_kernel(const float* x, size_t n4, size_t n, unsigned* out) {
@@ -541,11 +541,11 @@ hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned*
   if (rows <= 0 || cols <= 0) return hipSuccess;
   if ((ld == cols || rows == 1) && !((size_t)x & 15)) {   // contiguous block
     const size_t n = (size_t)rows * cols, n4 = n / 4;
-    size_t blocks = (n4 + 1023) / 1024; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    size_t blocks = (n4 + 1023) / 1024; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;      // (one atomic per workgroup: few of them)
     vnr_launch(absmax_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n4, n, out);
     return hipGetLastError();
   }
-  int blocks = (rows + 3) / 4; if (blocks > 2048) blocks = 2048;
+  int blocks = (rows + 3) / 4; if (blocks > 512) blocks = 512;
   vnr_launch(absmax2d_kernel, dim3(blocks), dim3(64, 4), 0, s, x, ld, rows, cols, out);
   return hipGetLastError();
 }
@@ -588,7 +588,7 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   // co-resident workgroups hiding each other's barrier per 32-row tile, not on operand reuse
   static const int force = getenv("VNR_GEMM_TN_TILE") ? atoi(getenv("VNR_GEMM_TN_TILE")) : 0;
   static const bool no3 = getenv("VNR_GEMM_TN_V2") != nullptr;      // A/B switch: the second-generation kernel everywhere
-  static const int target3 = getenv("VNR_GEMM_TN3_WGS") ? atoi(getenv("VNR_GEMM_TN3_WGS")) : 192;   // measurement knob
+  static const int target3 = getenv("VNR_GEMM_TN3_WGS") ? atoi(getenv("VNR_GEMM_TN3_WGS")) : 128;   // measurement knob (128 against 192: T1 step 22.50 -> 22.37 ms at rf 2, 16.8 -> 16.1 at rf 5: longer row ranges amortise the 8 kcyc prologue)
   if (!no3 && K >= 128 && N >= 128 && !(lda & 3) && !(ldb & 3) && !(K & 3) && !(N & 3) && !((size_t)A & 15) && !((size_t)B & 15) && M >= 256) {
     const int tk = (K + 127) / 128, tn = (N + 127) / 128;
     int splits = target3 / (tk * tn); if (splits < 1) splits = 1;
@@ -639,12 +639,23 @@ struct AttnBwdArgs {
   int balance = 1;                         // causal launches: XCD- and CU-balanced block order (balanced_block)
   float* rowdot = nullptr;                 // fused form (dS == nullptr): dO.O per query [B][H][Tq], scaled like dO; kernel A -> kernel B
 };
-// max over the wave of a non-negative value -> one atomicMax on its float bits (unsigned order = float order for x >= 0)
-__device__ __forceinline__ void wave_amax_to(unsigned* dst, float m) {
-  if (!dst) return;
+// max of a non-negative value -> atomicMax on its float bits (unsigned order = float order for x >= 0) ...
+// ... and one candidate per WORKGROUP: the waves' maxima meet in LDS first (contains a barrier: every live thread of the block calls it;
+// nwaves = the waves that are still alive).  Same-address atomics serialise; a 512-workgroup launch with one atomic per wave and word
+// spent 10-25 us in them.
+__device__ __forceinline__ void block_amax_to(unsigned* dst0, float m0, unsigned* dst1, float m1, int nwaves) {
+  __shared__ float wm[2][16];
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dst, __float_as_uint(m));
+  for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o, 64)); m1 = fmaxf(m1, __shfl_xor(m1, o, 64)); }
+  const int wave = (threadIdx.x >> 6) & 15;
+  if ((threadIdx.x & 63) == 0) { wm[0][wave] = m0; wm[1][wave] = m1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned* dst = threadIdx.x == 0 ? dst0 : dst1;
+    float r = 0.f;
+    for (int i = 0; i < nwaves; ++i) r = fmaxf(r, wm[threadIdx.x][i]);
+    if (dst) amax_publish(dst, r);
+  }
 }
 __global__ void __launch_bounds__(256)
 attn_bwd_dq_kernel(const AttnBwdArgs a) {
@@ -930,7 +941,7 @@ attn_bwd_dq_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
         mxq = fmaxf(mxq, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
       }
   }
-  wave_amax_to(a.amax_dq, mxq);                            // by-product: max |dQ| for the query projection's gradient GEMMs
+  block_amax_to(a.amax_dq, mxq, nullptr, 0.f, 4);          // by-product: max |dQ| for the query projection's gradient GEMMs
 }
 // WIDE (round 3; Tk % 4 == 0, 16-byte aligned rows): every global access of the q-tile loop is a 16-byte one.  The first form issued 48
 // four-byte loads per thread and tile (dO^T / Q^T column pieces, P / dS entries of the lane's key) -- at 60-130 clk of issue per
@@ -1170,8 +1181,7 @@ attn_bwd_dkv_mfma_kernel(const AttnBwdArgs a, const unsigned* amax) {
         mxk = fmaxf(mxk, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
       }
   }
-  wave_amax_to(a.amax_dv, mxv);
-  wave_amax_to(a.amax_dk, mxk);
+  block_amax_to(a.amax_dv, mxv, a.amax_dk, mxk, 4);
 }
 // ---- dK / dV kernel, third form (round 3): built for instruction count -------------------------------------------------------------
 // The tile loop of the forms above issues ~600 (dS from HBM) / ~900 (dS rebuilt) instructions per wave and 32-query tile around 24 / 36
@@ -1197,14 +1207,19 @@ __device__ __forceinline__ void split8_m(const float* x, h16x8_t& hi, h16x8_t& l
 #pragma unroll
   for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)__builtin_fmaf((float)h, -1.f, x[e]); }
 }
-__global__ void __launch_bounds__(256, 2)
+// QG = 2 (launches of few workgroups: the cross-attentions, one 128-key block per (b, h) = 128 workgroups of 13 serial tiles on 256 CUs):
+// eight waves, the second four take the odd query tiles of the same keys with their own LDS tiles, and the two halves' accumulators
+// meet in LDS at the end -- half the serial tiles per workgroup, no partial sums in memory, the same summation order in every run.
+template <int QG>
+__global__ void __launch_bounds__(256 * QG, QG == 1 ? 2 : 1)
 attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
   constexpr int VS = 72;                                     // dO / Q tiles [32 queries][d], row stride in halfs
   constexpr int PS = 36;                                     // P staging tile [32 queries][32 keys] per wave, row stride in floats
-  __shared__ __attribute__((aligned(16))) _Float16 Th[2][4][32 * VS];          // [buffer][dO hi, dO lo, Q hi, Q lo]
-  __shared__ __attribute__((aligned(16))) float Pt[2][4][32 * PS];            // [buffer][wave]
-  __shared__ __attribute__((aligned(16))) float rds[2][32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  __shared__ __attribute__((aligned(16))) _Float16 Th[2][QG][4][32 * VS];      // [buffer][query group][dO hi, dO lo, Q hi, Q lo]
+  __shared__ __attribute__((aligned(16))) float Pt[2][QG * 4][32 * PS];       // [buffer][wave]
+  __shared__ __attribute__((aligned(16))) float rds[2][QG][32];
+  const int grp = QG == 1 ? 0 : (int)(threadIdx.x >> 8);     // query group: tiles grp, grp + QG, ... of the workgroup's range
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
   int kblk, hd, b;
   if (a.causal && a.balance) balanced_block(gridDim.x, a.H, a.B, kblk, hd, b); else { kblk = blockIdx.x; hd = blockIdx.y; b = blockIdx.z; }
   const int wkey0 = kblk * 128 + wave * 32, key = wkey0 + l31;           // this lane's key
@@ -1257,15 +1272,16 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
     rO0 = *reinterpret_cast<const float4*>(dp); rO1 = *reinterpret_cast<const float4*>(dp + 4);
     rQ0 = *reinterpret_cast<const float4*>(qp); rQ1 = *reinterpret_cast<const float4*>(qp + 4);
     if (tid < 32) rrd = rdb[min(q0 + tid, a.Tq - 1)];
-    if (!wave_dead(q0)) {
+    if (q0 < a.Tq && !wave_dead(q0)) {
 #pragma unroll
       for (int x4 = 0; x4 < 4; ++x4) rP[x4] = *reinterpret_cast<const float4*>(Pb + (size_t)min(q0 + 8 * x4 + prow, a.Tq - 1) * a.Tk);
     }
   };
-  fetch(q_first);
+  fetch(q_first + 32 * grp);
   int buf = 0;
-  for (int q0 = q_first; q0 < a.Tq; q0 += 32, buf ^= 1) {
-    const bool dead = wave_dead(q0);
+  for (int qb = q_first; qb < a.Tq; qb += 32 * QG, buf ^= 1) {      // (qb: the first group's tile -- the trip count is workgroup-uniform)
+    const int q0 = qb + 32 * grp;
+    const bool dead = q0 >= a.Tq || wave_dead(q0);
     {   // registers -> LDS tiles of this buffer
       float x[8], y[8];
       x[0] = rO0.x * sc; x[1] = rO0.y * sc; x[2] = rO0.z * sc; x[3] = rO0.w * sc; x[4] = rO1.x * sc; x[5] = rO1.y * sc; x[6] = rO1.z * sc; x[7] = rO1.w * sc;
@@ -1274,11 +1290,11 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
       split8_m(x, xh, xl);
       split8_m(y, yh, yl);
       const int o = qi * VS + d8;
-      *reinterpret_cast<h16x8_t*>(&Th[buf][0][o]) = xh; *reinterpret_cast<h16x8_t*>(&Th[buf][1][o]) = xl;
-      *reinterpret_cast<h16x8_t*>(&Th[buf][2][o]) = yh; *reinterpret_cast<h16x8_t*>(&Th[buf][3][o]) = yl;
-      if (tid < 32) rds[buf][tid] = rrd;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][grp][0][o]) = xh; *reinterpret_cast<h16x8_t*>(&Th[buf][grp][1][o]) = xl;
+      *reinterpret_cast<h16x8_t*>(&Th[buf][grp][2][o]) = yh; *reinterpret_cast<h16x8_t*>(&Th[buf][grp][3][o]) = yl;
+      if (tid < 32) rds[buf][grp][tid] = rrd;
       if (!dead) {
-        float* Pw = Pt[buf][wave];
+        float* Pw = Pt[buf][4 * grp + wave];
 #pragma unroll
         for (int x4 = 0; x4 < 4; ++x4) {
           const bool ok = kc_in && q0 + 8 * x4 + prow < a.Tq;
@@ -1288,9 +1304,9 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
       }
     }
     __syncthreads();
-    if (q0 + 32 < a.Tq) fetch(q0 + 32);                       // next tile: in flight behind this tile's products
+    if (qb + 32 * QG < a.Tq) fetch(q0 + 32 * QG);             // next tile: in flight behind this tile's products
     if (dead) continue;
-    const _Float16* Oh = Th[buf][0]; const _Float16* Ol = Th[buf][1]; const _Float16* Qh = Th[buf][2]; const _Float16* Ql = Th[buf][3];
+    const _Float16* Oh = Th[buf][grp][0]; const _Float16* Ol = Th[buf][grp][1]; const _Float16* Qh = Th[buf][grp][2]; const _Float16* Ql = Th[buf][grp][3];
     // dP[q][key] = sum_d dO[q][d] V[key][d]
     f32x16 dpt;
 #pragma unroll
@@ -1303,10 +1319,10 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
     }
     float pv[16], sv[16];                                    // register r <-> query q0 + frow_t(r, half), the lane's key
     {
-      const float* Pw = Pt[buf][wave];
+      const float* Pw = Pt[buf][4 * grp + wave];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 rd4 = *reinterpret_cast<const float4*>(&rds[buf][8 * g4 + 4 * half]);
+        const float4 rd4 = *reinterpret_cast<const float4*>(&rds[buf][grp][8 * g4 + 4 * half]);
         const float rdv[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1340,26 +1356,49 @@ attn_bwd_dkv3_kernel(const AttnBwdArgs a, const unsigned* amax) {
       }
     }
   }
+  if (QG == 2) {   // the second query group's sums join the first's through LDS (the P tiles' region: 4 waves x 64 registers x 64 lanes)
+    float* red = &Pt[0][0][0];
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { red[((wave * 4 + nb) * 16 + r) * 64 + lane] = accv[nb][r]; red[((wave * 4 + 2 + nb) * 16 + r) * 64 + lane] = acck[nb][r]; }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accv[nb][r] += red[((wave * 4 + nb) * 16 + r) * 64 + lane]; acck[nb][r] += red[((wave * 4 + 2 + nb) * 16 + r) * 64 + lane]; }
+  }
+  // the abs-max words first, the stores last: the look at the word waits for everything the wave has in flight (one counter for loads and
+  // stores), so behind the stores it held every workgroup until its dK / dV rows were acknowledged by memory (12 us per launch)
   float mxv = 0.f, mxk = 0.f;
+  {
+    const float fk = a.scale * inv;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accv[nb][r] *= inv; acck[nb][r] *= fk;
+        mxv = fmaxf(mxv, fabsf(accv[nb][r])); mxk = fmaxf(mxk, fabsf(acck[nb][r]));
+      }
+    if (!kin) { mxv = 0.f; mxk = 0.f; }
+  }
+  block_amax_to(a.amax_dv, mxv, a.amax_dk, mxk, 4);
   if (kin) {
     float* pvd = a.dV + ((size_t)b * a.Tk + key) * a.lddv + hd * 64;
     float* pkd = a.dK + ((size_t)b * a.Tk + key) * a.lddk + hd * 64;
-    const float fk = a.scale * inv;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d = 32 * nb + 8 * g4 + 4 * half;
-        const float4 v4 = make_float4(accv[nb][4 * g4] * inv, accv[nb][4 * g4 + 1] * inv, accv[nb][4 * g4 + 2] * inv, accv[nb][4 * g4 + 3] * inv);
-        const float4 k4 = make_float4(acck[nb][4 * g4] * fk, acck[nb][4 * g4 + 1] * fk, acck[nb][4 * g4 + 2] * fk, acck[nb][4 * g4 + 3] * fk);
-        *reinterpret_cast<float4*>(pvd + d) = v4;
-        *reinterpret_cast<float4*>(pkd + d) = k4;
-        mxv = fmaxf(mxv, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
-        mxk = fmaxf(mxk, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
+        *reinterpret_cast<float4*>(pvd + d) = make_float4(accv[nb][4 * g4], accv[nb][4 * g4 + 1], accv[nb][4 * g4 + 2], accv[nb][4 * g4 + 3]);
+        *reinterpret_cast<float4*>(pkd + d) = make_float4(acck[nb][4 * g4], acck[nb][4 * g4 + 1], acck[nb][4 * g4 + 2], acck[nb][4 * g4 + 3]);
       }
   }
-  wave_amax_to(a.amax_dv, mxv);
-  wave_amax_to(a.amax_dk, mxk);
 }
 // ---- dQ kernel, third form (round 3): the same treatment -- K and V staged row-major ([key][d], four 16-byte LDS stores per thread instead of
 // eight 4-byte K^T loads), K^T operands by LDS transpose reads, clamped loads, the next tile prefetched into registers, double-buffered
@@ -1481,20 +1520,24 @@ attn_bwd_dq3_kernel(const AttnBwdArgs a, const unsigned* amax) {
       }
     }
   }
-  float mxq = 0.f;
-  if (qin) {
-    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
+  float mxq = 0.f;                                           // (the abs-max word first, the stores last: see the dK / dV kernel)
+  {
     const float f = a.scale * inv;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 o4 = make_float4(accq[nb][4 * g4] * f, accq[nb][4 * g4 + 1] * f, accq[nb][4 * g4 + 2] * f, accq[nb][4 * g4 + 3] * f);
-        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) = o4;
-        mxq = fmaxf(mxq, fmaxf(fmaxf(fabsf(o4.x), fabsf(o4.y)), fmaxf(fabsf(o4.z), fabsf(o4.w))));
-      }
+      for (int r = 0; r < 16; ++r) { accq[nb][r] *= f; mxq = fmaxf(mxq, fabsf(accq[nb][r])); }
+    if (!qin) mxq = 0.f;
   }
-  wave_amax_to(a.amax_dq, mxq);
+  block_amax_to(a.amax_dq, mxq, nullptr, 0.f, 4);
+  if (qin) {
+    float* dst = a.dQ + ((size_t)b * a.Tq + q) * a.lddq + hd * 64;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(dst + 32 * nb + 8 * g4 + 4 * half) = make_float4(accq[nb][4 * g4], accq[nb][4 * g4 + 1], accq[nb][4 * g4 + 2], accq[nb][4 * g4 + 3]);
+  }
 }
 hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,
                                 const float* dO, int lddo, const float* P, float* dS, float* dQ, int lddq, float* dK, int lddk,
@@ -1529,7 +1572,11 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
   if (fused && !dq2 && !(ldk & 3) && !(((size_t)K) & 15)) vnr_launch(attn_bwd_dq3_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   else vnr_launch(attn_bwd_dq_mfma_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   static const bool dkv2 = getenv("VNR_ATTN_BWD_DKV2") != nullptr;         // A/B switch: the first fused form
-  if (fused && !dkv2) vnr_launch(attn_bwd_dkv3_kernel, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
+  static const bool no_qg = getenv("VNR_ATTN_BWD_NO_QG") != nullptr;       // A/B switch: one query group always
+  static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+  const long dkv_wgs = (long)((Tk + 127) / 128) * H * B;
+  if (fused && !dkv2 && !no_qg && dkv_wgs <= ncu && Tq > 64) vnr_launch(attn_bwd_dkv3_kernel<2>, dim3((Tk + 127) / 128, H, B), dim3(512), 0, s, a, amax_slot);
+  else if (fused && !dkv2) vnr_launch(attn_bwd_dkv3_kernel<1>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   else if (fused) vnr_launch(attn_bwd_dkv_mfma_kernel<2>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   else if (wide) vnr_launch(attn_bwd_dkv_mfma_kernel<1>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);
   else vnr_launch(attn_bwd_dkv_mfma_kernel<0>, dim3((Tk + 127) / 128, H, B), dim3(256), 0, s, a, amax_slot);

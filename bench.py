@@ -474,6 +474,7 @@ def training_block(args, hps, device, rank, world):
         res = None
         for i in range(2):
             res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=i * world + rank)
+        tm.engine.synchronize()        # (a step returns when its results are on the host; the derived kernel copies for the next step follow it)
         n0 = tm.engine.launch_count()
         if world > 1:
             vdist.barrier()
@@ -481,6 +482,7 @@ def training_block(args, hps, device, rank, world):
         nst = 4
         for i in range(nst):
             res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=(2 + i) * world + rank)
+        tm.engine.synchronize()        # the timed region ends with an idle stream
         if world > 1:
             vdist.barrier()
         tdt = vdist.max_over_ranks((time.perf_counter() - t1) / nst)

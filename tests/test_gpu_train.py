@@ -123,6 +123,31 @@ def test_adam_update_matches_keras_formula():
         model.engine.close()
 
 
+def test_weights_uploaded_between_steps_reach_the_next_step():
+    """The transposed / flipped / split copies of the kernels are derived behind an optimizer step (not at the top of the next one);
+    an upload in between (a checkpoint restore: vnr_set_weight) must invalidate them.  Step, restore the initial weights, then the
+    gradients must be those of a fresh engine at the initial weights -- bit for bit apart from the atomic accumulation order."""
+    hps, w, b, mels, eps = _case("tiny")
+    args = (b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2)
+    fresh = VAENAR(hps, weights=w)
+    try:
+        fresh.train_step(*args, eps=eps, dropout_seed=5, apply_update=False)
+        g0 = fresh.gradients()
+    finally:
+        fresh.engine.close()
+    model = VAENAR(hps, weights=w)
+    try:
+        model.train_step(*args, eps=eps, dropout_seed=4, learning_rate=1e-2, apply_update=True)      # moves every kernel by ~1e-2
+        model.load_weights(w)
+        model.train_step(*args, eps=eps, dropout_seed=5, apply_update=False)
+        g1 = model.gradients()
+    finally:
+        model.engine.close()
+    for k in sorted(g0):
+        scale = max(np.abs(g0[k]).max(), 1e-12)
+        assert np.abs(g1[k] - g0[k]).max() <= 1e-4 * scale + 1e-9, k
+
+
 def test_rccl_allreduce_path_single_rank():
     """The gradient exchange of data-parallel training (RCCL all-reduce of the flat gradient between backward and Adam)
     on a one-rank communicator: the call sequence runs on the device and leaves the gradients unchanged (sum over one

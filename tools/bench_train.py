@@ -26,10 +26,12 @@ for rf in (2, 5):
     out = None
     for i in range(2):
         out = model.train_step(ids, mel_d, b["text_lengths"], b["mel_lengths"], 1e-5, rf, eps=eps_d, dropout_seed=i)
+    model.engine.synchronize()
     n0 = model.engine.launch_count()
     t0 = time.perf_counter()
     for i in range(steps):
         out = model.train_step(ids, mel_d, b["text_lengths"], b["mel_lengths"], 1e-5, rf, eps=eps_d, dropout_seed=2 + i)
+    model.engine.synchronize()          # (a step returns when its results are on the host; the kernel copies for the next step follow it)
     dt = (time.perf_counter() - t0) / steps
     print(json.dumps({"workload": "T1 train_step B=%d T_text=128 T_mel=800 rf=%d" % (B, rf), "ms_per_step": dt * 1e3,
                       "mel_frames_per_s": B * 800 / dt, "launches_per_step": (model.engine.launch_count() - n0) / steps,

@@ -83,6 +83,7 @@ struct vnr_context {
   vnr_config cfg;
   TrainState* train = nullptr;   // optimizer state, gradient buffers, transposed kernels (train.inc); built on the first training step
   bool packed_stale = false;
+  bool derived_fresh = false;    // training: the transposed / flipped / split copies of the kernels (train.inc) match the weight store
   // data-parallel training: RCCL communicator over xGMI (one process per GPU), bound at run time with dlopen so that an
   // inference-only process never loads librccl
   void* rccl_lib = nullptr; ncclComm_t comm = nullptr; int comm_size = 1, comm_rank = 0;     // an optimizer step changed the variables: inference panels are rebuilt lazily (check_ready)
@@ -1301,6 +1302,7 @@ int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int6
   HIP_TRY(h, hipMemcpyAsync(t.d, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->finalized = false;
+  h->derived_fresh = false;
   return VNR_OK;
 }
 
@@ -1704,6 +1706,7 @@ int vnr_comm_broadcast_weights(vnr_handle h) {
     RCCL_TRY(h, g_rccl.Broadcast(t.d, t.d, (size_t)t.n, ncclFloat, 0, h->comm, h->stream));
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->derived_fresh = false;
   for (auto& kv : h->w) if (kv.second.n == 1) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
   return vnr_finalize_weights(h);
 }
@@ -1788,6 +1791,7 @@ int vnr_init(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, 
   h->training = true;
   const int rc = init_impl(h, d_ids, d_text_lengths, d_reduced_lengths, B, Tt, Tz, pos_step, d_eps, d_mel);
   h->training = saved;
+  h->derived_fresh = false;
   TRY(rc);
   // ActNorm variables and BN moving statistics changed: rebuild every folded / packed panel from the weight store
   return vnr_finalize_weights(h);

@@ -54,16 +54,17 @@ def main(path):
     rs = by_q[main_q]
     gl = []
     prev = t0
-    for r in rs:
+    prev_name = "(step start)"
+    for i, r in enumerate(rs):
         if r[1] > prev:
-            gl.append((r[1] - prev, r[0]))
-        prev = max(prev, r[2])
+            gl.append((r[1] - prev, r[0] + "   <- after #%d %s at +%.2f ms" % (i, prev_name.replace("void ", "").replace("vnr::", "").split("(")[0], (r[1] - t0) / 1e6)))
+        prev = max(prev, r[2]); prev_name = r[0]
     gl.sort(reverse=True)
     tot_gap = sum(g for g, _ in gl)
     print("# main stream: %d gaps, %.2f ms in total; gaps > 20 us: %d (%.2f ms); the ten longest (us, kernel that followed):" % (
         len(gl), tot_gap / 1e6, sum(1 for g, _ in gl if g > 20000), sum(g for g, _ in gl if g > 20000) / 1e6))
     for g, n in gl[:10]:
-        print("   %8.1f  %s" % (g / 1e3, n.replace("void ", "").replace("vnr::", "")[:100]))
+        print("   %8.1f  %s" % (g / 1e3, n.replace("void ", "").replace("vnr::", "")[:170]))
     agg = defaultdict(lambda: [0, 0])
     for r in rs:
         k = r[0].replace("void ", "").replace("vnr::", "").split("(")[0]

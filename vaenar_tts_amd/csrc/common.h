@@ -146,6 +146,7 @@ struct GemmArgs {
   const void* Wsplit = nullptr;     // optional pre-split fp16 image of Wt (split-fp16 MFMA path), see gemm2.hip
   float acc_scale = 1.f;            // 2^-s when the split image was pre-scaled by 2^s
   const unsigned* a_absmax = nullptr;   // split path, A is a gradient: device word with the bits of max |A|; A is pre-scaled to ~2^10 (gemm2.hip)
+  const unsigned* a_absmax2 = nullptr; const unsigned* a_absmax3 = nullptr;   // more words of the same kind (A = column blocks with one word each): the largest counts
   const float* bias = nullptr;
   int act = ACT_IDENTITY;
   const float* bn_scale = nullptr; const float* bn_shift = nullptr;
@@ -434,7 +435,7 @@ struct BwdChainArgs {
   // serialised in the L2: 0.2 ms of the launch.)  Scratch of ceil(M / rows per workgroup) * pcols floats.
   float* partial;
 };
-hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s);
+hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s, hipStream_t finish_stream = nullptr, int part = 0);
 inline int bwd_chain_pcols(int seg, int F) { return seg == 0 ? 6 * 256 + F : 3 * 256; }
 struct OpmJobHost { const float* src; int N, K; char* dst; };          // same layout as the kernel's job record
 hipError_t launch_opmajor_batch(const void* jobs_device, int njobs, float scale, hipStream_t s);

@@ -289,7 +289,9 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     // is pre-scaled by the power of two that maps the launch-wide max |A| to ~2^10 and the result is scaled back exactly.
     float a_sc = 1.f;
     if (g.a_absmax) {
-      const unsigned bits = *g.a_absmax;
+      unsigned bits = *g.a_absmax;
+      if (g.a_absmax2) bits = max(bits, *g.a_absmax2);
+      if (g.a_absmax3) bits = max(bits, *g.a_absmax3);
       const int e = (int)(bits >> 23) & 0xff;
       if (e > 0 && e < 255) {
         int sft = 10 - (e - 127);

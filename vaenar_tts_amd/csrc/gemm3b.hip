@@ -421,7 +421,9 @@ __global__ void __launch_bounds__(256) bwd_chain_colsum_kernel(const ColFinishAr
   }
 }
 
-hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s) {
+// finish_stream: where the small kernel that adds up the per-workgroup partial column sums (bias / gamma / beta gradients) runs; the
+// caller orders it after `s` (the training step puts it on its kernel-gradient stream: it feeds nothing but gradients)
+hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s, hipStream_t finish_stream, int part) {
   if (g.M <= 0 || (g.seg != 0 && g.seg != 1) || !g.dy || !g.vA || !g.stA || !g.gA || !g.dvA || !g.dgA || !g.dbA || !g.dbiasA || !g.pr ||
       !g.out0 || !g.out1 || (g.ld_dy & 3) || !g.partial || g.npre < 0 || g.npre > 3)
     return hipErrorInvalidValue;
@@ -430,6 +432,7 @@ hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s) {
                      !g.dbB || !g.dbiasB))
     return hipErrorInvalidValue;
   const int rows = rows64 ? 64 : 32, nwg = (g.M + rows - 1) / rows;
+  if (part == 2) goto finish;                               // part: 0 both kernels, 1 the chain only, 2 the finish only
   if (rows64) {
     static int done[kMaxDevices] = {0};
     opt_in_dynamic_lds((const void*)bwd_chain_kernel<2>, BLds<2>::TOTAL, done);
@@ -439,8 +442,11 @@ hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s) {
     opt_in_dynamic_lds((const void*)bwd_chain_kernel<1>, BLds<1>::TOTAL, done);
     vnr_launch(bwd_chain_kernel<1>, dim3(nwg), dim3(512), BLds<1>::TOTAL, s, g);
   }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || part == 1) return e;
+  }
+finish:
   ColFinishArgs c;
   c.partial = g.partial; c.nwg = nwg; c.pcols = bwd_chain_pcols(g.seg, g.F);
   if (g.seg == 0) {
@@ -455,7 +461,7 @@ hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s) {
     for (int i = 0; i < 3; ++i) { c.dst[i] = d[i]; c.off[i] = 256 * i; }
     c.off[3] = 768;
   }
-  vnr_launch(bwd_chain_colsum_kernel, dim3((c.pcols + 31) / 32), dim3(256), 0, s, c);
+  vnr_launch(bwd_chain_colsum_kernel, dim3((c.pcols + 31) / 32), dim3(256), 0, finish_stream ? finish_stream : s, c);
   return hipGetLastError();
 }
 

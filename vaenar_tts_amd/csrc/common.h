@@ -330,12 +330,13 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 
 // training-mode statistics / dropout (misc.hip)
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s);
+hipError_t launch_col_sum2(const float* x, int M, int C, int ld, double* sum, double* sumsq, hipStream_t s);
 hipError_t launch_col_sum_amax(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, hipStream_t s);
 hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
 hipError_t launch_col_sum_grad_act(float* dy, const float* y, int act, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s);
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
-                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s);
+                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw = 0);
 hipError_t launch_actnorm_init_finish(const double* mean, const double* sq, int M, int C, float* log_scale, float* bias,
                                       float* scale, hipStream_t s);
 hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const float* shift, const float* pe, int T, float pe_w,

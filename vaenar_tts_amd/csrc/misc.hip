@@ -533,10 +533,12 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
 // columns of a row, the block's 4 waves take rows m, m+1, m+2, m+3 of a stride-(4 gridDim.y) walk with two loads in flight.
 // yact != null: x is a gradient dy and yact the OUTPUT of an activation (act_bwd_kernel's job folded into this pass: dy *= act'(y) is
 // written back in place before it enters the sums) -- one launch and one pass over dy less per activated Dense / Conv1D layer.
-__global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act) {
+__global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act,
+                                double* out2) {      // out2 != null (mean == null): also out2[c] += sum_m x^2 -- both BatchNorm sums in ONE pass
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   const int rg = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  double acc2[4] = {0.0, 0.0, 0.0, 0.0};
   float mx = 0.f;
   if (c < C) {
     double mu[4] = {0.0, 0.0, 0.0, 0.0};
@@ -550,6 +552,7 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
         mx = fmaxf(mx, fabsf(xv[e]));
         const double d = (double)xv[e] - mu[e];
         acc[e] += mean ? d * d : (double)xv[e];
+        if (out2) acc2[e] += (double)xv[e] * (double)xv[e];
       }
     };
     auto dact = [&](float4& v, const float4& y) {
@@ -598,13 +601,20 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
     if (fout) atomicAdd(&fout[cc], (float)t);
     else atomicAdd(&out[cc], t);
   }
+  if (out2) {                                                // (workgroup-uniform)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[rg][(threadIdx.x & 63) * 4 + e] = acc2[e];
+    __syncthreads();
+    if (cc < C) atomicAdd(&out2[cc], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  }
 }
 static bool col_sum4_ok(const float* x, int C, int ld) {
   static const bool v1 = getenv("VNR_COLSUM_V1") != nullptr;           // A/B switch
   return !v1 && !(C & 3) && !(ld & 3) && !((size_t)x & 15);
 }
 static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, hipStream_t s,
-                                     const float* yact = nullptr, int act = ACT_IDENTITY) {
+                                     const float* yact = nullptr, int act = ACT_IDENTITY, double* out2 = nullptr) {
   int rb = (M + 127) / 128; if (rb > 128) rb = 128; if (rb < 1) rb = 1;
   if (col_sum4_ok(x, C, ld) && (!yact || !((size_t)yact & 15))) {
     // every workgroup ends in one atomic per column: 256 groups contending for the same 256 words cost more than the longer
@@ -614,9 +624,10 @@ static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const
     const int cb = (C + 255) / 256;
     int rb4 = forced > 0 ? forced : 256 / cb; if (!forced) { if (rb4 > 128) rb4 = 128; if (rb4 < 32) rb4 = 32; }
     const int rmax = (M + 63) / 64; if (rb4 > rmax) rb4 = rmax; if (rb4 < 1) rb4 = 1;
-    vnr_launch(col_sum4_kernel, dim3(cb, rb4), dim3(256), 0, s, const_cast<float*>(x), M, C, ld, mean, out, amax, fout, yact, act);
+    vnr_launch(col_sum4_kernel, dim3(cb, rb4), dim3(256), 0, s, const_cast<float*>(x), M, C, ld, mean, out, amax, fout, yact, act, out2);
   } else {
     if (yact) return hipErrorInvalidValue;
+    if (out2) return hipErrorNotSupported;
     vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
   }
   return hipGetLastError();
@@ -635,6 +646,10 @@ hipError_t launch_col_sum_grad_act(float* dy, const float* y, int act, int M, in
   if (!col_sum4_ok(dy, C, ld) || ((size_t)y & 15)) return hipErrorNotSupported;
   return launch_col_sum_any(dy, M, C, ld, nullptr, nullptr, amax, grad, s, y, act);
 }
+// sum[c] += sum_m x[m][c] and sumsq[c] += sum_m x[m][c]^2 in one pass (float64); hipErrorNotSupported when the 16-byte kernel cannot take x
+hipError_t launch_col_sum2(const float* x, int M, int C, int ld, double* sum, double* sumsq, hipStream_t s) {
+  return launch_col_sum_any(x, M, C, ld, nullptr, sum, nullptr, nullptr, s, nullptr, ACT_IDENTITY, sumsq);
+}
 hipError_t launch_col_sum(const float* x, int M, int C, int ld, const double* mean, double* out, hipStream_t s) {
   return launch_col_sum_amax(x, M, C, ld, mean, out, nullptr, s);
 }
@@ -649,11 +664,19 @@ hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s) {
 // BatchNormalization(training=True) (Keras, TF 2.2, non-fused path for rank-3 inputs): normalise with the batch
 // mean / population variance, update the moving statistics with momentum 0.99.
 //   scale = gamma * rsqrt(var + eps), shift = beta - mean * scale;  moving = moving * 0.99 + batch * 0.01
-__global__ void bn_train_finish_kernel(const double* mean, const double* sq, int M, int C, const float* gamma,
+// raw: mean / sq hold sum x and sum x^2 (launch_col_sum2); they are rewritten as the mean and the centred sum of squares, which is
+// what the backward pass reads (float64: sum x^2 - M mean^2 keeps ~1e-13 of the variance for activations of unit order)
+__global__ void bn_train_finish_kernel(double* mean, double* sq, int M, int C, const float* gamma,
                                        const float* beta, float momentum, float* moving_mean, float* moving_var,
-                                       float* scale, float* shift) {
+                                       float* scale, float* shift, int raw) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (raw) {
+    const double m = mean[c] / (double)M;
+    double ss = sq[c] - (double)M * m * m;
+    if (ss < 0.0) ss = 0.0;
+    mean[c] = m; sq[c] = ss;
+  }
   const float mu = (float)mean[c], var = (float)(sq[c] / (double)M);
   const float inv = gamma[c] * (1.0f / sqrtf(var + kBnEps));
   scale[c] = inv;
@@ -662,9 +685,9 @@ __global__ void bn_train_finish_kernel(const double* mean, const double* sq, int
   moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
 }
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
-                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s) {
-  vnr_launch(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, mean, sq, M, C, gamma, beta, momentum,
-                     moving_mean, moving_var, scale, shift);
+                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw) {
+  vnr_launch(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, const_cast<double*>(mean), const_cast<double*>(sq), M, C, gamma, beta, momentum,
+                     moving_mean, moving_var, scale, shift, raw);
   return hipGetLastError();
 }
 // ActNormFlow.init (flow.py:189-196): log_scale = log(1 / (std + 1e-8)), bias = -mean / (std + 1e-8) from the

@@ -432,21 +432,19 @@ hipError_t launch_bwd_chain(const BwdChainArgs& g, int rows64, hipStream_t s, hi
                      !g.dbB || !g.dbiasB))
     return hipErrorInvalidValue;
   const int rows = rows64 ? 64 : 32, nwg = (g.M + rows - 1) / rows;
-  if (part == 2) goto finish;                               // part: 0 both kernels, 1 the chain only, 2 the finish only
-  if (rows64) {
-    static int done[kMaxDevices] = {0};
-    opt_in_dynamic_lds((const void*)bwd_chain_kernel<2>, BLds<2>::TOTAL, done);
-    vnr_launch(bwd_chain_kernel<2>, dim3(nwg), dim3(512), BLds<2>::TOTAL, s, g);
-  } else {
-    static int done[kMaxDevices] = {0};
-    opt_in_dynamic_lds((const void*)bwd_chain_kernel<1>, BLds<1>::TOTAL, done);
-    vnr_launch(bwd_chain_kernel<1>, dim3(nwg), dim3(512), BLds<1>::TOTAL, s, g);
-  }
-  {
-    hipError_t e = hipGetLastError();
+  if (part != 2) {                                          // part: 0 both kernels, 1 the chain only, 2 the finish only
+    if (rows64) {
+      static int done[kMaxDevices] = {0};
+      opt_in_dynamic_lds((const void*)bwd_chain_kernel<2>, BLds<2>::TOTAL, done);
+      vnr_launch(bwd_chain_kernel<2>, dim3(nwg), dim3(512), BLds<2>::TOTAL, s, g);
+    } else {
+      static int done[kMaxDevices] = {0};
+      opt_in_dynamic_lds((const void*)bwd_chain_kernel<1>, BLds<1>::TOTAL, done);
+      vnr_launch(bwd_chain_kernel<1>, dim3(nwg), dim3(512), BLds<1>::TOTAL, s, g);
+    }
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess || part == 1) return e;
   }
-finish:
   ColFinishArgs c;
   c.partial = g.partial; c.nwg = nwg; c.pcols = bwd_chain_pcols(g.seg, g.F);
   if (g.seg == 0) {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VNR_ABI_VERSION 3
+#define VNR_ABI_VERSION 4
 
 typedef struct vnr_context *vnr_handle;
 
@@ -105,6 +105,8 @@ int vnr_synchronize(vnr_handle h);
  * (vaenar_tts_amd/weights.py lists all paths).  The data is copied. */
 int vnr_set_weight(vnr_handle h, const char *path, const float *host, const int64_t *shape,
                    int ndim);
+/* (Updating an EXISTING variable with the same shape on a finalized engine -- tf.Variable.assign on one of
+ * model.trainable_variables -- needs no vnr_finalize_weights: the packed panels are rebuilt by the next module call.) */
 /* reads a variable back (model.trainable_variables / checkpoint save, train.py:246-255) */
 int vnr_get_weight(vnr_handle h, const char *path, float *host, int64_t count);
 /* packs the weights for the kernels (transposed [out][in] panels, fused QKV / K|V panels,
@@ -155,7 +157,27 @@ int vnr_inference(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_leng
 int vnr_prior_log_probability(vnr_handle h, const float *d_z, const float *d_text_embd,
                               const int32_t *d_z_lengths, const int32_t *d_text_lengths, int B, int Tz,
                               int Tt, float *d_logprobs);
-/* VAENAR.call (models/models.py:105-197) forward, n_sample = 1, reduce_loss=False.  With option "training" = 1 it is
+/* BasePosterior.reparameterize (modules/posterior.py:21-39): d_samples [B, nsamples, T, latent] = d_eps * exp(0.5 * logvar) + mu with
+ * d_mu, d_logvar [B, T, latent]; d_eps [B, nsamples, T, latent] replaces tf.random.normal (:35; draw it with vnr_random_normal) and
+ * NULL is the `random=False` branch (:37, zeros). */
+int vnr_posterior_reparameterize(vnr_handle h, const float *d_mu, const float *d_logvar, const float *d_eps, int B,
+                                 int nsamples, int T, float *d_samples);
+/* BasePosterior.log_probability (modules/posterior.py:42-72): d_logprobs [B, nsamples] = sum_{t < len} -0.5 (latent * log(2 pi) +
+ * sum_c (logvar + n^2)); n = d_eps when given (the `eps is not None` branch, :59), else (d_z - mu) / (exp(0.5 logvar) + epsilon)
+ * (:60-61).  d_z / d_eps [B, nsamples, T, latent]; d_lengths [B] or NULL = every frame (:66-68). */
+int vnr_posterior_log_probability(vnr_handle h, const float *d_mu, const float *d_logvar, const float *d_z, const float *d_eps,
+                                  const int32_t *d_lengths, int B, int nsamples, int T, float epsilon, float *d_logprobs);
+/* TransformerPrior.init (modules/prior.py:171-186): the flow run forwards like sample(), but every ActNormFlow first sets its
+ * log_scale / bias from the statistics of its input (flow.py:189-196).  The variables in the weight store are updated and every
+ * packed panel rebuilt.  d_eps [B,Tz,latent] the initial noise (NULL = zeros); d_z [B,Tz,latent]; d_logprobs [B] or NULL. */
+int vnr_prior_init(vnr_handle h, const int32_t *d_z_lengths, const float *d_text_embd, const int32_t *d_text_lengths, int B,
+                   int Tz, int Tt, const float *d_eps, float *d_z, float *d_logprobs);
+/* VAENAR.call (models/models.py:105-197) forward, reduce_loss=False.  Option "n_sample" (default 1) is hps.Train.num_samples
+ * (models.py:13): the encoder and the posterior run on the B utterances, then text encoding, targets and lengths are tiled n_sample
+ * times (sample index inner, models.py:149-178) and the decoder and prior.log_probability run on B * n_sample rows; d_eps is then
+ * [B, n_sample, Tz, latent], d_outs [B * n_sample, Tm, output_dim], d_alignments [dec_nblk][B * n_sample, heads, Tz, Tt], the
+ * per-utterance d_l2 / d_kl [B] are means over the samples (models.py:79-83,90), d_aux = predicted lengths [B] | posterior
+ * log-probs [B * n_sample] | prior log-probs [B * n_sample].  With option "training" = 1 it is
  * the training-mode forward of train.py:130-134: Dropout active (counter-based masks keyed by option "dropout_seed"),
  * BatchNormalization on batch statistics with the moving statistics updated in the weight store.  Default (training=0):
  * encoder -> length predictor -> posterior -> reparameterize (d_eps [B,Tz,latent] or NULL = zeros) ->
@@ -266,7 +288,10 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * launch per layer; 2 / 3 = 64- / 32-row panels forced, 1 picks 64-row panels from 192 panels up).  "train_chain_bwd" (default 1,
  * needs train_chain): the backward of those blocks between their attention cores -- LayerNorm', dense2', relu', dense1',
  * LayerNorm', att_proj' with the bias / gamma / beta gradients and the abs-max words of the kernel-gradient GEMMs as by-products --
- * as two backward-chain launches per block (0 = one launch per operation). */
+ * as two backward-chain launches per block (0 = one launch per operation).
+ * "n_sample" (default 1): hps.Train.num_samples for vnr_elbo_fwd / vnr_train_step (models.py:13,141-178), see vnr_elbo_fwd.
+ * "deterministic" (default 0): the reference pins TF_DETERMINISTIC_OPS=1 and every seed (train.py:17-32); with 1 vnr_train_step
+ * accumulates every gradient in a fixed order (no float atomics): two identical steps give bit-identical gradients and variables. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,
@@ -277,7 +302,7 @@ int vnr_set_option(vnr_handle h, const char *name, int value);
  * length_weight * length_l2 (train.py:135; reduce_loss=True means over the batch), gradients w.r.t. every trainable
  * variable (the length predictor sees stop_gradient(text_embd), models.py:133), then tf.keras.optimizers.Adam
  * (train.py:116-117: lr_t = lr sqrt(1-b2^t)/(1-b1^t), w -= lr_t m / (sqrt(v) + epsilon)).  Dropout masks follow option
- * "dropout_seed"; d_eps [B,Tz,latent] is the reparameterisation noise.  apply_update = 0 computes the gradients only
+ * "dropout_seed"; d_eps [B,Tz,latent] ([B,n_sample,Tz,latent] with option "n_sample") is the reparameterisation noise.  apply_update = 0 computes the gradients only
  * (vnr_get_gradient).  h_scalars (HOST, 4 floats or NULL) = mel_l2, kl, length_l2, loss -- the tuple train_step returns.
  * After an update the inference panels are rebuilt lazily by the next inference-mode call.  Synchronises. */
 int vnr_train_step(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengths,
@@ -295,6 +320,8 @@ int vnr_train_step(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_len
 int vnr_comm_unique_id(vnr_handle h, char *id128);
 int vnr_comm_init(vnr_handle h, int nranks, int rank, const char *id128);
 int vnr_comm_broadcast_weights(vnr_handle h);
+/* rank count and this rank as RCCL itself reports them for the bound communicator (ncclCommCount / ncclCommUserRank) */
+int vnr_comm_info(vnr_handle h, int *nranks, int *rank);
 int vnr_comm_destroy(vnr_handle h);
 
 /* d loss / d variable of the last vnr_train_step (n floats, layout of the variable) -- tape.gradient (train.py:136). */

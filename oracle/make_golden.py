@@ -189,6 +189,47 @@ def build_ref_train(name):
     return out
 
 
+def build_ref_b2():
+    """tests/golden/refshim_b2.npz -- the rest of the call surface models.VAENAR uses, by the REFERENCE's
+    own Python over the torch shim (tiny configuration): (i) the module-level posterior / prior methods
+    (run_reference_on_shim.reference_module_methods); (ii) train_step with hps.Train.num_samples = 2 (models.py:141-178 under
+    training=True and autograd): scalars, predictions, the gradient of every trainable variable."""
+    from oracle.run_reference_on_shim import reference_call_training, reference_module_methods, reference_train_step
+    hps = tiny_hps()
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    B, Tt, Tm, rf, ns = 3, 11, 40, 2, 2
+    b = make_batch(B, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
+                   text_step=3, mel_step=7)
+    r = np.random.Generator(np.random.PCG64(41))
+    C, Tz = hps.Common.latent_dim, (Tm + rf - 1) // rf
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    zl = ((b["mel_lengths"].astype(np.int64) + rf - 1) // rf).astype(np.int32)
+    eps_post = r.standard_normal((B, ns, Tz, C)).astype(np.float32)
+    eps_prior = r.standard_normal((B, int(zl.max()), C)).astype(np.float32)
+    eps_init = r.standard_normal((B, int(zl.max()), C)).astype(np.float32)
+    out = dict(ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], z_lengths=zl, mels=mels, eps_post=eps_post,
+               eps_prior=eps_prior, eps_init=eps_init, n_sample=np.int64(ns), reduction_factor=np.int64(rf), dropout_seed=np.int64(11),
+               weights_sha256=np.frombuffer(weights_digest(w).encode(), np.uint8))
+    mm = reference_module_methods(hps, w, b["ids"], b["text_lengths"], mels[:, ::rf], zl, eps_post, eps_prior, eps_init, 11)
+    for k, v in mm.items():
+        out["mod/" + k] = np.asarray(v, np.float64)
+    hps.Train.num_samples = ns
+    for tag, kw in (("kw1", 1.0), ("kw1e-5", 1e-5)):
+        sc, g, preds, stats = reference_train_step(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps_post, rf, kw, 11)
+        out["ns2/" + tag + "/scalars"] = np.array([sc["loss"], sc["mel_l2"], sc["kl"], sc["length_l2"]], np.float64)
+        for k in sorted(g):
+            out["ns2/" + tag + "/gdig/" + k] = digest(g[k])
+            if tag == "kw1" and g[k].size <= 4096:
+                out["ns2/kw1/grad/" + k] = g[k].astype(np.float32)
+        if tag == "kw1":
+            out["ns2/predictions"] = preds.astype(np.float32)
+            for k, v in stats.items():
+                out["ns2/moving/" + k] = v.astype(np.float64)
+    outs, l2, kl, ll, _ = reference_call_training(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps_post, rf, 11)
+    out.update({"ns2/call_l2": l2.astype(np.float64), "ns2/call_kl": kl.astype(np.float64), "ns2/call_length": ll.astype(np.float64)})
+    return out
+
+
 def digest(a):
     """[16 samples at fixed strided flat positions | sum | l2 norm | max abs] of an array, float64."""
     f = np.asarray(a, np.float64).reshape(-1)
@@ -210,6 +251,8 @@ def main():
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python over the tf shim)")
         np.savez_compressed(os.path.join(d, "refshim_nsample2.npz"), **build_ref_nsample(2))
         print("wrote refshim_nsample2", os.path.getsize(os.path.join(d, "refshim_nsample2.npz")) // 1024, "KiB (reference's own Python, num_samples = 2)")
+        np.savez_compressed(os.path.join(d, "refshim_b2.npz"), **build_ref_b2())
+        print("wrote refshim_b2", os.path.getsize(os.path.join(d, "refshim_b2.npz")) // 1024, "KiB (reference's own Python: module-level methods, num_samples = 2 training step)")
         for name in REF_TRAIN_CASES:
             np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref_train(name))
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python, training mode, over the torch tf shim)")

@@ -123,6 +123,12 @@ def _reset_dropout_calls(model):
         l.calls = 0
 
 
+def _eps4(eps):
+    """[B, Tz, C] (n_sample = 1) or [B, n_sample, Tz, C] -> the [batch, nsamples, time, dim] tensor posterior.py:35 draws."""
+    e = np.asarray(eps, np.float64)
+    return e[:, None] if e.ndim == 3 else e
+
+
 def _build(ours_hps, weights):
     tf, models, hp = load_reference("torch")
     apply_overrides(hp.LJHPS, ours_hps)
@@ -140,8 +146,7 @@ def reference_train_step(ours_hps, weights, ids, mels, mel_lengths, text_lengths
     tf, model, leaves = _build(ours_hps, weights)
     tf.DROPOUT["seed"] = int(dropout_seed)
     _reset_dropout_calls(model)
-    B, Tz, C = np.asarray(eps).shape
-    tf.random.queue[:] = [np.asarray(eps, np.float64).reshape(B, 1, Tz, C)]          # posterior.py:35: [batch, nsamples, time, dim]
+    tf.random.queue[:] = [_eps4(eps)]                                                # posterior.py:35: [batch, nsamples, time, dim]
     preds, mel_l2, kl, length_l2, _ = model(inputs=tf.constant(ids), mel_targets=tf.constant(np.asarray(mels, np.float64)),
                                             mel_lengths=tf.constant(mel_lengths), text_lengths=tf.constant(text_lengths),
                                             reduction_factor=reduction_factor, training=True, reduce_loss=True)
@@ -159,8 +164,7 @@ def reference_call_training(ours_hps, weights, ids, mels, mel_lengths, text_leng
     tf, model, leaves = _build(ours_hps, weights)
     tf.DROPOUT["seed"] = int(dropout_seed)
     _reset_dropout_calls(model)
-    B, Tz, C = np.asarray(eps).shape
-    tf.random.queue[:] = [np.asarray(eps, np.float64).reshape(B, 1, Tz, C)]
+    tf.random.queue[:] = [_eps4(eps)]
     outs, l2, kl, ll, ali = model(inputs=tf.constant(ids), mel_targets=tf.constant(np.asarray(mels, np.float64)),
                                   mel_lengths=tf.constant(mel_lengths), text_lengths=tf.constant(text_lengths),
                                   reduction_factor=reduction_factor, training=True, reduce_loss=False)
@@ -176,3 +180,46 @@ def reference_init(ours_hps, weights, ids, mel_lengths, text_lengths, eps, dropo
     tf.random.queue[:] = [np.asarray(eps, np.float64)]
     mel = model.init(text_inputs=tf.constant(ids), mel_lengths=tf.constant(mel_lengths), text_lengths=tf.constant(text_lengths))
     return mel.numpy().copy(), {k: v.numpy().copy() for k, v in leaves.items()}
+
+
+def reference_module_methods(ours_hps, weights, ids, text_lengths, mels_reduced, z_lengths, eps_post, eps_prior, eps_init, dropout_seed):
+    """The module-level methods VAENAR.call / VAENAR.init reach into (models.py:141-144,216-219), executed by the REFERENCE's own
+    classes: BasePosterior.reparameterize / log_probability (posterior.py:21-72) with nsamples = eps_post.shape[1],
+    TransformerPrior.call / sample / log_probability with training=True and training=False (prior.py:101-169: the flag reaches no
+    training-dependent layer), TransformerPrior.init (prior.py:171-186) with the variables it assigns."""
+    tf, model, leaves = _build(ours_hps, weights)
+    tf.DROPOUT["seed"] = int(dropout_seed)
+    _reset_dropout_calls(model)
+    out = {}
+    tl, zl = tf.constant(text_lengths), tf.constant(z_lengths)
+    text = model.text_encoder(tf.constant(ids), tl, pos_step=1.0, training=False)
+    out["text_embd"] = text.numpy().copy()
+    mu, logvar, _ = model.posterior(tf.constant(np.asarray(mels_reduced, np.float64)), text, src_lengths=tl, target_lengths=zl, training=False)
+    out["mu"], out["logvar"] = mu.numpy().copy(), logvar.numpy().copy()
+    ns = int(np.asarray(eps_post).shape[1])
+    tf.random.queue[:] = [np.asarray(eps_post, np.float64)]
+    samples, eps = model.posterior.reparameterize(mu, logvar, ns)
+    out["samples"], out["eps_back"] = samples.numpy().copy(), eps.numpy().copy()
+    out["lp_eps"] = model.posterior.log_probability(mu, logvar, eps=eps, seq_lengths=zl).numpy().copy()
+    out["lp_z"] = model.posterior.log_probability(mu, logvar, z=samples, seq_lengths=zl).numpy().copy()
+    out["lp_z_nolen"] = model.posterior.log_probability(mu, logvar, z=samples).numpy().copy()
+    samples0, eps0 = model.posterior.reparameterize(mu, logvar, ns, tf.constant(False))
+    out["samples_notrandom"] = samples0.numpy().copy()
+    for flag in (False, True):
+        tag = "train" if flag else "eval"
+        tf.random.queue[:] = [np.asarray(eps_prior, np.float64)]
+        z, lp = model.prior.sample(zl, text, tl, training=flag)
+        out["prior_sample_z_" + tag], out["prior_sample_lp_" + tag] = z.numpy().copy(), lp.numpy().copy()
+        tf.random.queue[:] = [np.asarray(eps_prior, np.float64)]
+        z2, lp2 = model.prior(text, zl, tl, training=flag)
+        out["prior_call_z_" + tag], out["prior_call_lp_" + tag] = z2.numpy().copy(), lp2.numpy().copy()
+        out["prior_logprob_" + tag] = model.prior.log_probability(z, text, z_lengths=zl, condition_lengths=tl, training=flag).numpy().copy()
+    tf.random.queue[:] = [np.asarray(eps_init, np.float64)]
+    zi, lpi = model.prior.init(conditions=text, targets_lengths=zl, condition_lengths=tl, training=True)
+    out["prior_init_z"], out["prior_init_lp"] = zi.numpy().copy(), lpi.numpy().copy()
+    for k, v in leaves.items():
+        if k.startswith("prior/glow/") and (k.endswith("/0/log_scale") or k.endswith("/0/bias")):
+            # ActNormFlow.init assigns the variables (flow.py:194-195): read them from the model, not from the stale leaf table
+            parts = k.split("/")
+            out["init/" + k] = getattr(_resolve(model, parts[:-1]), parts[-1]).numpy().copy()
+    return out

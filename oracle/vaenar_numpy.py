@@ -511,11 +511,15 @@ class Oracle:
         std = np.exp(0.5 * logvar)
         return eps * std[:, None] + mu[:, None], eps
 
-    def posterior_log_probability(self, mu, logvar, eps, seq_lengths):
-        """BasePosterior.log_probability (posterior.py:42-72), eps given."""
+    def posterior_log_probability(self, mu, logvar, eps=None, seq_lengths=None, z=None, epsilon=1e-8):
+        """BasePosterior.log_probability (posterior.py:42-72): eps given, or z given (then the noise is rebuilt as
+        (z - mu) / (std + epsilon), :59-61); seq_lengths None = every frame (:66-68).  [B, nsamples]."""
         dim = mu.shape[2]
+        if eps is None:
+            eps = (z - mu[:, None]) / (np.exp(0.5 * logvar)[:, None] + epsilon)
         tl = -0.5 * (dim * LOG_2PI + (logvar[:, None] + eps ** 2.0).sum(3))
-        mask = sequence_mask(seq_lengths, mu.shape[1])[:, None, :].astype(self.dtype)
+        mask = (sequence_mask(seq_lengths, mu.shape[1])[:, None, :].astype(self.dtype) if seq_lengths is not None
+                else np.ones((mu.shape[0], 1, mu.shape[1]), self.dtype))
         return (mask * tl).sum(2)
 
     # -- models.py -------------------------------------------------------------
@@ -563,10 +567,12 @@ class Oracle:
 
     def call(self, ids, mel_targets, mel_lengths, text_lengths, reduction_factor=2,
              training=False, reduce_loss=True, eps=None):
-        """VAENAR.call (models.py:105-197), n_sample = 1.  eps [B,1,Tz,C] injected."""
-        assert self.hps.Train.num_samples == 1
+        """VAENAR.call (models.py:105-197).  eps [B, n_sample, Tz, C] injected (n_sample = hps.Train.num_samples, models.py:13);
+        decoded outputs and alignments have batch * n_sample rows, sample index inner (models.py:146-178)."""
+        ns = int(self.hps.Train.num_samples)
         rf = reduction_factor
         mel_lengths = np.asarray(mel_lengths)
+        text_lengths = np.asarray(text_lengths)
         mel_targets = np.asarray(mel_targets, self.dtype)
         B, Tm, _ = mel_targets.shape
         reduced_mels = mel_targets[:, ::rf, :]                                     # :123
@@ -580,16 +586,19 @@ class Oracle:
         logvar, mu = self.posterior(reduced_mels, text_embd, text_lengths, reduced_lens, training)
         Tz = reduced_mels.shape[1]
         if eps is None:
-            eps = np.zeros((B, 1, Tz, self.hps.Common.latent_dim), self.dtype)
-        samples, eps = self.reparameterize(mu, logvar, eps.astype(self.dtype))     # :141
-        post_lp = self.posterior_log_probability(mu, logvar, eps, reduced_lens)    # :143-144
-        zs = samples.reshape(B, Tz, -1)
-        initial, outs, ali = self.decoder(zs, text_embd, reduced_lens, text_lengths, rf, training)
+            eps = np.zeros((B, ns, Tz, self.hps.Common.latent_dim), self.dtype)
+        eps = np.asarray(eps, self.dtype).reshape(B, ns, Tz, -1)
+        samples, eps = self.reparameterize(mu, logvar, eps)                        # :141
+        post_lp = self.posterior_log_probability(mu, logvar, eps, reduced_lens)    # :143-144  [B, ns]
+        zs = samples.reshape(B * ns, Tz, -1)                                       # :146-148
+        rep = lambda a: np.repeat(np.asarray(a), ns, axis=0)                       # noqa: E731  tile(expand_dims(x, 1), [1, ns, ...]) -> reshape (:150-178)
+        b_text, b_tgt, b_ml, b_rl, b_tl = rep(text_embd), rep(mel_targets), rep(mel_lengths), rep(reduced_lens), rep(text_lengths)
+        initial, outs, ali = self.decoder(zs, b_text, b_rl, b_tl, rf, training)
         initial, outs = initial[:, :Tm], outs[:, :Tm]                              # :182-183
-        l2 = self.l2_loss(outs, mel_targets, mel_lengths, 1, reduce_loss) + \
-            self.l2_loss(initial, mel_targets, mel_lengths, 1, reduce_loss)        # :184-188
-        prior_lp = self.prior_log_probability(zs, text_embd, reduced_lens, text_lengths)
-        kl = (post_lp - prior_lp.reshape(B, 1)).mean(1)                            # :89-95
+        l2 = self.l2_loss(outs, b_tgt, b_ml, ns, reduce_loss) + \
+            self.l2_loss(initial, b_tgt, b_ml, ns, reduce_loss)                    # :184-188
+        prior_lp = self.prior_log_probability(zs, b_text, b_rl, b_tl)
+        kl = (post_lp - prior_lp.reshape(B, ns)).mean(1)                           # :89-95
         kl = kl.mean() if reduce_loss else kl
         self.last.update(text_embd=text_embd, mu=mu, logvar=logvar, samples=zs,
                          post_lp=post_lp, prior_lp=prior_lp, initial=initial)

@@ -1,0 +1,314 @@
+"""The rest of the reference's Python call surface (VERDICT round 3 "missing" 1, 2, 4).
+
+tests/golden/refshim_b2.npz is produced by /root/reference's own classes over oracle/tf_shim_torch
+(oracle/make_golden.build_ref_b2, oracle/run_reference_on_shim.reference_module_methods):
+  * BasePosterior.reparameterize / log_probability (posterior.py:21-72) with nsamples = 2, TransformerPrior.call / sample /
+    log_probability with training=True and False (prior.py:101-169), TransformerPrior.init (prior.py:171-186);
+  * train_step with hps.Train.num_samples = 2 (models.py:141-178 under training=True + autograd).
+CPU: the fixture is reproducible from the reference (this container only) and the NumPy restatement agrees with it; the Keras
+order of `model.trainable_variables`.  GPU: the HIP path against the fixture -- reference-made numbers, no builder oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.make_golden import SEED, digest, weights_digest
+from vaenar_tts_amd.configs import tiny_hps
+from vaenar_tts_amd.weights import init_weights, is_trainable, weight_spec
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HAVE_REF = os.path.isdir("/root/reference")
+
+
+def _load():
+    with np.load(os.path.join(GOLD, "refshim_b2.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    hps = tiny_hps()
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode(), "synthetic weight generator changed"
+    return g, hps, w
+
+
+def _dig_close(d, ref, n, rel):
+    mx = max(ref[18], 1e-30)
+    return (np.abs(d[:16] - ref[:16]).max() <= rel * mx + 1e-13 and abs(d[16] - ref[16]) <= rel * mx * max(1.0, np.sqrt(n)) * 4 + 1e-12
+            and abs(d[17] - ref[17]) <= rel * max(ref[17], 1e-30) + 1e-13 and abs(d[18] - ref[18]) <= rel * mx + 1e-13)
+
+
+# ---- CPU ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not HAVE_REF, reason="the reference checkout only exists in the build container")
+def test_b2_fixture_is_reproducible_from_the_reference():
+    from oracle.make_golden import build_ref_b2
+    fresh = build_ref_b2()
+    with np.load(os.path.join(GOLD, "refshim_b2.npz")) as z:
+        assert set(z.files) == set(fresh)
+        for k in z.files:
+            assert np.array_equal(z[k], fresh[k]), k
+
+
+def test_reference_flows_ignore_the_training_flag():
+    """prior.sample / call / log_probability with training=True equal training=False in the reference's own Python (no Dropout /
+    BatchNormalization inside the flows) and TransformerPrior.call equals sample (inverse=False: flow.py:39-44)."""
+    g, _, _ = _load()
+    for k in ("prior_sample_z", "prior_sample_lp", "prior_call_z", "prior_call_lp", "prior_logprob"):
+        assert np.array_equal(g["mod/%s_train" % k], g["mod/%s_eval" % k]), k
+    assert np.array_equal(g["mod/prior_call_z_eval"], g["mod/prior_sample_z_eval"])
+    assert np.array_equal(g["mod/prior_call_lp_eval"], g["mod/prior_sample_lp_eval"])
+
+
+def test_numpy_oracle_module_methods_match_reference():
+    from oracle.vaenar_numpy import Oracle
+    g, hps, w = _load()
+    o = Oracle(hps, w, np.float64)
+    mu, logvar, eps = g["mod/mu"], g["mod/logvar"], g["eps_post"].astype(np.float64)
+    zl, tl = g["z_lengths"], g["text_lengths"]
+    samples, _ = o.reparameterize(mu, logvar, eps)
+    assert np.abs(samples - g["mod/samples"]).max() < 1e-12
+    assert np.abs(o.reparameterize(mu, logvar, np.zeros_like(eps))[0] - g["mod/samples_notrandom"]).max() < 1e-12
+    assert np.abs(o.posterior_log_probability(mu, logvar, eps, zl) - g["mod/lp_eps"]).max() < 1e-9
+    assert np.abs(o.posterior_log_probability(mu, logvar, None, zl, z=samples) - g["mod/lp_z"]).max() < 1e-9
+    assert np.abs(o.posterior_log_probability(mu, logvar, None, None, z=samples) - g["mod/lp_z_nolen"]).max() < 1e-9
+    text = g["mod/text_embd"]
+    # (the restatement keeps TensorFlow's float32 positional-encoding table, the shim computes it in float64: 1e-7 apart)
+    z, lp = o.prior_sample(zl, text, tl, g["eps_prior"].astype(np.float64))
+    assert np.abs(z - g["mod/prior_sample_z_eval"]).max() < 2e-6
+    np.testing.assert_allclose(lp, g["mod/prior_sample_lp_eval"], rtol=1e-7)
+    np.testing.assert_allclose(o.prior_log_probability(z, text, zl, tl), g["mod/prior_logprob_eval"], rtol=1e-7)
+    zi, lpi = o.prior_init(zl, text, tl, g["eps_init"].astype(np.float64))
+    assert np.abs(zi - g["mod/prior_init_z"]).max() < 2e-6
+    np.testing.assert_allclose(lpi, g["mod/prior_init_lp"], rtol=1e-7)
+    for k in g:
+        if k.startswith("mod/init/"):
+            assert np.abs(o.w[k[len("mod/init/"):]] - g[k]).max() < 1e-6, k
+
+
+def test_numpy_oracle_n_sample_2_training_forward_matches_reference():
+    """VAENAR.call(training=True) with hps.Train.num_samples = 2 (models.py:141-178): per-utterance terms and the train.py:135 loss."""
+    from oracle.vaenar_numpy import Oracle
+    g, hps, w = _load()
+    hps.Train.num_samples = int(g["n_sample"])
+    o = Oracle(hps, w, np.float64)
+    o.dropout_seed = int(g["dropout_seed"])
+    rf = int(g["reduction_factor"])
+    outs, l2, kl, ll, _ = o.call(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], rf, training=True, reduce_loss=False, eps=g["eps_post"])
+    assert outs.shape[0] == 3 * 2 and np.abs(outs - g["ns2/predictions"]).max() < 1e-5
+    np.testing.assert_allclose(l2, g["ns2/call_l2"], rtol=1e-6)
+    np.testing.assert_allclose(kl, g["ns2/call_kl"], rtol=1e-6)
+    np.testing.assert_allclose(ll, g["ns2/call_length"], rtol=1e-5)
+    sc = g["ns2/kw1/scalars"]
+    loss = l2.mean() + 1.0 * max(kl.mean(), 0.0) + hps.Train.length_weight * ll.mean()
+    np.testing.assert_allclose([loss, l2.mean(), kl.mean(), ll.mean()], sc, rtol=2e-6)
+
+
+def test_trainable_variables_order_is_the_keras_order():
+    """models.VAENAR attaches text_encoder, decoder, length_predictor, posterior, prior (models.py:16-65); a layer lists its own
+    tf.Variables before its sub-layers'; BN moving statistics are not trainable (train.py:136)."""
+    from vaenar_tts_amd.configs import LJHPS
+    from vaenar_tts_amd.variables import keras_variable_order
+    o = keras_variable_order(LJHPS)
+    spec = weight_spec(LJHPS)
+    assert len(o) == len(set(o)) == sum(1 for k in spec if is_trainable(k)) == 485
+    tops = []
+    for p in o:
+        t = p.split("/")[0]
+        if not tops or tops[-1] != t:
+            tops.append(t)
+    assert tops == ["text_encoder", "decoder", "length_predictor", "posterior", "prior"]
+    assert o[0] == "text_encoder/pos_weight" and o[1] == "text_encoder/emb_layer/embeddings"       # encoder.py:64 before the sub-layers
+    i = o.index("prior/glow/0/2/net/pos_weight")
+    assert o[i - 3:i] == ["prior/glow/0/0/log_scale", "prior/glow/0/0/bias", "prior/glow/0/1/weight"]         # prior.py:99, flow.py:160-164
+    assert o[i + 1] == "prior/glow/0/2/net/log_scale_proj/kernel" and o[i + 5] == "prior/glow/0/2/net/pre_projection/kernel"   # transform.py:12-17 before :36
+    allv = keras_variable_order(LJHPS, trainable_only=False)
+    assert allv[:485] == o and all(not is_trainable(p) for p in allv[485:]) and len(allv) == len(spec) == 501
+    assert len(keras_variable_order(LJHPS, include_posterior=False)) == 485 - sum(1 for k in spec if k.startswith("posterior/"))
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def b2_model():
+    from vaenar_tts_amd.models import VAENAR
+    g, hps, w = _load()
+    model = VAENAR(hps, weights=w)
+    yield g, hps, w, model
+    model.engine.close()
+
+
+@pytest.mark.gpu
+def test_posterior_module_methods_match_reference_python(b2_model):
+    """TransformerPosterior.reparameterize / log_probability / sample (posterior.py:21-72,132-138) on the device."""
+    g, hps, w, model = b2_model
+    post = model.posterior
+    rf = int(g["reduction_factor"])
+    text = model.text_encoder(g["ids"], g["text_lengths"], pos_step=1.0, training=False)
+    assert np.abs(text.numpy() - g["mod/text_embd"]).max() < 2e-5
+    mu, logvar, none = post(g["mels"][:, ::rf], text, src_lengths=g["text_lengths"], target_lengths=g["z_lengths"], training=False)
+    assert none is None
+    assert np.abs(mu.numpy() - g["mod/mu"]).max() < 2e-5 and np.abs(logvar.numpy() - g["mod/logvar"]).max() < 2e-5
+    samples, eps = post.reparameterize(g["mod/mu"].astype(np.float32), g["mod/logvar"].astype(np.float32), 2, eps=g["eps_post"])
+    assert samples.shape == g["mod/samples"].shape == eps.shape
+    assert np.abs(samples.numpy() - g["mod/samples"]).max() < 2e-6 and np.array_equal(eps.numpy(), g["eps_post"])
+    s0, e0 = post.reparameterize(g["mod/mu"].astype(np.float32), g["mod/logvar"].astype(np.float32), 2, random=False)
+    assert np.abs(s0.numpy() - g["mod/samples_notrandom"]).max() < 2e-6 and not e0.numpy().any()
+    m32, l32 = g["mod/mu"].astype(np.float32), g["mod/logvar"].astype(np.float32)
+    lp = post.log_probability(m32, l32, eps=g["eps_post"], seq_lengths=g["z_lengths"])
+    np.testing.assert_allclose(lp.numpy(), g["mod/lp_eps"], rtol=2e-6)
+    lpz = post.log_probability(m32, l32, z=g["mod/samples"].astype(np.float32), seq_lengths=g["z_lengths"])
+    np.testing.assert_allclose(lpz.numpy(), g["mod/lp_z"], rtol=3e-6)
+    lpn = post.log_probability(m32, l32, z=g["mod/samples"].astype(np.float32))
+    np.testing.assert_allclose(lpn.numpy(), g["mod/lp_z_nolen"], rtol=3e-6)
+    # random draws: N(0, 1) noise from the device stream, samples consistent with it, log-probability of exactly that noise
+    sr, er = post.reparameterize(mu, logvar, 3)
+    e = er.numpy()
+    assert e.shape == (3, 3, mu.shape[1], mu.shape[2]) and abs(e.mean()) < 0.05 and abs(e.std() - 1.0) < 0.05
+    ref = e * np.exp(0.5 * logvar.numpy())[:, None] + mu.numpy()[:, None]
+    assert np.abs(sr.numpy() - ref).max() < 1e-5
+    # sample(): call -> reparameterize -> log_probability of the noise over the valid frames (the contract of posterior.py:74-87)
+    smp, lps = post.sample(g["mels"][:, ::rf], text, g["z_lengths"], g["text_lengths"], nsamples=2, eps=g["eps_post"])
+    assert np.abs(smp.numpy() - g["mod/samples"]).max() < 5e-5
+    np.testing.assert_allclose(lps.numpy(), g["mod/lp_eps"], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_prior_call_init_and_training_flag_match_reference_python(b2_model):
+    """TransformerPrior.call / sample / log_probability accept training=True (prior.py:101-169), TransformerPrior.init sets the ActNorm
+    variables from the data (prior.py:171-186, flow.py:189-196) and returns (z, logprobs)."""
+    g, hps, w, model = b2_model
+    prior = model.prior
+    text = g["mod/text_embd"].astype(np.float32)
+    zl, tl = g["z_lengths"], g["text_lengths"]
+    for flag in (False, True):
+        z, lp = prior.sample(zl, text, tl, training=flag, eps=g["eps_prior"])
+        assert np.abs(z.numpy() - g["mod/prior_sample_z_eval"]).max() < 5e-5
+        np.testing.assert_allclose(lp.numpy(), g["mod/prior_sample_lp_eval"], rtol=2e-5)
+        z2, lp2 = prior(text, zl, tl, training=flag, eps=g["eps_prior"])
+        assert np.array_equal(z2.numpy(), z.numpy()) and np.array_equal(lp2.numpy(), lp.numpy())
+        lq = prior.log_probability(g["mod/prior_sample_z_eval"].astype(np.float32), text, z_lengths=zl, condition_lengths=tl, training=flag)
+        np.testing.assert_allclose(lq.numpy(), g["mod/prior_logprob_eval"], rtol=2e-5)
+    zi, lpi = prior.init(conditions=text, targets_lengths=zl, condition_lengths=tl, training=True, eps=g["eps_init"])
+    assert np.abs(zi.numpy() - g["mod/prior_init_z"]).max() < 1e-4
+    np.testing.assert_allclose(lpi.numpy(), g["mod/prior_init_lp"], rtol=3e-5)
+    byname = {v.path: v for v in model.trainable_variables}
+    for k in g:
+        if k.startswith("mod/init/"):
+            assert np.abs(byname[k[len("mod/init/"):]].numpy() - g[k]).max() < 2e-5, k
+    # the re-packed engine uses the new variables: sampling again differs from before the init and matches an engine loaded with them
+    z3, _ = prior.sample(zl, text, tl, eps=g["eps_prior"])
+    assert np.abs(z3.numpy() - g["mod/prior_sample_z_eval"]).max() > 1e-3
+    from vaenar_tts_amd.models import VAENAR
+    w2 = dict(w)
+    for k in g:
+        if k.startswith("mod/init/"):
+            w2[k[len("mod/init/"):]] = g[k].astype(np.float32)
+    other = VAENAR(hps, weights=w2)
+    try:
+        z4, _ = other.prior.sample(zl, text, tl, eps=g["eps_prior"])
+        assert np.abs(z3.numpy() - z4.numpy()).max() < 1e-4
+    finally:
+        other.engine.close()
+
+
+@pytest.mark.gpu
+def test_trainable_variables_views(b2_model):
+    """model.trainable_variables (train.py:136-137): ordered views with .name / .numpy() / .assign(); an assign reaches the next
+    module call without an explicit re-pack; gradients of the last step through the same views."""
+    from vaenar_tts_amd.models import VAENAR
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.variables import keras_variable_order
+    g, hps, w, model = b2_model
+    tv = model.trainable_variables
+    assert [v.path for v in tv] == keras_variable_order(hps) and all(v.trainable for v in tv)
+    assert len(model.variables) == len(w) and len(model.non_trainable_variables) == len(w) - len(tv)
+    assert [v.path for v in model.text_encoder.trainable_variables] == [p for p in keras_variable_order(hps) if p.startswith("text_encoder/")]
+    for v in tv[:40] + tv[-40:]:
+        assert v.name == v.path + ":0" and v.shape == tuple(np.shape(w[v.path])) and np.array_equal(v.numpy(), w[v.path])
+    b = make_batch(2, 9, 24, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, temperature=1.0,
+                   text_step=2, mel_step=5)
+    mel0, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])
+    mel0 = mel0.numpy()
+    r = np.random.Generator(np.random.PCG64(5))
+    w2 = dict(w)
+    byname = {v.path: v for v in model.variables}
+    for p in ("decoder/out_projection/kernel", "prior/glow/1/0/log_scale", "text_encoder/pos_weight", "prior/glow/2/1/weight",
+              "decoder/postnet/conv_stack/0/bn/moving_mean", "decoder/attentions/0/ffn/dense1/bias"):
+        new = (np.asarray(w[p]) + 0.05 * r.standard_normal(np.shape(w[p]))).astype(np.float32)
+        byname[p].assign(new)
+        w2[p] = new
+        assert np.array_equal(byname[p].numpy(), new)
+    mel1, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])       # no finalize call in between
+    other = VAENAR(hps, weights=w2)
+    try:
+        mel2, _ = other.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])
+        assert np.abs(mel1.numpy() - mel0).max() > 1e-3
+        assert np.abs(mel1.numpy() - mel2.numpy()).max() < 1e-5
+    finally:
+        other.engine.close()
+    with pytest.raises(ValueError):
+        byname["decoder/out_projection/kernel"].assign(np.zeros((3, 3), np.float32))
+    # gradients through the views == model.gradients()
+    rr = np.random.Generator(np.random.PCG64(6))
+    mels = rr.standard_normal((2, 24, hps.Audio.num_mels)).astype(np.float32)
+    eps = rr.standard_normal((2, 12, hps.Common.latent_dim)).astype(np.float32)
+    model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, eps=eps, dropout_seed=3, apply_update=False)
+    gr = model.gradients()
+    for v in model.trainable_variables[::7]:
+        assert np.array_equal(v.gradient(), gr[v.path])
+
+
+@pytest.mark.gpu
+def test_n_sample_2_train_step_matches_reference_python(b2_model):
+    """train_step with hps.Train.num_samples = 2 (models.py:141-178, train.py:127-138): scalars, predictions and the gradient of every
+    trainable variable against the reference's own Python under autograd."""
+    g, hps, w, model = b2_model
+    rf, seed, ns = int(g["reduction_factor"]), int(g["dropout_seed"]), int(g["n_sample"])
+    model.n_sample = ns
+    for tag, kw in (("kw1", 1.0), ("kw1e-5", 1e-5)):
+        loss, l2, kl, ll = model.train_step(g["ids"], g["mels"], g["text_lengths"], g["mel_lengths"], kw, rf, eps=g["eps_post"],
+                                            dropout_seed=seed, apply_update=False)
+        np.testing.assert_allclose([loss, l2, kl, ll], g["ns2/%s/scalars" % tag], rtol=2e-4)
+        grads = model.gradients()
+        worst = 0.0
+        bad = []
+        for k, a in grads.items():           # the criterion of tests/test_refshim_train.py (gradients that are analytically zero -- a conv bias in
+            d, rd = digest(a), g["ns2/%s/gdig/%s" % (tag, k)]      # front of a BatchNormalization -- are rounding noise on both sides)
+            mx = max(rd[18], 1e-30)
+            ok = (np.abs(d[:16] - rd[:16]).max() <= 2e-3 * mx + 1e-7 and abs(d[17] - rd[17]) <= 2e-3 * rd[17] + 1e-7
+                  and abs(d[18] - rd[18]) <= 2e-3 * mx + 1e-7)
+            full = g.get("ns2/kw1/grad/" + k) if tag == "kw1" else None
+            if ok and full is not None:
+                ok = np.abs(a - full).max() <= 2e-3 * np.abs(full).max() + 1e-7
+                worst = max(worst, float(np.abs(a - full).max() / max(np.abs(full).max(), 1e-6)))
+            if not ok:
+                bad.append(k)
+        assert not bad, (tag, bad[:10])
+        print("n_sample 2, kl weight %g: worst small-variable gradient error %.2e of the variable's max" % (kw, worst))
+    outs, l2v, klv, llv, ali = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=rf, training=True,
+                                     reduce_loss=False, eps=g["eps_post"], dropout_seed=seed)
+    assert outs.shape == g["ns2/predictions"].shape and np.abs(outs.numpy() - g["ns2/predictions"]).max() < 2e-4
+    np.testing.assert_allclose(l2v.numpy(), g["ns2/call_l2"], rtol=1e-4)
+    np.testing.assert_allclose(klv.numpy(), g["ns2/call_kl"], rtol=1e-3, atol=6e-2)
+    np.testing.assert_allclose(llv.numpy(), g["ns2/call_length"], rtol=1e-3, atol=1e-7)
+    assert all(a.shape[0] == 3 * ns for a in ali.values())
+    # n_sample = 1 afterwards: the option does not stick to the handle
+    model.n_sample = 1
+    o1, *_ = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=rf, training=False, eps=g["eps_post"][:, 0])
+    assert o1.shape[0] == 3
+
+
+@pytest.mark.gpu
+def test_training_flag_does_not_stick_after_a_failing_call(b2_model):
+    """A module call that fails in training mode must not leave the handle with Dropout / batch statistics on."""
+    from vaenar_tts_amd._lib import VnrError
+    from vaenar_tts_amd.synthetic import make_batch
+    g, hps, w, model = b2_model
+    b = make_batch(2, 9, 24, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, temperature=1.0,
+                   text_step=2, mel_step=5)
+    mel0, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])
+    z = np.zeros((2, 12, hps.Common.latent_dim), np.float32)
+    text = g["mod/text_embd"].astype(np.float32)[:2]
+    with pytest.raises(VnrError):
+        model.decoder(z, text, b["mel_lengths"] // 2, g["text_lengths"][:2], reduction_factor=99, training=True, dropout_seed=1)
+    with pytest.raises(VnrError):
+        model(b["ids"], np.zeros((2, 24, hps.Audio.num_mels), np.float32), b["mel_lengths"], b["text_lengths"], reduction_factor=99,
+              training=True, eps=np.zeros((2, 1, 1, hps.Common.latent_dim), np.float32))
+    mel1, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])
+    assert np.array_equal(mel0.numpy(), mel1.numpy())

@@ -327,9 +327,9 @@ def test_n_sample_2_matches_reference_python():
         outs, l2, kl, ll, ali = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,
                                       reduce_loss=False, eps=g["eps"])
         assert outs.shape == g["outs"].shape and np.abs(outs.numpy() - g["outs"]).max() < 2e-4
-        np.testing.assert_allclose(l2, g["l2"], rtol=1e-4)
-        np.testing.assert_allclose(ll, g["length"], rtol=1e-3, atol=1e-7)
-        np.testing.assert_allclose(kl, g["kl"], rtol=1e-3, atol=6e-2)
+        np.testing.assert_allclose(l2.numpy(), g["l2"], rtol=1e-4)
+        np.testing.assert_allclose(ll.numpy(), g["length"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(kl.numpy(), g["kl"], rtol=1e-3, atol=6e-2)
         for k in ali:
             np.testing.assert_allclose(ali[k].numpy(), g["ali_" + k], atol=1e-5)
         _, l2m, klm, llm, _ = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,

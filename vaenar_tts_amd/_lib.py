@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
 
@@ -84,6 +84,9 @@ PROTOTYPES = {
     "vnr_posterior_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "vnr_inference": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "vnr_prior_log_probability": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "vnr_posterior_reparameterize": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "vnr_posterior_log_probability": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "vnr_prior_init": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "vnr_elbo_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnr_op_dense": [_vp, C.POINTER(vnr_dense_desc)],
     "vnr_op_conv1d_bn": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
@@ -105,6 +108,7 @@ PROTOTYPES = {
     "vnr_comm_unique_id": [_vp, C.c_char_p],
     "vnr_comm_init": [_vp, _i, _i, C.c_char_p],
     "vnr_comm_broadcast_weights": [_vp],
+    "vnr_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "vnr_comm_destroy": [_vp],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
@@ -314,6 +318,10 @@ class Engine:
         check(self.lib.vnr_set_weight(self.handle, path.encode(), a.ctypes.data, shape, a.ndim), self.handle)
         self._weights_loaded.add(path)
 
+    def has_posterior(self):
+        """False for an inference-only weight set (no posterior/ variables were uploaded)."""
+        return not self._weights_loaded or any(p.startswith("posterior/") for p in self._weights_loaded)
+
     def get_weight(self, path, shape):
         out = np.empty(shape, np.float32)
         check(self.lib.vnr_get_weight(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
@@ -331,6 +339,12 @@ class Engine:
 
     def comm_broadcast_weights(self):
         check(self.lib.vnr_comm_broadcast_weights(self.handle), self.handle)
+
+    def comm_info(self):
+        """(nranks, rank) of the bound communicator as RCCL reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r = C.c_int(0), C.c_int(0)
+        check(self.lib.vnr_comm_info(self.handle, C.byref(n), C.byref(r)), self.handle)
+        return n.value, r.value
 
     def comm_destroy(self):
         check(self.lib.vnr_comm_destroy(self.handle), self.handle)

@@ -30,7 +30,7 @@ __device__ __forceinline__ float fast_tanhf(float x) {
   const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
   const float x2 = ax * ax;
   const float small = ax * (1.f + x2 * (-0.333333333333f + x2 * (0.133333333333f + x2 * -0.0539682539683f)));
-  return copysignf(ax < 0.125f ? small : big, x);
+  return (x != x) ? x : copysignf(ax < 0.125f ? small : big, x);       // NaN propagates like tf.nn.tanh (fminf would have clamped it to +-1)
 }
 #endif
 
@@ -306,6 +306,13 @@ hipError_t launch_reparam(const float* mu, const float* logvar, const float* eps
                           float* row_lp, hipStream_t s);
 hipError_t launch_sqerr_rows(const float* rec, int rec_T, const float* tgt, int T, int B, int C, float* rows,
                              hipStream_t s);
+// n_sample > 1 (models.py:146-178): dst[(b * ns + s) * n + i] = src[b * n + i] (4-byte words), and the gradient of that tiling
+hipError_t launch_tile_rows(const void* src, size_t n_words, int B, int ns, void* dst, hipStream_t s);
+hipError_t launch_tile_sum(const float* src, size_t n, int B, int ns, float scale, int accumulate, float* dst, hipStream_t s);
+// BasePosterior.reparameterize / log_probability rows with nsamples (posterior.py:21-72); see misc.hip
+hipError_t launch_posterior_rows(const float* mu, const float* logvar, const float* eps, const float* zin, int B, int ns, int T, int C,
+                                 float epsilon, float* z_out, float* row_lp, hipStream_t s);
+hipError_t launch_group_mean(const float* x, int B, int ns, float* out, hipStream_t s);
 hipError_t launch_elbo_scalars(const float* sum_out, const float* sum_init, const int32_t* mel_len,
                                const float* pred_len, const float* post_lp, const float* prior_lp, int B,
                                float* l2, float* length_l2, float* kl, hipStream_t s);
@@ -399,7 +406,7 @@ hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float*
 hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s);
 hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s);
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
-                              const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
+                              const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw, float* g_post, float* g_prior,
                               float* cg, float* scalars, hipStream_t s);
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
 struct TransposeJobHost { const float* in; float* out; int rows, cols; };      // same layout as the device-side job record

@@ -140,6 +140,8 @@ struct vnr_context {
   bool split_encoder = true;     // engine option "split_encoder": the text encoder uses the split path too (measured as accurate as exact fp32: profiles/r01_split_accuracy.txt)
   bool op_dense_split = false;   // engine option "op_dense_split" (kernel-level tests of the split path)
   bool training = false;         // engine option "training": Dropout active, BatchNormalization on batch statistics (+ moving update)
+  int n_sample = 1;              // engine option "n_sample": hps.Train.num_samples of VAENAR.call (models.py:13,141-178) for vnr_elbo_fwd / vnr_train_step
+  bool deterministic = false;    // engine option "deterministic": TF_DETERMINISTIC_OPS=1 of train.py:17-32 -- no float atomics in the training step
   unsigned drop_seed = 0;        // engine option "dropout_seed"
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
@@ -938,11 +940,12 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
 // of its input (ActNormFlow.init, flow.py:189-196) -- written straight into the weight store.  Runs unfolded (the folded
 // panels are rebuilt by the caller afterwards).
 int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B,
-                    int Tz, int Tt, const float* eps, float* z_out) {
+                    int Tz, int Tt, const float* eps, float* z_out, float* logprobs = nullptr) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
   WS(za, (size_t)M * C); WS(zb, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C);
-  WS(stat, (size_t)4 * C + C); WS(wt, (size_t)C * C);
+  WS(stat, (size_t)4 * C + C); WS(wt, (size_t)C * C); WS(rowld, (size_t)M); WS(lsum, (size_t)64 + 2 * C);
+  if (logprobs) RUN_MISC(h, launch_gauss_logprob(eps, z_len, B, Tz, C, logprobs, h->stream));      // _initial_sample (prior.py:36-41)
   double* mean = reinterpret_cast<double*>(stat);
   double* sq = mean + C;
   float* sc = stat + 4 * C;
@@ -961,6 +964,11 @@ int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, co
     RUN_MISC(h, launch_col_sum(zc, M, C, C, mean, sq, h->stream));
     RUN_MISC(h, launch_actnorm_init_finish(mean, sq, M, C, f.an_log_scale, f.an_bias, sc, h->stream));
     RUN_MISC(h, launch_rowop(zc, M, C, sc, f.an_bias, nullptr, 1, 0.f, 0.f, 0u, zc, h->stream));       // z * exp(ls) + b
+    if (logprobs) {        // logprobs -= len * sum(log_scale) (the NEW variables, flow.py:166-175) + len * log|det W| (flow.py:127-135)
+      RUN_MISC(h, launch_actnorm_inv_params(f.an_log_scale, f.an_bias, C, lsum + 64, lsum + 64 + C, lsum, h->stream));
+      RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lsum, -1.f, B, h->stream));
+      RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)(-f.lin_logdet), B, h->stream));
+    }
     // InvertibleLinear forward z . W on the exact fp32 path (flow.py:123-135)
     RUN_MISC(h, launch_transpose(f.lin_w, C, C, wt, C, h->stream));
     GemmArgs g;
@@ -983,7 +991,8 @@ int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, co
       g.C = heads; g.ldc = C; g.M = M; g.N = C;
       TRY(run_gemm(h, g));
     }
-    RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, nullptr, h->stream));
+    RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, logprobs ? rowld : nullptr, h->stream));
+    if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));
     std::swap(zc, zn);
   }
   HIP_TRY(h, hipMemcpyAsync(z_out, zc, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -1293,7 +1302,9 @@ int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int6
   for (int i = 0; i < ndim; ++i) { if (shape[i] <= 0) return fail(h, VNR_ERR_ARG, "bad shape"); n *= shape[i]; shp.push_back(shape[i]); }
   // optimizer state and gradient tables point into the weight store: they survive an in-place update of an existing variable
   // (a checkpoint restore), but not a new or resized one
-  if (h->train) { auto it = h->w.find(path); if (it == h->w.end() || it->second.n != n || it->second.shape != shp) train_free(h); }
+  bool in_place = false;
+  { auto it = h->w.find(path); in_place = it != h->w.end() && it->second.d && it->second.n == n && it->second.shape == shp; }
+  if (h->train && !in_place) train_free(h);
   Tensor& t = h->w[path];
   if (t.d && t.n != n) { hipFree(t.d); t.d = nullptr; }
   if (!t.d) HIP_TRY(h, hipMalloc((void**)&t.d, (size_t)n * sizeof(float)));
@@ -1301,7 +1312,11 @@ int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int6
   if (n == 1) t.scalar = host[0];
   HIP_TRY(h, hipMemcpyAsync(t.d, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  h->finalized = false;
+  // a variable of the SAME shape updated in place on a finalized engine (tf.Variable.assign, model.trainable_variables): every
+  // pointer of the packed model stays valid, the packed panels are rebuilt lazily by the next call (check_ready), like after an
+  // optimizer step.  A new or resized variable needs an explicit vnr_finalize_weights.
+  if (in_place && h->finalized) h->packed_stale = true;
+  else h->finalized = false;
   h->derived_fresh = false;
   return VNR_OK;
 }
@@ -1318,6 +1333,8 @@ int vnr_finalize_weights(vnr_handle h) {
   if (!h) return fail(h, VNR_ERR_ARG, "null handle");
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->packed_stale = false;
+  for (auto& kv : h->w) if (kv.second.n == 1 && kv.second.d) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
   for (auto p : h->packed_allocs) hipFree(p);
   h->packed_allocs.clear();
   for (auto p : h->split_allocs) hipFree(p);
@@ -1589,6 +1606,48 @@ int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_tex
   return prior_logprob_body(h, zc, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_logprobs);
 }
 
+// BasePosterior.reparameterize (posterior.py:21-39): samples [B, ns, T, C] = eps * exp(0.5 logvar) + mu; d_eps [B, ns, T, C] is the
+// noise (the caller draws it with vnr_random_normal) or NULL = zeros (`random=False`).
+int vnr_posterior_reparameterize(vnr_handle h, const float* d_mu, const float* d_logvar, const float* d_eps, int B, int nsamples, int T,
+                                 float* d_samples) {
+  if (!h || !d_mu || !d_logvar || !d_samples || B <= 0 || nsamples <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  RUN_MISC(h, launch_posterior_rows(d_mu, d_logvar, d_eps, nullptr, B, nsamples, T, h->cfg.latent_dim, 0.f, d_samples, nullptr, h->stream));
+  return VNR_OK;
+}
+// BasePosterior.log_probability (posterior.py:42-72): d_logprobs [B, ns] = sum_{t < len} -0.5 (C log 2pi + sum_c (logvar + n^2)), n = eps
+// when given, else (z - mu) / (exp(0.5 logvar) + epsilon); d_lengths NULL = every frame.
+int vnr_posterior_log_probability(vnr_handle h, const float* d_mu, const float* d_logvar, const float* d_z, const float* d_eps,
+                                  const int32_t* d_lengths, int B, int nsamples, int T, float epsilon, float* d_logprobs) {
+  if (!h || !d_mu || !d_logvar || !d_logprobs || (!d_z && !d_eps) || B <= 0 || nsamples <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  ws_reset(h);
+  const int Bt = B * nsamples;
+  WS(rowlp, (size_t)Bt * T);
+  RUN_MISC(h, launch_posterior_rows(d_mu, d_logvar, d_eps, d_z, B, nsamples, T, h->cfg.latent_dim, epsilon, nullptr, rowlp, h->stream));
+  const int32_t* len = d_lengths;
+  if (d_lengths && nsamples > 1) {
+    WS(lt, (size_t)Bt);
+    RUN_MISC(h, launch_tile_rows(d_lengths, 1, B, nsamples, lt, h->stream));
+    len = reinterpret_cast<const int32_t*>(lt);
+  }
+  RUN_MISC(h, launch_masked_row_reduce(rowlp, len, Bt, T, 1.0f, d_logprobs, 0, h->stream));
+  return VNR_OK;
+}
+// TransformerPrior.init (prior.py:171-186): like sample(), but every ActNormFlow first takes log_scale / bias from the statistics of its
+// input (flow.py:189-196).  The variables in the weight store are updated and all packed panels rebuilt.  d_logprobs [B] may be NULL.
+int vnr_prior_init(vnr_handle h, const int32_t* d_z_lengths, const float* d_text_embd, const int32_t* d_text_lengths, int B, int Tz, int Tt,
+                   const float* d_eps, float* d_z, float* d_logprobs) {
+  TRY(check_ready(h));
+  if (!d_z_lengths || !d_text_embd || !d_z || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
+  ws_reset(h);
+  WS(kv, (size_t)B * Tt * h->prior_kv_n);
+  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
+  h->derived_fresh = false;
+  TRY(prior_init_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs));
+  return vnr_finalize_weights(h);
+}
+
 int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
                  const int32_t* d_mel_lengths, const int32_t* d_reduced_lengths, int B, int Tt, int Tm, int rf,
                  float pos_step, const float* d_eps, float* d_outs, float* d_l2, float* d_kl, float* d_length_l2,
@@ -1602,10 +1661,11 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
   const vnr_config& c = h->cfg;
   const int Dm = c.enc_pre_hidden, C = c.latent_dim, od = c.output_dim;
   const int Tz = (Tm + rf - 1) / rf;                                   // mel_targets[:, ::rf, :] (models.py:123)
+  const int ns = h->n_sample, Bt = B * ns;                             // models.py:141-178: everything after the posterior runs on batch * n_sample rows
   if (c.num_mels != od) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");
   WS(text_embd, (size_t)B * Tt * Dm);
   TRY(encoder_body(h, d_ids, d_text_lengths, B, Tt, pos_step, text_embd));
-  WS(pred, (size_t)B);
+  WS(pred, (size_t)Bt);
   RUN_MISC(h, launch_length_predictor(text_embd, h->lp_w, h->lp_b, d_text_lengths, B, Tt, Dm, c.lenpred_activation, pred, h->stream));
   // reduced mels: frames 0, rf, 2rf, ... (strided copy, rows of num_mels floats)
   WS(rmel, (size_t)B * Tz * c.num_mels);
@@ -1613,36 +1673,57 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
     HIP_TRY(h, hipMemcpy2DAsync(rmel + (size_t)b * Tz * c.num_mels, (size_t)c.num_mels * 4, d_mel_targets + (size_t)b * Tm * c.num_mels,
                                 (size_t)rf * c.num_mels * 4, (size_t)c.num_mels * 4, Tz, hipMemcpyDeviceToDevice, h->stream));
   // posterior (first head is USED as logvar, second as mu: models.py:136 vs posterior.py:130)
-  const int kvn = h->post_kv_n + h->prior_kv_n + h->dec_kv_n;
   WS(kvp, (size_t)B * Tt * h->post_kv_n);
   TRY(run_kv(h, text_embd, B, Tt, Dm, h->post_kv_wt, h->post_kv_n, kvp, h->cfg.post_attention_dim));
-  WS(kv, (size_t)B * Tt * (h->prior_kv_n + h->dec_kv_n));
-  TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n + h->dec_kv_n, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
-  (void)kvn;
   WS(head1, (size_t)B * Tz * C); WS(head2, (size_t)B * Tz * C);
   TRY(posterior_body(h, rmel, kvp, h->post_kv_n, d_text_lengths, d_reduced_lengths, B, Tz, Tt, head1, head2));
   const float* logvar = head1; const float* mu = head2;
-  WS(z, (size_t)B * Tz * C); WS(rowlp, (size_t)B * Tz); WS(post_lp, (size_t)B);
-  RUN_MISC(h, launch_reparam(mu, logvar, d_eps, B * Tz, C, z, rowlp, h->stream));
-  RUN_MISC(h, launch_masked_row_reduce(rowlp, d_reduced_lengths, B, Tz, 1.0f, post_lp, 0, h->stream));
-  // decoder on the samples, cropped to the target length (models.py:179-183)
-  WS(dinit, (size_t)B * Tz * rf * od); WS(douts, (size_t)B * Tz * rf * od);
+  // n_sample > 1: text encoding, targets and lengths tiled n_sample times, sample index inner (models.py:149-178)
+  const float* text_t = text_embd; const float* mel_t = d_mel_targets;
+  const int32_t *tl_t = d_text_lengths, *rl_t = d_reduced_lengths, *ml_t = d_mel_lengths;
+  if (ns > 1) {
+    WS(tt, (size_t)Bt * Tt * Dm); WS(mt, (size_t)Bt * Tm * od); WS(lens, (size_t)3 * Bt + 64); WS(pt, (size_t)Bt);
+    RUN_MISC(h, launch_tile_rows(text_embd, (size_t)Tt * Dm, B, ns, tt, h->stream));
+    RUN_MISC(h, launch_tile_rows(d_mel_targets, (size_t)Tm * od, B, ns, mt, h->stream));
+    int32_t* li = reinterpret_cast<int32_t*>(lens);
+    if (d_text_lengths) RUN_MISC(h, launch_tile_rows(d_text_lengths, 1, B, ns, li, h->stream));
+    RUN_MISC(h, launch_tile_rows(d_reduced_lengths, 1, B, ns, li + Bt, h->stream));
+    RUN_MISC(h, launch_tile_rows(d_mel_lengths, 1, B, ns, li + 2 * Bt, h->stream));
+    RUN_MISC(h, launch_tile_rows(pred, 1, B, ns, pt, h->stream));
+    text_t = tt; mel_t = mt; tl_t = d_text_lengths ? li : nullptr; rl_t = li + Bt; ml_t = li + 2 * Bt; pred = pt;
+  }
   const int kv_ld = h->prior_kv_n + h->dec_kv_n;
-  TRY(decoder_body(h, z, kv + h->prior_kv_n, kv_ld, d_reduced_lengths, d_text_lengths, B, Tz, Tt, rf, dinit, douts, d_alignments));
-  HIP_TRY(h, hipMemcpy2DAsync(d_outs, (size_t)Tm * od * 4, douts, (size_t)Tz * rf * od * 4, (size_t)Tm * od * 4, B, hipMemcpyDeviceToDevice, h->stream));
-  WS(rows, (size_t)B * Tm); WS(sum_out, (size_t)B); WS(sum_init, (size_t)B);
-  RUN_MISC(h, launch_sqerr_rows(douts, Tz * rf, d_mel_targets, Tm, B, od, rows, h->stream));
-  RUN_MISC(h, launch_masked_row_reduce(rows, d_mel_lengths, B, Tm, 1.0f, sum_out, 0, h->stream));
-  RUN_MISC(h, launch_sqerr_rows(dinit, Tz * rf, d_mel_targets, Tm, B, od, rows, h->stream));
-  RUN_MISC(h, launch_masked_row_reduce(rows, d_mel_lengths, B, Tm, 1.0f, sum_init, 0, h->stream));
+  WS(kv, (size_t)Bt * Tt * kv_ld);
+  TRY(run_kv(h, text_t, Bt, Tt, Dm, h->prior_kv_wt, kv_ld, kv, (h->cfg.prior_attention_dim == h->cfg.dec_attention_dim ? h->cfg.prior_attention_dim : 0)));
+  WS(z, (size_t)Bt * Tz * C); WS(rowlp, (size_t)Bt * Tz); WS(post_lp, (size_t)Bt);
+  if (ns > 1) RUN_MISC(h, launch_posterior_rows(mu, logvar, d_eps, nullptr, B, ns, Tz, C, 0.f, z, rowlp, h->stream));
+  else RUN_MISC(h, launch_reparam(mu, logvar, d_eps, B * Tz, C, z, rowlp, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rowlp, rl_t, Bt, Tz, 1.0f, post_lp, 0, h->stream));
+  // decoder on the samples, cropped to the target length (models.py:179-183)
+  WS(dinit, (size_t)Bt * Tz * rf * od); WS(douts, (size_t)Bt * Tz * rf * od);
+  TRY(decoder_body(h, z, kv + h->prior_kv_n, kv_ld, rl_t, tl_t, Bt, Tz, Tt, rf, dinit, douts, d_alignments));
+  HIP_TRY(h, hipMemcpy2DAsync(d_outs, (size_t)Tm * od * 4, douts, (size_t)Tz * rf * od * 4, (size_t)Tm * od * 4, Bt, hipMemcpyDeviceToDevice, h->stream));
+  WS(rows, (size_t)Bt * Tm); WS(sum_out, (size_t)Bt); WS(sum_init, (size_t)Bt);
+  RUN_MISC(h, launch_sqerr_rows(douts, Tz * rf, mel_t, Tm, Bt, od, rows, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rows, ml_t, Bt, Tm, 1.0f, sum_out, 0, h->stream));
+  RUN_MISC(h, launch_sqerr_rows(dinit, Tz * rf, mel_t, Tm, Bt, od, rows, h->stream));
+  RUN_MISC(h, launch_masked_row_reduce(rows, ml_t, Bt, Tm, 1.0f, sum_init, 0, h->stream));
   // prior log-probability of the samples (z is consumed)
-  WS(prior_lp, (size_t)B);
-  TRY(prior_logprob_body(h, z, d_reduced_lengths, d_text_lengths, kv, kv_ld, B, Tz, Tt, prior_lp));
-  RUN_MISC(h, launch_elbo_scalars(sum_out, sum_init, d_mel_lengths, pred, post_lp, prior_lp, B, d_l2, d_length_l2, d_kl, h->stream));
-  if (d_aux) {   // [pred_lengths | posterior_logprobs | prior_logprobs], B floats each (diagnostics / tests)
-    HIP_TRY(h, hipMemcpyAsync(d_aux, pred, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_aux + B, post_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_aux + 2 * (size_t)B, prior_lp, (size_t)B * 4, hipMemcpyDeviceToDevice, h->stream));
+  WS(prior_lp, (size_t)Bt);
+  TRY(prior_logprob_body(h, z, rl_t, tl_t, kv, kv_ld, Bt, Tz, Tt, prior_lp));
+  if (ns > 1) {          // per-utterance terms = means over the samples (models.py:79-83,90)
+    WS(l2t, (size_t)Bt); WS(llt, (size_t)Bt); WS(klt, (size_t)Bt);
+    RUN_MISC(h, launch_elbo_scalars(sum_out, sum_init, ml_t, pred, post_lp, prior_lp, Bt, l2t, llt, klt, h->stream));
+    RUN_MISC(h, launch_group_mean(l2t, B, ns, d_l2, h->stream));
+    RUN_MISC(h, launch_group_mean(llt, B, ns, d_length_l2, h->stream));
+    RUN_MISC(h, launch_group_mean(klt, B, ns, d_kl, h->stream));
+  } else {
+    RUN_MISC(h, launch_elbo_scalars(sum_out, sum_init, d_mel_lengths, pred, post_lp, prior_lp, B, d_l2, d_length_l2, d_kl, h->stream));
+  }
+  if (d_aux) {   // [pred_lengths (B) | posterior_logprobs (B * n_sample) | prior_logprobs (B * n_sample)] (diagnostics / tests)
+    HIP_TRY(h, hipMemcpy2DAsync(d_aux, 4, pred, (size_t)ns * 4, 4, B, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_aux + B, post_lp, (size_t)Bt * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_aux + B + (size_t)Bt, prior_lp, (size_t)Bt * 4, hipMemcpyDeviceToDevice, h->stream));
   }
   if (h->training) TRY(refresh_bn_affine(h));     // the moving statistics moved
   return VNR_OK;
@@ -1709,6 +1790,15 @@ int vnr_comm_broadcast_weights(vnr_handle h) {
   h->derived_fresh = false;
   for (auto& kv : h->w) if (kv.second.n == 1) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
   return vnr_finalize_weights(h);
+}
+// rank count and rank of the bound communicator AS RCCL REPORTS THEM (ncclCommCount / ncclCommUserRank), not the launcher's environment
+int vnr_comm_info(vnr_handle h, int* nranks, int* rank) {
+  if (!h || !nranks || !rank) return fail(h, VNR_ERR_ARG, "null argument");
+  if (!h->comm) return fail(h, VNR_ERR_STATE, "communicator not initialised");
+  if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(h, VNR_ERR_STATE, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+  RCCL_TRY(h, g_rccl.CommCount(h->comm, nranks));
+  RCCL_TRY(h, g_rccl.CommUserRank(h->comm, rank));
+  return VNR_OK;
 }
 int vnr_comm_destroy(vnr_handle h) {
   if (!h) return VNR_OK;
@@ -1977,6 +2067,8 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "op_dense_split")) { h->op_dense_split = value != 0; return VNR_OK; }
   if (!strcmp(name, "training")) { h->training = value != 0; return VNR_OK; }
   if (!strcmp(name, "dropout_seed")) { h->drop_seed = (unsigned)value; return VNR_OK; }
+  if (!strcmp(name, "n_sample")) { if (value < 1 || value > 64) return fail(h, VNR_ERR_ARG, "n_sample: 1..64"); h->n_sample = value; return VNR_OK; }
+  if (!strcmp(name, "deterministic")) { h->deterministic = value != 0; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }
 

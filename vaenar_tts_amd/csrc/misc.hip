@@ -745,6 +745,82 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
 // pairs: u = ((x >> 8) + 0.5) 2^-24 in (0, 1), r = sqrt(-2 ln u_a), theta = 2 pi u_b -> r cos(theta), r sin(theta).  Same
 // statement in oracle/vaenar_numpy.py (philox_normal).  TensorFlow's own Philox stream layout is not reproduced (its op-level
 // seeding is unavailable without TensorFlow): parity runs inject eps, this generator serves temperature > 0 runs.
+// ---- n_sample > 1 (models.py:146-178): the reference tiles the text encoding, targets and lengths n_sample times (sample index inner)
+// dst[(b * ns + s) * n + i] = src[b * n + i]   (n 4-byte words per batch element; floats and int32 lengths alike)
+__global__ void __launch_bounds__(256) tile_rows_kernel(const uint32_t* __restrict__ src, size_t n, int B, int ns, uint32_t* __restrict__ dst) {
+  const size_t total = (size_t)B * ns * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / n, b = row / ns;
+    dst[i] = src[b * n + (i - row * n)];
+  }
+}
+hipError_t launch_tile_rows(const void* src, size_t n_words, int B, int ns, void* dst, hipStream_t s) {
+  const size_t total = (size_t)B * ns * n_words;
+  if (!total) return hipSuccess;
+  size_t blocks = (total + 1023) / 1024; if (blocks > 4096) blocks = 4096;
+  vnr_launch(tile_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint32_t*>(src), n_words, B, ns, static_cast<uint32_t*>(dst));
+  return hipGetLastError();
+}
+// the gradient of that tiling: dst[b * n + i] (+)= scale * sum_s src[(b * ns + s) * n + i], samples added in index order (deterministic)
+__global__ void __launch_bounds__(256) tile_sum_kernel(const float* __restrict__ src, size_t n, int B, int ns, float scale, int accumulate, float* __restrict__ dst) {
+  const size_t total = (size_t)B * n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / n, c = i - b * n;
+    float acc = 0.f;
+    for (int k = 0; k < ns; ++k) acc += src[(b * ns + k) * n + c];
+    dst[i] = accumulate ? dst[i] + scale * acc : scale * acc;
+  }
+}
+hipError_t launch_tile_sum(const float* src, size_t n, int B, int ns, float scale, int accumulate, float* dst, hipStream_t s) {
+  const size_t total = (size_t)B * n;
+  if (!total) return hipSuccess;
+  size_t blocks = (total + 1023) / 1024; if (blocks > 4096) blocks = 4096;
+  vnr_launch(tile_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, B, ns, scale, accumulate, dst);
+  return hipGetLastError();
+}
+
+// ---- BasePosterior.reparameterize / log_probability with nsamples (posterior.py:21-72): row m' = (b * ns + s) * T + t reads mu / logvar
+// row b * T + t.  samples = eps * exp(0.5 logvar) + mu (NULL eps = zeros, the `random=False` branch); row_lp[m'] = -0.5 (C log 2pi +
+// sum_c (logvar + n^2)) with n = eps when given, else (z - mu) / (exp(0.5 logvar) + epsilon) (posterior.py:59-61).  One wave per row.
+__global__ void __launch_bounds__(256)
+posterior_rows_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps, const float* __restrict__ zin,
+                      int Mt, int ns, int T, int C, float epsilon, float* __restrict__ z_out, float* __restrict__ row_lp) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Mt) return;
+  const int bs = row / T, t = row - bs * T, b = bs / ns;
+  const size_t o = (size_t)row * C, so = ((size_t)b * T + t) * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float lv = logvar[so + c], m = mu[so + c];
+    float nrm;
+    if (zin && !eps) nrm = (zin[o + c] - m) / (expf(0.5f * lv) + epsilon);
+    else nrm = eps ? eps[o + c] : 0.f;
+    if (z_out) z_out[o + c] = nrm * expf(0.5f * lv) + m;
+    acc += lv + nrm * nrm;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && row_lp) row_lp[row] = -0.5f * ((float)C * 1.8378770664093453f + acc);
+}
+hipError_t launch_posterior_rows(const float* mu, const float* logvar, const float* eps, const float* zin, int B, int ns, int T, int C,
+                                 float epsilon, float* z_out, float* row_lp, hipStream_t s) {
+  const int Mt = B * ns * T;
+  vnr_launch(posterior_rows_kernel, dim3((Mt + 3) / 4), dim3(256), 0, s, mu, logvar, eps, zin, Mt, ns, T, C, epsilon, z_out, row_lp);
+  return hipGetLastError();
+}
+// out[b] = mean_s x[b * ns + s]   (the means over the samples of models.py:79-83,90)
+__global__ void group_mean_kernel(const float* x, int B, int ns, float* out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int k = 0; k < ns; ++k) acc += x[b * ns + k];
+  out[b] = acc / (float)ns;
+}
+hipError_t launch_group_mean(const float* x, int B, int ns, float* out, hipStream_t s) {
+  vnr_launch(group_mean_kernel, dim3((B + 63) / 64), dim3(64), 0, s, x, B, ns, out);
+  return hipGetLastError();
+}
+
 namespace {
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
   const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;

@@ -2563,16 +2563,17 @@ hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha,
 //   g_post[b] = kw * [mean kl > 0] / B ; g_prior[b] = -g_post[b] ; cg[0] = sum_b g_prior[b] * len[b]
 // scalars[0..3] = mel_l2, kl, length_l2, total loss
 __global__ void train_seeds_kernel(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll,
-                                   const float* post_lp, const float* prior_lp, const int32_t* red_len, int B, float kw, float lw,
+                                   const float* post_lp, const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw,
                                    float* g_post, float* g_prior, float* cg, float* scalars) {
+  // B = utterances x samples (the rows of the decoder / prior terms), Bl = utterances (the rows of the length loss): models.py:67-103
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double l2 = 0.0, kl = 0.0, l = 0.0;
   for (int b = 0; b < B; ++b) {
     l2 += ((double)sum_out[b] + (double)sum_init[b]) / (double)mel_len[b];
     kl += (double)post_lp[b] - (double)prior_lp[b];
-    l += (double)ll[b];
   }
-  l2 /= B; kl /= B; l /= B;
+  for (int b = 0; b < Bl; ++b) l += (double)ll[b];
+  l2 /= B; kl /= B; l /= Bl;
   const float gk = kl > 0.0 ? kw / (float)B : 0.f;
   double c = 0.0;
   for (int b = 0; b < B; ++b) { g_post[b] = gk; g_prior[b] = -gk; c += (double)(-gk) * (double)red_len[b]; }
@@ -2581,9 +2582,9 @@ __global__ void train_seeds_kernel(const float* sum_out, const float* sum_init, 
   scalars[3] = (float)(l2 + (double)kw * (kl > 0.0 ? kl : 0.0) + (double)lw * l);
 }
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
-                              const float* prior_lp, const int32_t* red_len, int B, float kw, float lw, float* g_post, float* g_prior,
+                              const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw, float* g_post, float* g_prior,
                               float* cg, float* scalars, hipStream_t s) {
-  vnr_launch(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, kw, lw,
+  vnr_launch(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, Bl, kw, lw,
                      g_post, g_prior, cg, scalars);
   return hipGetLastError();
 }

@@ -48,6 +48,7 @@ class VAENAR:
             n_blk=p.n_blk, channels=hps.Common.latent_dim, n_transformer_blk=p.n_transformer_blk,
             attention_dim=p.attention_dim, attention_heads=p.attention_heads,
             temperature=p.temperature, ffn_hidden=p.ffn_hidden, inverse=p.inverse, engine=eng)
+        self.posterior.noise = self.prior           # one device noise stream for both tf.random.normal sites (prior.py:35, posterior.py:35)
         self._len_cache = {}
         if weights is not None:
             self.load_weights(weights)
@@ -127,37 +128,12 @@ class VAENAR:
         statistics with the moving statistics updated in the engine's weight store.
         Returns (decoded_outs [B,Tm,out_dim], l2_loss, kl_divergence, length_loss, dec_alignments); with
         reduce_loss the three losses are means over the batch (models.py:84,92,101), otherwise [B] vectors.
-        ``eps`` [B,1,Tz,C] or [B,Tz,C] replaces tf.random.normal of posterior.reparameterize
-        (posterior.py:35); default: drawn on the device (prior.draw).  (The backward pass and Adam: ``train_step``.)"""
+        ``eps`` [B,n_sample,Tz,C] (or [B,Tz,C] when n_sample = 1) replaces tf.random.normal of posterior.reparameterize
+        (posterior.py:35); default: drawn on the device (prior.draw).  With ``self.n_sample`` > 1 (hps.Train.num_samples) the
+        outputs follow models.py:146-197: decoded_outs and the alignments have batch * n_sample rows (sample index inner), the
+        per-utterance l2 / kl are means over the samples.  (The backward pass and Adam: ``train_step``.)"""
         eng = self.engine
-        ns = int(self.n_sample)
-        if ns > 1:
-            # n_sample > 1 (models.py:146-178): the reference tiles text_embd / targets / lengths n_sample times (sample index
-            # inner) and decodes batch * n_sample latents.  Same arithmetic here by tiling the INPUTS: the encoder / posterior of
-            # a tiled batch are the same rows repeated (and the same BatchNorm statistics), every (utterance, sample) row then
-            # carries its own eps; the per-utterance terms are means over the samples (models.py:67-95).  Evaluation mode only.
-            assert not training, "n_sample > 1 is supported for the evaluation forward (dev_step); train_step uses n_sample = 1 (hparams.py:247)"
-            assert eps is not None, "n_sample > 1: pass eps [B, n_sample, Tz, C]"
-            ids_h = np.asarray(inputs.numpy() if hasattr(inputs, "numpy") and not isinstance(inputs, np.ndarray) else inputs)
-            B0 = ids_h.shape[0]
-            rep = lambda a: np.repeat(np.asarray(a.numpy() if hasattr(a, "numpy") and not isinstance(a, np.ndarray) else a), ns, axis=0)   # noqa: E731
-            e4 = np.asarray(eps, np.float32)
-            assert e4.ndim == 4 and e4.shape[:2] == (B0, ns), e4.shape
-            self.n_sample = 1
-            try:
-                outs, l2, kl, ll, ali = self.__call__(rep(ids_h), rep(mel_targets), rep(mel_lengths),
-                                                      None if text_lengths is None else rep(text_lengths), reduction_factor, False, False,
-                                                      e4.reshape(B0 * ns, e4.shape[2], e4.shape[3]), return_alignments, dropout_seed)
-            finally:
-                self.n_sample = ns
-            l2, kl, ll = (t.numpy().reshape(B0, ns) for t in (l2, kl, ll))
-            l2, kl, ll = l2.mean(1, dtype=np.float32), kl.mean(1, dtype=np.float32), ll[:, 0]
-            if reduce_loss:
-                l2, kl, ll = (np.float32(t.mean(dtype=np.float32)) for t in (l2, kl, ll))
-            return outs, l2, kl, ll, ali
-        eng.set_option("training", 1 if training else 0)
-        if training:
-            eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
+        ns = int(self.n_sample)                                                 # models.py:13 (hps.Train.num_samples)
         rf = int(reduction_factor)
         ids = eng.asarray(inputs, np.int32)
         B, Tt = ids.shape
@@ -170,25 +146,38 @@ class VAENAR:
         tl = eng.asarray(np.full(B, Tt, np.int32) if text_lengths is None else text_lengths, np.int32)
         Tz = (Tm + rf - 1) // rf
         C = self.hps.Common.latent_dim
+        # posterior.reparameterize draws eps [batch, n_sample, time, dim] (posterior.py:35): everything after the posterior runs on
+        # batch * n_sample rows (sample index inner, models.py:146-178) -- the engine tiles text encoding, targets and lengths itself
         if eps is None:
-            eps = self.prior.draw((B, Tz, C))                              # on the device (posterior.py:35 / prior.py:35)
-        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+            eps = self.prior.draw((B, ns, Tz, C))                          # on the device (posterior.py:35 / prior.py:35)
+        if hasattr(eps, "ptr"):
+            eps_d = eps
+            assert eps_d.size == B * ns * Tz * C, (eps_d.shape, (B, ns, Tz, C))
+        else:
+            eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, ns, Tz, C), np.float32)
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:128
         dec = self.decoder
-        outs = eng.empty((B, Tm, dec.out_dim))
+        outs = eng.empty((B * ns, Tm, dec.out_dim))
         l2, kl, ll = eng.empty((B,)), eng.empty((B,)), eng.empty((B,))
-        ali = eng.empty((dec.nblk, B, dec.heads, Tz, Tt)) if return_alignments else None
-        aux = eng.empty((3, B))
-        check(eng.lib.vnr_elbo_fwd(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
-                                   eps_d.ptr, outs.ptr, l2.ptr, kl.ptr, ll.ptr, None if ali is None else ali.ptr,
-                                   aux.ptr), eng.handle)
-        eng.set_option("training", 0)
-        self.last_aux = aux           # predicted lengths | posterior log-probs | prior log-probs
+        ali = eng.empty((dec.nblk, B * ns, dec.heads, Tz, Tt)) if return_alignments else None
+        aux = eng.empty((3, B) if ns == 1 else (B + 2 * B * ns,))
+        eng.set_option("n_sample", ns)
+        eng.set_option("training", 1 if training else 0)
+        try:
+            if training:
+                eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
+            check(eng.lib.vnr_elbo_fwd(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+                                       eps_d.ptr, outs.ptr, l2.ptr, kl.ptr, ll.ptr, None if ali is None else ali.ptr,
+                                       aux.ptr), eng.handle)
+        finally:                       # a failing call must not leave the handle in training mode (the next inference would run
+            eng.set_option("training", 0)      # with Dropout and batch statistics)
+            eng.set_option("n_sample", 1)
+        self.last_aux = aux           # predicted lengths [B] | posterior log-probs [B * n_sample] | prior log-probs [B * n_sample]
         alignments = {}
         if ali is not None:
-            n = B * dec.heads * Tz * Tt
+            n = B * ns * dec.heads * Tz * Tt
             for i, nm in enumerate(dec.block_names):
-                alignments[nm] = ali.view(i * n, (B, dec.heads, Tz, Tt))
+                alignments[nm] = ali.view(i * n, (B * ns, dec.heads, Tz, Tt))
         if reduce_loss:
             l2, kl, ll = (np.float32(t.numpy().mean(dtype=np.float32)) for t in (l2, kl, ll))
         return outs, l2, kl, ll, alignments
@@ -240,17 +229,23 @@ class VAENAR:
         tl = eng.asarray(np.full(B, Tt, np.int32) if t_lengths is None else t_lengths, np.int32)
         Tz = (Tm + rf - 1) // rf
         C = self.hps.Common.latent_dim
+        ns = int(self.n_sample)
         if eps is None:
-            eps = self.prior.draw((B, Tz, C))                              # on the device (posterior.py:35 / prior.py:35)
-        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+            eps = self.prior.draw((B, ns, Tz, C))                          # on the device (posterior.py:35 / prior.py:35)
+        eps_d = eng.asarray(np.asarray(eps, np.float32).reshape(B, ns, Tz, C) if not hasattr(eps, "ptr") else eps, np.float32)
+        assert eps_d.size == B * ns * Tz * C, (eps_d.shape, (B, ns, Tz, C))
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)
         tr = self.hps.Train
         lr = tr.learning_rate if learning_rate is None else learning_rate
         scal = np.zeros(4, np.float32)
         eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
-        check(eng.lib.vnr_train_step(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
-                                     eps_d.ptr, float(kl_weight), float(tr.length_weight), float(lr), 0.9, 0.999, 1e-7,
-                                     1 if apply_update else 0, scal.ctypes.data), eng.handle)
+        eng.set_option("n_sample", ns)
+        try:
+            check(eng.lib.vnr_train_step(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+                                         eps_d.ptr, float(kl_weight), float(tr.length_weight), float(lr), 0.9, 0.999, 1e-7,
+                                         1 if apply_update else 0, scal.ctypes.data), eng.handle)
+        finally:
+            eng.set_option("n_sample", 1)
         self._len_cache = {}
         return float(scal[3]), float(scal[0]), float(scal[1]), float(scal[2])
 
@@ -309,11 +304,33 @@ class VAENAR:
         self._len_cache = {}
         return ck["step"] or 0
 
+    # model.trainable_variables (train.py:136-137) ---------------------------------------------------------------------------
+    @property
+    def trainable_variables(self):
+        """The list `tape.gradient(loss, model.trainable_variables)` / `optimizer.apply_gradients(zip(...))` iterate
+        (train.py:136-137), in Keras order: views with ``.name``, ``.shape``, ``.numpy()``, ``.assign()`` (and ``.gradient()``
+        after a ``train_step``).  The BatchNormalization moving statistics are not in it (``non_trainable_variables``)."""
+        from .variables import model_variables
+        return model_variables(self.engine, self.hps, True, None, self.engine.has_posterior())
+
+    @property
+    def variables(self):
+        from .variables import model_variables
+        return model_variables(self.engine, self.hps, False, None, self.engine.has_posterior())
+
+    @property
+    def non_trainable_variables(self):
+        return [v for v in self.variables if not v.trainable]
+
+    trainable_weights = trainable_variables
+    weights = variables
+
     def get_weights(self, paths=None):
         """{path: ndarray} read back from the engine (after init / training-mode forwards)."""
         from .weights import weight_spec
         spec = weight_spec(self.hps)
-        return {k: eng_get(self.engine, k, spec[k]) for k in (paths or spec)}
+        have = self.engine._weights_loaded
+        return {k: eng_get(self.engine, k, spec[k]) for k in (paths or [p for p in spec if not have or p in have])}
 
 
 def eng_get(engine, path, shape):

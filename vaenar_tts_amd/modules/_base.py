@@ -8,6 +8,8 @@ from .._lib import DeviceArray, check
 
 
 class EngineModule:
+    var_prefix = None        # object-graph attribute of this layer in models.VAENAR (models.py:16-65)
+
     def __init__(self, name, engine):
         if engine is None:
             raise ValueError("%s needs engine= (vaenar_tts_amd._lib.Engine); there is no CPU path" % name)
@@ -28,15 +30,35 @@ class EngineModule:
     def _ptr(a):
         return None if a is None else C.c_void_p(a.ptr)
 
-    def _no_training(self, training):
-        if training:
-            raise NotImplementedError(
-                "%s: training=True is not built for this module (no dropout / batch statistics inside it; "
-                "the backward pass is the next row, DESIGN.md)" % self.name)
+    def _training(self, training, dropout_seed=None):
+        """The reference's `training=` argument as a context: Dropout on (counter-based masks keyed by the engine option
+        "dropout_seed"), BatchNormalization on batch statistics + moving update for the calls inside the `with` block; the
+        option is reset on the way out even when the call fails (a handle left in training mode would run the next inference
+        with Dropout and batch statistics)."""
+        return _TrainingScope(self.engine, training, dropout_seed)
 
-    def _set_training(self, training, dropout_seed=None):
-        """The reference's `training=` argument: Dropout on (counter-based masks keyed by the engine option
-        "dropout_seed"), BatchNormalization on batch statistics + moving update.  Forward only."""
-        self.engine.set_option("training", 1 if training else 0)
-        if training and dropout_seed is not None:
-            self.engine.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
+    @property
+    def trainable_variables(self):
+        """This layer's slice of `model.trainable_variables` (Keras order)."""
+        from ..variables import model_variables
+        return model_variables(self.engine, self.engine.hps, True, self.var_prefix, self.engine.has_posterior())
+
+    @property
+    def variables(self):
+        from ..variables import model_variables
+        return model_variables(self.engine, self.engine.hps, False, self.var_prefix, self.engine.has_posterior())
+
+
+class _TrainingScope:
+    def __init__(self, engine, training, dropout_seed):
+        self.engine, self.training, self.seed = engine, bool(training), dropout_seed
+
+    def __enter__(self):
+        self.engine.set_option("training", 1 if self.training else 0)
+        if self.training and self.seed is not None:
+            self.engine.set_option("dropout_seed", int(self.seed) & 0x7FFFFFFF)
+        return self
+
+    def __exit__(self, *exc):
+        self.engine.set_option("training", 0)
+        return False

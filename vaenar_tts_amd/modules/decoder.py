@@ -3,6 +3,8 @@ from ._base import EngineModule, check
 
 
 class TransformerDecoder(EngineModule):
+    var_prefix = "decoder"
+
     def __init__(self, nblk, attention_dim, attention_heads, temperature, ffn_hidden, post_n_conv,
                  post_conv_filters, post_conv_kernel, post_drop_rate, out_dim, max_reduction_factor,
                  name='TransformerDecoder', engine=None):
@@ -15,7 +17,6 @@ class TransformerDecoder(EngineModule):
     def __call__(self, inputs, text_embd, z_lengths=None, text_lengths=None, reduction_factor=2,
                  training=None, return_alignments=True, dropout_seed=None):
         """decoder.py:181-199 -> (initial_outs, outputs, {name: alignments [B,H,Tz,Tt]})."""
-        self._set_training(training, dropout_seed)
         e = self.engine
         z = self._f32(inputs)
         mem = self._f32(text_embd)
@@ -27,9 +28,9 @@ class TransformerDecoder(EngineModule):
         initial = e.empty((B, Tz * rf, self.out_dim))
         outputs = e.empty((B, Tz * rf, self.out_dim))
         ali = e.empty((self.nblk, B, self.heads, Tz, Tt)) if return_alignments else None
-        check(e.lib.vnr_decoder_fwd(e.handle, z.ptr, mem.ptr, zl.ptr, tl.ptr, B, Tz, Tt, rf, initial.ptr,
-                                    outputs.ptr, self._ptr(ali)), e.handle)
-        self._set_training(False)
+        with self._training(training, dropout_seed):
+            check(e.lib.vnr_decoder_fwd(e.handle, z.ptr, mem.ptr, zl.ptr, tl.ptr, B, Tz, Tt, rf, initial.ptr,
+                                        outputs.ptr, self._ptr(ali)), e.handle)
         alignments = {}
         if ali is not None:
             n = B * self.heads * Tz * Tt

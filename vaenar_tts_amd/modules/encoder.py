@@ -3,6 +3,8 @@ from ._base import EngineModule, check
 
 
 class TransformerEncoder(EngineModule):
+    var_prefix = "text_encoder"
+
     def __init__(self, vocab_size, embd_dim, pre_nconv, pre_hidden, pre_conv_kernel,
                  prenet_drop_rate, pre_activation, bn_before_act, pos_drop_rate, nblk,
                  attention_dim, attention_heads, attention_temperature, ffn_hidden,
@@ -12,14 +14,13 @@ class TransformerEncoder(EngineModule):
 
     def __call__(self, inputs, input_lengths=None, pos_step=1.0, training=None, dropout_seed=None):
         """encoder.py:79-93: ids [B,T] -> text encoding [B,T,pre_hidden] (device)."""
-        self._set_training(training, dropout_seed)
         e = self.engine
         ids = e.asarray(inputs, 'int32')
         B, T = ids.shape
         lens = self._i32(input_lengths, B, T)
         out = e.empty((B, T, self.pre_hidden))
-        check(e.lib.vnr_text_encoder_fwd(e.handle, ids.ptr, lens.ptr, B, T, float(pos_step), out.ptr), e.handle)
-        self._set_training(False)
+        with self._training(training, dropout_seed):
+            check(e.lib.vnr_text_encoder_fwd(e.handle, ids.ptr, lens.ptr, B, T, float(pos_step), out.ptr), e.handle)
         return out
 
     call = __call__

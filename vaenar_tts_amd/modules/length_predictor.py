@@ -3,6 +3,8 @@ from ._base import EngineModule, check
 
 
 class DenseLengthPredictor(EngineModule):
+    var_prefix = "length_predictor"
+
     def __init__(self, activation, name='lengthPredictor', engine=None):
         super().__init__(name, engine)
         self.activation = activation

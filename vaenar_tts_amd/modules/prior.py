@@ -5,11 +5,14 @@ from ._base import EngineModule, check
 
 
 class TransformerPrior(EngineModule):
+    var_prefix = "prior"
+
     def __init__(self, n_blk, channels, n_transformer_blk, attention_dim, attention_heads,
                  temperature, ffn_hidden, inverse=False, name='GlowPrior', engine=None, **kwargs):
         super().__init__(name, engine)
         if inverse:
-            raise NotImplementedError("inverse=True flows are not used by LJHPS/DataBakerHPS (hparams.py:344)")
+            raise NotImplementedError("inverse=True flows (flow.py:39-44 dispatch call -> _backward) are not built: "
+                                      "LJHPS / DataBakerHPS use inverse=False (hparams.py:344)")
         self.channels = channels
         self.noise_seed = 0          # seed / running offset of the device generator (vnr_random_normal): tf.random.normal's role
         self.noise_offset = 0
@@ -31,7 +34,16 @@ class TransformerPrior(EngineModule):
         """prior.py:154-169.  ``eps`` (already scaled by the temperature, [B, max(len), C]) replaces
         tf.random.normal (prior.py:35) when given; otherwise it is drawn on the device (``draw``; temperature 0 -> exact zeros,
         the inference.py:95 default -- no noise buffer at all)."""
-        self._no_training(training)
+        # (training: the flows hold no Dropout / BatchNormalization -- prior.py:161-169 forwards the flag to layers that ignore it)
+        e = self.engine
+        B, Tz, Tt, zl, cond, tl, eps_d = self._flow_args(targets_lengths, condition_inputs, condition_lengths, temperature, eps)
+        z = e.empty((B, Tz, self.channels))
+        logp = e.empty((B,)) if return_logprobs else None
+        check(e.lib.vnr_prior_sample(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr,
+                                     self._ptr(logp)), e.handle)
+        return z, logp
+
+    def _flow_args(self, targets_lengths, condition_inputs, condition_lengths, temperature, eps):
         e = self.engine
         lens_h = targets_lengths.numpy() if hasattr(targets_lengths, "numpy") and not isinstance(
             targets_lengths, np.ndarray) else np.asarray(targets_lengths)
@@ -46,16 +58,30 @@ class TransformerPrior(EngineModule):
         eps_d = None if eps is None else self._f32(eps)
         if eps_d is not None:
             assert eps_d.shape == (B, Tz, self.channels), (eps_d.shape, (B, Tz, self.channels))
+        return B, Tz, Tt, zl, cond, tl, eps_d
+
+    def __call__(self, inputs, targets_lengths, condition_lengths, training=None, temperature=1.0, eps=None):
+        """TransformerPrior.call (prior.py:101-117): ``inputs`` are the condition inputs; with inverse=False every flow runs its
+        forward pass (flow.py:39-44), i.e. the same arithmetic as ``sample`` with the arguments in this order."""
+        return self.sample(targets_lengths, inputs, condition_lengths, training=training, temperature=temperature, eps=eps)
+
+    call = __call__
+
+    def init(self, conditions, targets_lengths, condition_lengths, training=None, eps=None):
+        """TransformerPrior.init (prior.py:171-186): data-dependent initialisation -- every ActNormFlow takes log_scale / bias
+        from the statistics of its input (flow.py:189-196), written to the engine's weight store (``model.trainable_variables``
+        / ``get_weights`` read them back).  Returns (z, logprobs).  ``eps`` [B, max(len), C] replaces tf.random.normal of
+        _initial_sample (prior.py:35, temperature 1)."""
+        e = self.engine
+        B, Tz, Tt, zl, cond, tl, eps_d = self._flow_args(targets_lengths, conditions, condition_lengths, 1.0, eps)
         z = e.empty((B, Tz, self.channels))
-        logp = e.empty((B,)) if return_logprobs else None
-        check(e.lib.vnr_prior_sample(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr,
-                                     self._ptr(logp)), e.handle)
+        logp = e.empty((B,))
+        check(e.lib.vnr_prior_init(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr, logp.ptr), e.handle)
         return z, logp
 
     def log_probability(self, z, condition_inputs, z_lengths=None, condition_lengths=None, training=None):
         """prior.py:119-152: log p(z | text) by running the flow backwards; [B] (device)."""
-        self._no_training(training)
-        e = self.engine
+        e = self.engine                 # (training: no training-dependent layer inside the flows, see sample)
         zd = self._f32(z)
         cond = self._f32(condition_inputs)
         B, Tz, _ = zd.shape

@@ -176,7 +176,7 @@ def load_traffic_record():
 def run_rank(args):
     import numpy as np
     from vaenar_tts_amd import dist as vdist
-    rank, local_rank, world = vdist.init("gloo")      # control plane only; no data-path collective in the inference measurement
+    rank, local_rank, world = vdist.init()      # control plane only; no data-path collective in the inference measurement
     barrier = vdist.barrier if world > 1 else (lambda: None)
 
     from vaenar_tts_amd import _lib
@@ -383,9 +383,8 @@ def run_rank(args):
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        import torch.distributed as tdist
-        tdist.barrier()
-        tdist.destroy_process_group()
+        vdist.barrier()
+        vdist.shutdown()
 
 
 def cpu_baseline_block(args, hps, weights, batch, mel, value):

@@ -39,7 +39,7 @@ def inference_test():
     parser.add_argument('--num_utterances', type=int, default=8, help='synthetic data only')
     parser.add_argument('--seed', type=int, default=1234)
     args = parser.parse_args()
-    rank, local_rank, world = vdist.init('gloo')
+    rank, local_rank, world = vdist.init()
     ckpt_step = args.ckpt_path.split('-')[-1]                                     # inference.py:102
     os.makedirs(args.test_dir, exist_ok=True)
     hparams = {'ljspeech': LJHPS, 'databaker': DataBakerHPS}[args.dataset]        # inference.py:107

@@ -1,6 +1,8 @@
-"""The N>1 path on CPU: world_size-2 gloo processes run the batch-sharding / barrier / max-over-ranks /
-gather logic bench.py and inference.py use (the per-rank compute is replaced by the oracle on a
-tiny model so the shards' results can be checked against the unsharded run)."""
+"""The N>1 path on CPU: world_size-2 processes run the batch-sharding / barrier / max-over-ranks / gather logic bench.py,
+inference.py and train.py use (the per-rank compute is replaced by the oracle on a tiny model so the shards' results can be
+checked against the unsharded run).  The product's control plane (vaenar_tts_amd/dist.py) is standard-library TCP;
+torch.distributed with the gloo backend runs BESIDE it in these tests as the checker: every collective of the control plane must
+return what gloo returns."""
 import os
 import socket
 import sys
@@ -25,8 +27,11 @@ def _worker(rank, world, port, out_dir):
     from vaenar_tts_amd.configs import tiny_hps
     from vaenar_tts_amd.synthetic import make_batch
     from vaenar_tts_amd.weights import init_weights
-    r, lr, w = dist.init("gloo")
-    assert (r, w) == (rank, world)
+    import torch
+    import torch.distributed as tdist
+    r, lr, w = dist.init()
+    assert (r, w) == (rank, world) and dist.is_initialized()
+    tdist.init_process_group("gloo", rank=rank, world_size=world)           # the checker
     hps = tiny_hps()
     weights = init_weights(hps, seed=5)
     batch = make_batch(5, 9, 24, latent_dim=hps.Common.latent_dim, ragged=False, temperature=1.0)
@@ -37,10 +42,27 @@ def _worker(rank, world, port, out_dir):
                                                         shard["eps"])
     t = dist.max_over_ranks(1.0 + rank)
     assert t == float(world)
+    x = torch.tensor([1.0 + rank, 0.1 * (rank + 1)], dtype=torch.float64)
+    tdist.all_reduce(x[:1], op=tdist.ReduceOp.MAX)
+    tdist.all_reduce(x[1:], op=tdist.ReduceOp.SUM)
+    assert t == float(x[0]) and abs(dist.mean_over_ranks(0.1 * (rank + 1)) - float(x[1]) / world) < 1e-15
     full = dist.gather_to_rank0(mel)
+    box = [None] * world if rank == 0 else None
+    tdist.gather_object(mel, box, dst=0)
     if rank == 0:
+        assert np.array_equal(full, np.concatenate(box, 0))
         np.save(os.path.join(out_dir, "gathered.npy"), full)
+    else:
+        assert full is None
+    blob = dist.broadcast_bytes(bytes(range(7, 135)) if rank == 0 else None)
+    ref = [bytes(range(7, 135)) if rank == 0 else None]
+    tdist.broadcast_object_list(ref, src=0)
+    assert blob == ref[0]
     dist.barrier()
+    tdist.barrier()
+    dist.shutdown()
+    assert not dist.is_initialized() and dist.max_over_ranks(3.0) == 3.0      # back to the single-process behaviour
+    tdist.destroy_process_group()
 
 
 def test_batch_sharded_inference_world2(tmp_path):
@@ -97,7 +119,8 @@ def _train_worker(rank, world, port, out_dir):
     import torch.distributed as tdist
     from oracle.vaenar_torch import TorchOracle
     from vaenar_tts_amd import dist
-    dist.init("gloo")
+    dist.init()
+    tdist.init_process_group("gloo", rank=rank, world_size=world)           # stands in for the device all-reduce (RCCL) below
     uid = dist.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
     assert uid == bytes(range(128))
     hps, w, batch = _dp_case()
@@ -115,6 +138,8 @@ def _train_worker(rank, world, port, out_dir):
     if rank == 0:
         np.save(os.path.join(out_dir, "avg_grad.npy"), flat.numpy())
     dist.barrier()
+    dist.shutdown()
+    tdist.destroy_process_group()
 
 
 def test_data_parallel_gradient_average_world2(tmp_path):
@@ -131,3 +156,34 @@ def test_data_parallel_gradient_average_world2(tmp_path):
     ref = np.concatenate([g[k].reshape(-1) for k in sorted(g)])
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+
+
+def _late_worker(rank, world, port, out_dir):
+    """Ranks that start seconds apart, with a foreign listener squatting on the first candidate port."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    from vaenar_tts_amd import dist
+    if rank == 0:
+        time.sleep(1.5)                      # the other ranks poll until rank 0 listens
+    dist.init(timeout=60.0)
+    assert dist.max_over_ranks(float(rank)) == float(world - 1)
+    got = dist.gather_to_rank0(np.full((rank + 1, 2), rank, np.int32))
+    if rank == 0:
+        assert got.shape == (sum(range(1, world + 1)), 2) and got[0, 0] == 0 and got[-1, 0] == world - 1
+    dist.barrier()
+    dist.shutdown()
+
+
+def test_control_plane_world3_with_a_foreign_listener_and_late_rank0():
+    port = _free_port()
+    squat = socket.socket(); squat.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        squat.bind(("127.0.0.1", port + 1)); squat.listen(4)      # not ours: no handshake reply -> the ranks move to the next candidate
+    except OSError:
+        squat = None
+    try:
+        mp.spawn(_late_worker, args=(3, port, ""), nprocs=3, join=True)
+    finally:
+        if squat is not None:
+            squat.close()

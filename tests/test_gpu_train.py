@@ -21,6 +21,9 @@ def _case(name):
     elif name == "tiny-mid":     # T_z = 132, T_text = 12 (multiples of 4: the third-form attention backward on self- AND cross-attention; five
         b = make_batch(2, 12, 264, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,   # query tiles, so the
                        ragged=True, text_step=3, mel_step=62)                                                           # two-query-group dK / dV form runs)
+    elif name == "lj-mid":       # LJ widths, 264 latent rows: the third-generation kernel-gradient GEMM (M >= 256, K and N >= 128) runs
+        b = make_batch(2, 12, 264, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
+                       ragged=True, text_step=3, mel_step=62)
     elif name == "tiny":
         b = make_batch(3, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim,
                        ragged=True, text_step=3, mel_step=7)
@@ -88,12 +91,12 @@ def test_adam_update_matches_keras_formula():
     here at the weights reached after two updates."""
     hps, w, b, mels, eps = _case("tiny")
     model = VAENAR(hps, weights=w)
-    # The learning rate picks the trajectory.  With 1e-3 the weights reached after one update put ONE hidden unit of one FFN
-    # (prior/glow/1 .. attentions/1/ffn/dense1, unit 8 of one frame) within float32 rounding of zero: its ReLU mask then follows the
-    # last bits of the forward pass (atomic accumulation orders differ from run to run) and disagrees with the float64 oracle in one
-    # run out of four -- a single flipped mask is a 4e-3 error in that layer's gradient (tools/r03_adam_err.py prints it).  2e-3 has
-    # no such unit: 48 repetitions, worst gradient error 4e-6.
-    LR = 2e-3
+    # hps.Train.learning_rate (1e-3, the reference's).  On this trajectory the weights reached after one update put ONE hidden unit of
+    # one FFN within float32 rounding of zero: its ReLU mask is not defined at fp32 resolution (it follows the last bits of the
+    # forward pass) and one flipped mask is a 4e-3 error in that FFN's kernel gradients (tools/r03_adam_err.py).  The oracle reports
+    # how close each FFN's hidden layer comes to the kink; the gradients of an FFN closer than 1e-5 are compared at 2e-2, everything
+    # else at the usual 2e-3.
+    LR = 1e-3
     try:
         m = v = None
         for step in (1, 2, 3):
@@ -111,8 +114,10 @@ def test_adam_update_matches_keras_formula():
             if step == 2:      # gradients at the updated weights (transposed kernels, inverse flow matrices, scalars refreshed)
                 o = TorchOracle(hps, before)
                 gr, _ = o.gradients(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, kl_weight=1.0, dropout_seed=step)
+                near = [p for p, mg in o.last.get("relu_margin", {}).items() if mg < 1e-5]
                 for k in sorted(gr):
-                    assert np.abs(g[k] - gr[k]).max() <= 2e-3 * np.abs(gr[k]).max() + 1e-7, k
+                    tol = 2e-2 if any(k.startswith(p + "/") for p in near) else 2e-3
+                    assert np.abs(g[k] - gr[k]).max() <= tol * np.abs(gr[k]).max() + 1e-7, (k, near)
         # BN moving statistics are assigned by the forward, not optimised: three momentum-0.99 updates moved them
         k = "decoder/postnet/conv_stack/0/bn/moving_mean"
         assert np.abs(after[k] - w[k]).max() > 1e-4
@@ -167,3 +172,38 @@ def test_rccl_allreduce_path_single_rank():
         model.engine.close()
     for k in g0:
         assert np.abs(g1[k] - g0[k]).max() <= 1e-5 * np.abs(g0[k]).max() + 1e-7, k    # (float atomics: summation order varies)
+
+
+def test_deterministic_training_mode():
+    """Engine option "deterministic" (the reference pins TF_DETERMINISTIC_OPS=1 and every seed, train.py:17-32): the kernel-gradient
+    GEMMs' row splits, the column sums, the LayerNorm / BatchNorm / ActNorm / embedding / length-predictor gradients leave ordered
+    partials instead of float atomics.  Two identical steps then give bit-identical gradients, three identical runs of two optimizer
+    steps bit-identical variables; the gradients agree with the default (atomic) mode to rounding."""
+    hps, w, b, mels, eps = _case("lj-mid")
+    args = (b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2)
+
+    def run(det, steps):
+        model = VAENAR(hps, weights=w)
+        try:
+            model.engine.set_option("deterministic", det)
+            out = []
+            for i in range(steps):
+                model.train_step(*args, eps=eps, dropout_seed=7 + i, apply_update=steps > 1)
+                out.append(model.gradients())
+            return out, (model.get_weights() if steps > 1 else None)
+        finally:
+            model.engine.close()
+
+    (g0,), _ = run(1, 1)
+    (g1,), _ = run(1, 1)
+    for k in sorted(g0):
+        assert np.array_equal(g0[k], g1[k]), "gradient of %s differs between two identical deterministic steps" % k
+    (ga,), _ = run(0, 1)
+    for k in sorted(g0):
+        assert np.abs(ga[k] - g0[k]).max() <= 1e-4 * max(np.abs(g0[k]).max(), 1e-12) + 1e-9, k
+    runs = [run(1, 2) for _ in range(3)]
+    for gs, ws in runs[1:]:
+        for k in sorted(ws):
+            assert np.array_equal(ws[k], runs[0][1][k]), "variable %s differs after two deterministic optimizer steps" % k
+        for k in sorted(gs[1]):
+            assert np.array_equal(gs[1][k], runs[0][0][1][k]), k

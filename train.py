@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--seed', type=int, default=None)
     args = ap.parse_args()
     hps = {'ljspeech': LJHPS, 'databaker': DataBakerHPS, 'tiny': tiny_hps()}[args.dataset]
-    rank, local_rank, world = vdist.init('gloo')
+    rank, local_rank, world = vdist.init()
     seed = hps.Train.random_seed if args.seed is None else args.seed
     os.makedirs(args.model_dir, exist_ok=True)
     gb = args.batch_size or hps.Train.train_batch_size

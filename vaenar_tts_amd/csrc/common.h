@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <hip/hip_ext.h>
+#include <map>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -60,6 +61,37 @@ inline void vnr_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned
   }
 }
 #endif
+
+// ---- deterministic accumulation (engine option "deterministic": TF_DETERMINISTIC_OPS=1 of the reference's train.py:17-32) --------
+// Every kernel of the training step that ends in float / double atomics onto shared words (column sums over row groups, the row splits
+// of the kernel-gradient GEMMs ...) can instead leave one PARTIAL per contributing workgroup in a scratch buffer (plain stores); a small
+// finish kernel then adds the partials in index order -- a fixed summation order, so two identical steps give identical bits.  The
+// launchers look at g_det (set by vnr_train_step around the step); the scratch is per stream and is reused by consecutive launches
+// of that stream (the finish kernel of launch i precedes the producer of launch i + 1 in stream order).
+struct DetState {
+  std::map<hipStream_t, std::pair<void*, size_t>> bufs;
+  std::vector<void*> retired;                              // outgrown buffers: possibly still read by kernels in flight, freed with the context
+  void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); for (void* p : retired) (void)hipFree(p); bufs.clear(); retired.clear(); }
+};
+inline thread_local DetState* g_det = nullptr;
+inline void* det_scratch(hipStream_t s, size_t bytes) {
+  if (!g_det) return nullptr;
+  auto& b = g_det->bufs[s];
+  if (b.second < bytes) {
+    void* p = nullptr;
+    const size_t cap = bytes < ((size_t)16 << 20) ? ((size_t)16 << 20) : bytes + bytes / 2;
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    if (b.first) g_det->retired.push_back(b.first);
+    b = {p, cap};
+  }
+  return b.first;
+}
+// out[i] += sum_{p < nparts} part[p * n + i], partials added in index order (i < n)
+hipError_t launch_det_finish_dd(const double* part, int nparts, size_t n, double* out, hipStream_t s);
+hipError_t launch_det_finish_df(const double* part, int nparts, size_t n, float* out, hipStream_t s);
+hipError_t launch_det_finish_ff(const float* part, int nparts, size_t n, float* out, hipStream_t s);
+// C[k * ldc + n] += sum_{p < nparts} part[(p * K + k) * N + n]
+hipError_t launch_det_finish_2d(const float* part, int nparts, int K, int N, float* C, int ldc, hipStream_t s);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -142,6 +142,7 @@ struct vnr_context {
   bool training = false;         // engine option "training": Dropout active, BatchNormalization on batch statistics (+ moving update)
   int n_sample = 1;              // engine option "n_sample": hps.Train.num_samples of VAENAR.call (models.py:13,141-178) for vnr_elbo_fwd / vnr_train_step
   bool deterministic = false;    // engine option "deterministic": TF_DETERMINISTIC_OPS=1 of train.py:17-32 -- no float atomics in the training step
+  DetState det;                  // its scratch: per-stream partial buffers (common.h)
   unsigned drop_seed = 0;        // engine option "dropout_seed"
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
@@ -1225,6 +1226,7 @@ int vnr_destroy(vnr_handle h) {
   hipStreamSynchronize(h->stream);
   if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   train_free(h);
+  h->det.release();
   for (auto& kv : h->w) hipFree(kv.second.d);
   for (auto p : h->packed_allocs) hipFree(p);
   for (auto& c : h->chunks) hipFree(c.p);
@@ -1748,8 +1750,10 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
   h->split_scope = false;            // exact fp32 GEMMs throughout the training step
   h->training = true;
   h->in_train_step = true;
+  g_det = h->deterministic ? &h->det : nullptr;          // kernels that would end in float atomics leave ordered partials instead (common.h: DetState)
   const int rc = train_step_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps,
                                  kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
+  g_det = nullptr;
   h->split_scope = saved_split; h->training = saved_training; h->in_train_step = false;
   if (rc == VNR_OK && !h->packed_stale) TRY(refresh_bn_affine(h));      // moving statistics moved
   return rc;

@@ -490,7 +490,7 @@ hipError_t launch_bn_affine(const float* gamma, const float* beta, const float* 
 // Column sums of x[M][C] (row stride ld) in float64: out[c] += sum_m f(x[m][c]) with f(v) = v, or (v - mean[c])^2
 // when `mean` is given (second pass of a two-pass variance).  Used by BatchNormalization(training=True)
 // (tf.nn.moments over axes (0,1), padded frames included: utils.py:79-83) and ActNormFlow.init (flow.py:189-196).
-__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout) {
+__global__ void col_sum_kernel(const float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, double* det) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;                       // 4 row groups per block
   double acc = 0.0;
@@ -525,7 +525,8 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
   if (amax && threadIdx.x == 0) amax_publish(amax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
   if (rg == 0 && c < C) {
     const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    if (fout) atomicAdd(&fout[c], (float)t);             // straight into a float32 gradient (<= 128 block partials per column)
+    if (det) det[(size_t)blockIdx.y * C + c] = t;        // deterministic mode: this row group's partial, added in order by the finish kernel
+    else if (fout) atomicAdd(&fout[c], (float)t);        // straight into a float32 gradient (<= 128 block partials per column)
     else atomicAdd(&out[c], t);
   }
 }
@@ -534,7 +535,7 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
 // yact != null: x is a gradient dy and yact the OUTPUT of an activation (act_bwd_kernel's job folded into this pass: dy *= act'(y) is
 // written back in place before it enters the sums) -- one launch and one pass over dy less per activated Dense / Conv1D layer.
 __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act,
-                                double* out2) {      // out2 != null (mean == null): also out2[c] += sum_m x^2 -- both BatchNorm sums in ONE pass
+                                double* out2, double* det) {      // out2 != null (mean == null): also out2[c] += sum_m x^2 -- both BatchNorm sums in ONE pass
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   const int rg = threadIdx.x >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -598,7 +599,8 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
   const int cc = blockIdx.x * 256 + threadIdx.x;
   if (cc < C) {
     const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    if (fout) atomicAdd(&fout[cc], (float)t);
+    if (det) det[(size_t)blockIdx.y * C + cc] = t;
+    else if (fout) atomicAdd(&fout[cc], (float)t);
     else atomicAdd(&out[cc], t);
   }
   if (out2) {                                                // (workgroup-uniform)
@@ -606,7 +608,11 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
 #pragma unroll
     for (int e = 0; e < 4; ++e) part[rg][(threadIdx.x & 63) * 4 + e] = acc2[e];
     __syncthreads();
-    if (cc < C) atomicAdd(&out2[cc], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (cc < C) {
+      const double t2 = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+      if (det) det[((size_t)gridDim.y + blockIdx.y) * C + cc] = t2;
+      else atomicAdd(&out2[cc], t2);
+    }
   }
 }
 static bool col_sum4_ok(const float* x, int C, int ld) {
@@ -624,11 +630,19 @@ static hipError_t launch_col_sum_any(const float* x, int M, int C, int ld, const
     const int cb = (C + 255) / 256;
     int rb4 = forced > 0 ? forced : 256 / cb; if (!forced) { if (rb4 > 128) rb4 = 128; if (rb4 < 32) rb4 = 32; }
     const int rmax = (M + 63) / 64; if (rb4 > rmax) rb4 = rmax; if (rb4 < 1) rb4 = 1;
-    vnr_launch(col_sum4_kernel, dim3(cb, rb4), dim3(256), 0, s, const_cast<float*>(x), M, C, ld, mean, out, amax, fout, yact, act, out2);
+    double* det = static_cast<double*>(det_scratch(s, (size_t)2 * rb4 * C * sizeof(double)));
+    vnr_launch(col_sum4_kernel, dim3(cb, rb4), dim3(256), 0, s, const_cast<float*>(x), M, C, ld, mean, out, amax, fout, yact, act, out2, det);
+    if (det) {
+      hipError_t e = fout ? launch_det_finish_df(det, rb4, (size_t)C, fout, s) : launch_det_finish_dd(det, rb4, (size_t)C, out, s);
+      if (e == hipSuccess && out2) e = launch_det_finish_dd(det + (size_t)rb4 * C, rb4, (size_t)C, out2, s);
+      return e;
+    }
   } else {
     if (yact) return hipErrorInvalidValue;
     if (out2) return hipErrorNotSupported;
-    vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout);
+    double* det = static_cast<double*>(det_scratch(s, (size_t)rb * C * sizeof(double)));
+    vnr_launch(col_sum_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, M, C, ld, mean, out, amax, fout, det);
+    if (det) return fout ? launch_det_finish_df(det, rb, (size_t)C, fout, s) : launch_det_finish_dd(det, rb, (size_t)C, out, s);
   }
   return hipGetLastError();
 }

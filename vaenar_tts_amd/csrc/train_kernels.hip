@@ -23,7 +23,7 @@ __device__ __forceinline__ int frow_t(int r, int half) { return (r & 3) + 8 * (r
 // T = M for a Dense layer; shift = j - (k-1)/2 for tap j of a 'same' Conv1D.
 __global__ void __launch_bounds__(256)
 gemm_tn_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
-               int rows_per_split) {
+               int rows_per_split, float* det) {
   __shared__ float As[32][68];
   __shared__ float Bs[32][68];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +73,7 @@ gemm_tn_kernel(const float* A, int lda, const float* B, int ldb, float* C, int l
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = k0 + wk * 32 + frow_t(r, half);
-      if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[r]);
+      if (k < K) { if (det) det[((size_t)blockIdx.z * K + k) * N + n] = acc[r]; else atomicAdd(C + (size_t)k * ldc + n, acc[r]); }
     }
 }
 // Second generation of the kernel-gradient GEMM: the same contraction on the f16 matrix pipe with the 3-term hi/lo split
@@ -88,7 +88,7 @@ typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
 template <int TK, int TN>
 __global__ void __launch_bounds__(256)
 gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
-                     int rows_per_split, const unsigned* b_absmax) {
+                     int rows_per_split, const unsigned* b_absmax, float* det) {
   constexpr int CS = 40;                                   // column stride in halfs (80 B: 16-byte aligned, bank-spread)
   constexpr int KW = 64 * TK, NW = 64 * TN;                // workgroup tile: KW output rows (k) x NW output columns (n)
   extern __shared__ __attribute__((aligned(16))) char tn_smem[];
@@ -197,7 +197,7 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int k = k0 + (wk * TK + i) * 32 + frow_t(r, half);
-          if (k < K) atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv);
+          if (k < K) { if (det) det[((size_t)blockIdx.z * K + k) * N + n] = acc[i][j][r] * binv; else atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv); }
         }
     }
 }
@@ -237,7 +237,7 @@ __device__ __forceinline__ void tn3_barrier() {           // LDS traffic of this
 // waves in lock step between barriers), and a second workgroup per CU did not get scheduled beside it.
 __global__ void __launch_bounds__(768)
 gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
-                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts) {
+                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det) {
   constexpr int TS = 2048 + 64;                            // one 32-column tile of a plane: [2 steps][2 halves][8 rows][32 halves] + pad
   constexpr int PL = 4 * TS;                               // one plane of one stage: 32 rows x 128 halves
   extern __shared__ __attribute__((aligned(16))) char tn3_smem[];      // [2 stages][A hi | A lo | B hi | B lo][PL]
@@ -482,7 +482,8 @@ gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int 
         for (int r = 0; r < 16; ++r) {
           const int k = k0 + (2 * wk + i) * 32 + frow_t(r, half);
           if (k < K) {
-            if (dbg_out == 0) atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv);
+            if (det) det[((size_t)split * K + k) * N + n] = acc[i][j][r] * binv;       // deterministic mode: this row split's partial
+            else if (dbg_out == 0) atomicAdd(C + (size_t)k * ldc + n, acc[i][j][r] * binv);
             else if (dbg_out == 1) C[(size_t)k * ldc + n] = acc[i][j][r] * binv;       // (measurement only: wrong sums)
           }
         }
@@ -567,7 +568,9 @@ static hipError_t launch_tn_cfg(const float* A, int lda, const float* B, int ldb
   const size_t lds = (size_t)2 * 2 * (KW + NW) * 40 * sizeof(_Float16);
   static int attr_done[kMaxDevices] = {0};
   if (lds > 48 * 1024) opt_in_dynamic_lds((const void*)gemm_tn_split_kernel<TK, TN>, (int)lds, attr_done);
-  vnr_launch(gemm_tn_split_kernel<TK, TN>, dim3(tk, tn, splits), dim3(256), (unsigned)lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax);
+  float* det = static_cast<float*>(det_scratch(s, (size_t)splits * K * N * sizeof(float)));
+  vnr_launch(gemm_tn_split_kernel<TK, TN>, dim3(tk, tn, splits), dim3(256), (unsigned)lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, det);
+  if (det) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);
   return hipGetLastError();
 }
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
@@ -580,7 +583,9 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
     int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
     int rps = ((M + splits - 1) / splits + 31) / 32 * 32;
     splits = (M + rps - 1) / rps;
-    vnr_launch(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps);
+    float* det = static_cast<float*>(det_scratch(s, (size_t)splits * K * N * sizeof(float)));
+    vnr_launch(gemm_tn_kernel, dim3(tk, tn, splits), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, det);
+    if (det) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);
     return hipGetLastError();
   }
   // 64 x 64 workgroup tiles by default.  The 128 x 128 variant (VNR_GEMM_TN_TILE=2) measured SLOWER on the T1 step (45.9 vs
@@ -606,7 +611,7 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
       unsigned long long* d = nullptr;
       if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
       (void)hipMemset(d, 0, n * 8);
-      vnr_launch(gemm_tn3_kernel, dim3(wgs), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, dbg_out, tk, tn, splits, d);
+      vnr_launch(gemm_tn3_kernel, dim3(wgs), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, dbg_out, tk, tn, splits, d, (float*)nullptr);
       (void)hipStreamSynchronize(s);
       std::vector<unsigned long long> hbuf(n);
       (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -615,8 +620,10 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
       if (f) { int hdr[4] = {M, K, N, (int)wgs}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
       return hipGetLastError();
     }
+    float* det = static_cast<float*>(det_scratch(s, (size_t)splits * K * N * sizeof(float)));
     vnr_launch(gemm_tn3_kernel, dim3((unsigned)((splits + 7) / 8 * 8 * tk * tn)), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps,
-               b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr);
+               b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr, det);
+    if (det) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);
     return hipGetLastError();
   }
   const bool big = force == 2 && K >= 128 && N >= 128 && (long long)((K + 127) / 128) * ((N + 127) / 128) * ((M + 127) / 128) >= 256;
@@ -1890,7 +1897,7 @@ hipError_t launch_attention_bwd_recompute(const float* Q, int ldq, const float* 
 // y = (v - mu) * rstd * gamma + beta.  dv = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma;
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy.   One wave per row, D <= 512.
 __global__ void __launch_bounds__(256)
-ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta) {
+ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma, float* dbeta, float* det) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = gridDim.x * 4;
   float pg[8], pb[8];
@@ -1932,8 +1939,9 @@ ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int
   for (int j = 0; j < 8; ++j) { const int c = lane + 64 * j; if (c < 512) { rg[wave][c] = pg[j]; rb[wave][c] = pb[j]; } }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma + c, rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c]);
-    atomicAdd(dbeta + c, rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c]);
+    const float tg = rg[0][c] + rg[1][c] + rg[2][c] + rg[3][c], tb = rb[0][c] + rb[1][c] + rb[2][c] + rb[3][c];
+    if (det) { det[(size_t)blockIdx.x * D + c] = tg; det[((size_t)gridDim.x + blockIdx.x) * D + c] = tb; }
+    else { atomicAdd(dgamma + c, tg); atomicAdd(dbeta + c, tb); }
   }
 }
 // Second generation (round 2) for D = 64 * NJ (256: NJ = 4, 512: NJ = 8): 16 lanes per row with 16-byte accesses (16 rows per
@@ -1941,7 +1949,7 @@ ln_bwd_kernel(const float* v, const float* dy, const float* gamma, int rows, int
 // per lane per access and spent most of its 46 us per call in 30 dependent shuffles per row.
 template <int NJ>
 __global__ void __launch_bounds__(256)
-ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, float* dv, int lddv, int accumulate, float* dgamma, float* dbeta) {
+ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, float* dv, int lddv, int accumulate, float* dgamma, float* dbeta, float* det) {
   constexpr int D = 64 * NJ;
   const int l16 = threadIdx.x & 15, rg = threadIdx.x >> 4;           // 16 row groups of 16 lanes
   float4 ga[NJ], pg[NJ], pb[NJ];
@@ -2001,7 +2009,8 @@ ln_bwd16_kernel(const float* v, const float* dy, const float* gamma, int rows, f
       float a = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) a += red[k][c];
-      atomicAdd((pass == 0 ? dgamma : dbeta) + c, a);
+      if (det) det[((size_t)pass * gridDim.x + blockIdx.x) * D + c] = a;
+      else atomicAdd((pass == 0 ? dgamma : dbeta) + c, a);
     }
     __syncthreads();
   }
@@ -2017,9 +2026,12 @@ bool launch_ln_bwd_acc(const float* v, const float* dy, const float* gamma, int 
   //  launch queueing there -- at most ~256 workgroups, several trips each; VNR_LN_BWD_BLOCKS pins the count)
   static const int maxb = getenv("VNR_LN_BWD_BLOCKS") ? atoi(getenv("VNR_LN_BWD_BLOCKS")) : 256;
   int blocks = (rows + 15) / 16; if (blocks > maxb) blocks = maxb; if (blocks < 1) blocks = 1;
-  if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
-  else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta);
+  float* det = static_cast<float*>(det_scratch(s, (size_t)2 * blocks * D * sizeof(float)));
+  if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta, det);
+  else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dst, lddst, 1, dgamma, dbeta, det);
   *err = hipGetLastError();
+  if (det && *err == hipSuccess) *err = launch_det_finish_ff(det, blocks, (size_t)D, dgamma, s);
+  if (det && *err == hipSuccess) *err = launch_det_finish_ff(det + (size_t)blocks * D, blocks, (size_t)D, dbeta, s);
   return true;
 }
 hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, int rows, int D, float* dv, float* dgamma,
@@ -2030,12 +2042,16 @@ hipError_t launch_ln_bwd(const float* v, const float* dy, const float* gamma, in
   if (!v1 && al && (D == 256 || D == 512)) {
     static const int maxb = getenv("VNR_LN_BWD_BLOCKS") ? atoi(getenv("VNR_LN_BWD_BLOCKS")) : 256;
     int blocks = (rows + 15) / 16; if (blocks > maxb) blocks = maxb; if (blocks < 1) blocks = 1;
-    if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
-    else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta);
+    float* det = static_cast<float*>(det_scratch(s, (size_t)2 * blocks * D * sizeof(float)));
+    if (D == 256) vnr_launch(ln_bwd16_kernel<4>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta, det);
+    else vnr_launch(ln_bwd16_kernel<8>, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, dv, D, 0, dgamma, dbeta, det);
+    if (det) { hipError_t e = launch_det_finish_ff(det, blocks, (size_t)D, dgamma, s); return e != hipSuccess ? e : launch_det_finish_ff(det + (size_t)blocks * D, blocks, (size_t)D, dbeta, s); }
     return hipGetLastError();
   }
   int blocks = (rows + 15) / 16; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
-  vnr_launch(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta);
+  float* det = static_cast<float*>(det_scratch(s, (size_t)2 * blocks * D * sizeof(float)));
+  vnr_launch(ln_bwd_kernel, dim3(blocks), dim3(256), 0, s, v, dy, gamma, rows, D, dv, dgamma, dbeta, det);
+  if (det) { hipError_t e = launch_det_finish_ff(det, blocks, (size_t)D, dgamma, s); return e != hipSuccess ? e : launch_det_finish_ff(det + (size_t)blocks * D, blocks, (size_t)D, dbeta, s); }
   return hipGetLastError();
 }
 
@@ -2118,7 +2134,7 @@ hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream
 }
 // column sums of two products in float64: s1[c] += sum_m d[m][c] ; s2[c] += sum_m d[m][c] * (x[m][c] - mean[c]) * rstd[c]
 __global__ void bn_bwd_sums_kernel(const float* d, const float* x, const double* mean, const double* sq, int M, int C, double* s1,
-                                   double* s2) {
+                                   double* s2, double* det) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   double a1 = 0.0, a2 = 0.0;
@@ -2135,8 +2151,10 @@ __global__ void bn_bwd_sums_kernel(const float* d, const float* x, const double*
   p1[rg][threadIdx.x & 63] = a1; p2[rg][threadIdx.x & 63] = a2;
   __syncthreads();
   if (rg == 0 && c < C) {
-    atomicAdd(&s1[c], p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
-    atomicAdd(&s2[c], p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
+    const double t1 = p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x];
+    const double t2 = p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x];
+    if (det) { det[(size_t)blockIdx.y * C + c] = t1; det[((size_t)gridDim.y + blockIdx.y) * C + c] = t2; }
+    else { atomicAdd(&s1[c], t1); atomicAdd(&s2[c], t2); }
   }
 }
 // dx = gamma * rstd * (d - s1/M - xhat * s2/M) ; dgamma += s2 ; dbeta += s1   (d = gradient at the BN output)
@@ -2154,7 +2172,13 @@ __global__ void bn_bwd_apply_kernel(const float* d, const float* x, const double
 hipError_t launch_bn_bwd(const float* d, const float* x, const double* mean, const double* sq, const float* gamma, int M, int C,
                          double* s1, double* s2, float* dx, float* dgamma, float* dbeta, hipStream_t s) {
   int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-  vnr_launch(bn_bwd_sums_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, d, x, mean, sq, M, C, s1, s2);
+  double* det = static_cast<double*>(det_scratch(s, (size_t)2 * rb * C * sizeof(double)));
+  vnr_launch(bn_bwd_sums_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, d, x, mean, sq, M, C, s1, s2, det);
+  if (det) {
+    hipError_t e = launch_det_finish_dd(det, rb, (size_t)C, s1, s);
+    if (e == hipSuccess) e = launch_det_finish_dd(det + (size_t)rb * C, rb, (size_t)C, s2, s);
+    if (e != hipSuccess) return e;
+  }
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
   vnr_launch(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, d, x, mean, sq, s1, s2, gamma, M, C, dx, dgamma, dbeta);
@@ -2168,14 +2192,26 @@ __global__ void embed_bwd_kernel(const float* d, const int32_t* ids, int M, int 
     atomicAdd(dE + (size_t)ids[m] * C + c, d[i]);
   }
 }
+// deterministic form: one thread per column walks the M positions in order and adds each row's value to its embedding row -- every
+// (row, column) word has ONE writer and a fixed summation order (the table has tens of rows: the atomics of the default form meet
+// on the same words all the time)
+__global__ void embed_bwd_ordered_kernel(const float* d, const int32_t* ids, int M, int C, float* dE) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  for (int m = 0; m < M; ++m) dE[(size_t)ids[m] * C + c] += d[(size_t)m * C + c];
+}
 hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s) {
+  if (g_det) {
+    vnr_launch(embed_bwd_ordered_kernel, dim3((C + 63) / 64), dim3(64), 0, s, d, ids, M, C, dE);
+    return hipGetLastError();
+  }
   const size_t n = (size_t)M * C;
   int blocks = (int)((n + 1023) / 1024); if (blocks > 2048) blocks = 2048;
   vnr_launch(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, d, ids, M, C, dE);
   return hipGetLastError();
 }
 // *out += sum_m sum_c d[m][c] * pe[m % T][c]     (gradient of the scalar pos_weight)
-__global__ void pe_weight_bwd_kernel(const float* d, const float* pe, int M, int C, int T, float* out) {
+__global__ void pe_weight_bwd_kernel(const float* d, const float* pe, int M, int C, int T, float* out, double* det) {
   double acc = 0.0;
   const size_t n = (size_t)M * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -2186,11 +2222,11 @@ __global__ void pe_weight_bwd_kernel(const float* d, const float* pe, int M, int
   __shared__ double part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
+  if (threadIdx.x == 0) { if (det) det[blockIdx.x] = part[0] + part[1] + part[2] + part[3]; else atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3])); }
 }
 // 16-byte form (C a multiple of 4, 16-byte aligned operands): a wave walks whole rows (no per-element division), products summed
 // per thread in float64 as above; ~1000 workgroups instead of 64 (the scalar kernel took 62 us for 13 MB)
-__global__ void __launch_bounds__(256) pe_weight_bwd4_kernel(const float* d, const float* pe, int M, int C, int T, float* out) {
+__global__ void __launch_bounds__(256) pe_weight_bwd4_kernel(const float* d, const float* pe, int M, int C, int T, float* out, double* det) {
   double acc = 0.0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
@@ -2205,15 +2241,19 @@ __global__ void __launch_bounds__(256) pe_weight_bwd4_kernel(const float* d, con
   __shared__ double part[4];
   if (lane == 0) part[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3]));
+  if (threadIdx.x == 0) { if (det) det[blockIdx.x] = part[0] + part[1] + part[2] + part[3]; else atomicAdd(out, (float)(part[0] + part[1] + part[2] + part[3])); }
 }
 hipError_t launch_pe_weight_bwd(const float* d, const float* pe, int M, int C, int T, float* out, hipStream_t s) {
   if (!(C & 3) && !((size_t)d & 15) && !((size_t)pe & 15)) {
     int blocks = (M + 15) / 16; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
-    vnr_launch(pe_weight_bwd4_kernel, dim3(blocks), dim3(256), 0, s, d, pe, M, C, T, out);
+    double* det = static_cast<double*>(det_scratch(s, (size_t)blocks * sizeof(double)));
+    vnr_launch(pe_weight_bwd4_kernel, dim3(blocks), dim3(256), 0, s, d, pe, M, C, T, out, det);
+    if (det) return launch_det_finish_df(det, blocks, 1, out, s);
     return hipGetLastError();
   }
-  vnr_launch(pe_weight_bwd_kernel, dim3(64), dim3(256), 0, s, d, pe, M, C, T, out);
+  double* det = static_cast<double*>(det_scratch(s, (size_t)64 * sizeof(double)));
+  vnr_launch(pe_weight_bwd_kernel, dim3(64), dim3(256), 0, s, d, pe, M, C, T, out, det);
+  if (det) return launch_det_finish_df(det, 64, 1, out, s);
   return hipGetLastError();
 }
 
@@ -2274,7 +2314,7 @@ hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float
 // ActNorm inverse (flow.py:177-187): y = (x - bias) / (exp(ls) + 1e-8).  Backward: dx = dy/den (in place on dy);
 // dbias[c] -= sum dy/den ; dls[c] -= sum dy (x - b)/den^2 * exp(ls)   [accumulated in float64 buffers s1, s2]
 __global__ void actnorm_inv_bwd_kernel(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b,
-                                       double* s_ls) {
+                                       double* s_ls, double* det) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
   double a1 = 0.0, a2 = 0.0;
@@ -2293,14 +2333,18 @@ __global__ void actnorm_inv_bwd_kernel(const float* x, float* dy, const float* l
   p1[rg][threadIdx.x & 63] = a1; p2[rg][threadIdx.x & 63] = a2;
   __syncthreads();
   if (rg == 0 && c < C) {
-    atomicAdd(&s_b[c], p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x]);
-    atomicAdd(&s_ls[c], p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x]);
+    const double t1 = p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x];
+    const double t2 = p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x];
+    if (det) { det[(size_t)blockIdx.y * C + c] = t1; det[((size_t)gridDim.y + blockIdx.y) * C + c] = t2; }
+    else { atomicAdd(&s_b[c], t1); atomicAdd(&s_ls[c], t2); }
   }
 }
 hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b,
                                   double* s_ls, hipStream_t s) {
   int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
-  vnr_launch(actnorm_inv_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, bias, M, C, s_b, s_ls);
+  double* det = static_cast<double*>(det_scratch(s, (size_t)2 * rb * C * sizeof(double)));
+  vnr_launch(actnorm_inv_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, bias, M, C, s_b, s_ls, det);
+  if (det) { hipError_t e = launch_det_finish_dd(det, rb, (size_t)C, s_b, s); return e != hipSuccess ? e : launch_det_finish_dd(det + (size_t)rb * C, rb, (size_t)C, s_ls, s); }
   return hipGetLastError();
 }
 // d eps = -eps * mask * g_b  (gradient of sum_t mask * -0.5 (log 2pi + eps^2)); written (not accumulated)
@@ -2363,7 +2407,7 @@ hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, con
 // dw += seed * 2 (log pred - log len) / pred * sum_t exp(.) x_t ; dbias likewise.  (x is stop_gradient'ed, models.py:133)
 __global__ void __launch_bounds__(256)
 length_loss_kernel(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len, int T, int D,
-                   float seed, float* pred, float* ll, float* dw, float* db) {
+                   float seed, float* pred, float* ll, float* dw, float* db, float* det) {
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ float e_t[1024];
   __shared__ double red[256];
@@ -2391,15 +2435,20 @@ length_loss_kernel(const float* x, const float* w, const float* bias, const int3
         const float e = t < 1024 ? e_t[t] : 0.f;
         s += e * x[((size_t)b * T + t) * D + d];
       }
-      atomicAdd(dw + d, gp * s);
+      if (det) det[(size_t)b * D + d] = gp * s; else atomicAdd(dw + d, gp * s);       // deterministic mode: [B][D] partials, then [B] for the bias
     }
-    if (tid == 0) atomicAdd(db, gp * p);
+    if (tid == 0) { if (det) det[(size_t)gridDim.x * D + b] = gp * p; else atomicAdd(db, gp * p); }
   }
 }
 hipError_t launch_length_loss(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len,
                               int B, int T, int D, float seed, float* pred, float* ll, float* dw, float* db, hipStream_t s) {
   if (T > 1024) return hipErrorInvalidValue;
-  vnr_launch(length_loss_kernel, dim3(B), dim3(256), 0, s, x, w, bias, text_len, mel_len, T, D, seed, pred, ll, dw, db);
+  float* det = dw ? static_cast<float*>(det_scratch(s, (size_t)B * (D + 1) * sizeof(float))) : nullptr;
+  vnr_launch(length_loss_kernel, dim3(B), dim3(256), 0, s, x, w, bias, text_len, mel_len, T, D, seed, pred, ll, dw, db, det);
+  if (det) {                 // utterances added in index order
+    hipError_t e = launch_det_finish_ff(det, B, (size_t)D, dw, s);
+    return e != hipSuccess ? e : launch_det_finish_ff(det + (size_t)B * D, B, 1, db, s);
+  }
   return hipGetLastError();
 }
 
@@ -2694,6 +2743,65 @@ hipError_t launch_opmajor_batch(const void* jobs_device, int njobs, float scale,
 hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, hipStream_t s) {
   if (njobs <= 0) return hipSuccess;
   vnr_launch(split_batch_kernel, dim3(32, njobs), dim3(256), 0, s, static_cast<const SplitJob*>(jobs_device), scale);
+  return hipGetLastError();
+}
+
+
+// ---- deterministic accumulation: ordered sums of per-workgroup partials (common.h: DetState) ---------------------------------------
+template <typename P, typename O>
+__global__ void det_finish_kernel(const P* __restrict__ part, int nparts, size_t n, O* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  P acc = part[i];
+  for (int p = 1; p < nparts; ++p) acc += part[(size_t)p * n + i];
+  out[i] += (O)acc;
+}
+hipError_t launch_det_finish_dd(const double* part, int nparts, size_t n, double* out, hipStream_t s) {
+  if (!n || nparts <= 0) return hipSuccess;
+  vnr_launch(det_finish_kernel<double, double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_det_finish_df(const double* part, int nparts, size_t n, float* out, hipStream_t s) {
+  if (!n || nparts <= 0) return hipSuccess;
+  vnr_launch(det_finish_kernel<double, float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_det_finish_ff(const float* part, int nparts, size_t n, float* out, hipStream_t s) {
+  if (!n || nparts <= 0) return hipSuccess;
+  vnr_launch(det_finish_kernel<float, float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  return hipGetLastError();
+}
+// kernel-gradient GEMMs: C[k][n] += sum over the row splits, in split order (16-byte accesses when N and ldc allow)
+__global__ void det_finish_2d_kernel(const float* __restrict__ part, int nparts, int K, int N, float* __restrict__ C, int ldc) {
+  const size_t kn = (size_t)K * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < kn; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = part[i];
+    for (int p = 1; p < nparts; ++p) acc += part[(size_t)p * kn + i];
+    const size_t k = i / N, n = i - k * N;
+    C[k * ldc + n] += acc;
+  }
+}
+__global__ void det_finish_2d4_kernel(const float* __restrict__ part, int nparts, int K, int N4, float* __restrict__ C, int ldc) {
+  const size_t kn = (size_t)K * N4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < kn; i += (size_t)gridDim.x * blockDim.x) {
+    float4 acc = reinterpret_cast<const float4*>(part)[i];
+    for (int p = 1; p < nparts; ++p) { const float4 v = reinterpret_cast<const float4*>(part)[(size_t)p * kn + i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    const size_t k = i / N4, n = (i - k * N4) * 4;
+    float4* dst = reinterpret_cast<float4*>(C + k * ldc + n);
+    float4 o = *dst; o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w; *dst = o;
+  }
+}
+hipError_t launch_det_finish_2d(const float* part, int nparts, int K, int N, float* C, int ldc, hipStream_t s) {
+  if (K <= 0 || N <= 0 || nparts <= 0) return hipSuccess;
+  if (!(N & 3) && !(ldc & 3) && !((size_t)C & 15) && !((size_t)part & 15)) {
+    const size_t n4 = (size_t)K * (N / 4);
+    unsigned blocks = (unsigned)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    vnr_launch(det_finish_2d4_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, K, N / 4, C, ldc);
+  } else {
+    const size_t n = (size_t)K * N;
+    unsigned blocks = (unsigned)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    vnr_launch(det_finish_2d_kernel, dim3(blocks), dim3(256), 0, s, part, nparts, K, N, C, ldc);
+  }
   return hipGetLastError();
 }
 

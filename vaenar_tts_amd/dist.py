@@ -1,13 +1,28 @@
-"""Multi-GPU plumbing for the batch-sharded inference path (one process per GPU).
+"""Multi-GPU plumbing of the batch-sharded path (one process per GPU) -- standard library only.
 
-Utterances are independent, so a global batch is split into contiguous
-per-rank shards and there is NO data-path collective; the only cross-rank traffic is control
-plane (barrier, max of elapsed time, gathering results on rank 0), carried by torch.distributed
-(gloo on CPU tensors -- the engine's device buffers never go through torch).
+Utterances are independent, so a global batch is split into contiguous per-rank shards and there is NO
+data-path collective in inference; training exchanges gradients with RCCL inside the engine (vnr_train_step).  What the host side
+needs between ranks is a control plane: a barrier, the max / mean of a scalar, gathering small host arrays on rank 0 and
+broadcasting the 128-byte RCCL unique id.  That is a star of TCP connections to rank 0, keyed on the launcher's
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's environment; `bench.py --gpus N` sets the same variables itself).
+No PyTorch here: torch.distributed (gloo) is only the checker of tests/test_dist_gloo.py.
+
+torchrun's own rendezvous store already listens on MASTER_PORT, so rank 0 listens on the first free port of
+MASTER_PORT + 1 ... + 32 (VNR_RDZV_PORT overrides the base) and every connection starts with a handshake that carries a job key
+(hash of MASTER_ADDR, MASTER_PORT, WORLD_SIZE): a foreign listener on a candidate port is skipped, not trusted.
 """
+import hashlib
+import io
 import os
+import socket
+import struct
+import time
 
 import numpy as np
+
+_MAGIC = b"VNRCTL1\0"
+_CANDIDATES = 32
+_state = {"rank": 0, "world": 1, "hub": None, "peers": None, "sock": None}
 
 
 def env_rank():
@@ -16,15 +31,134 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend="gloo"):
+def _job_key(addr, port, world):
+    return hashlib.sha256(("%s:%d:%d" % (addr, port, world)).encode()).digest()[:16]
+
+
+def _send(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control plane: peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+def init(backend=None, timeout=300.0):
+    """Join the control plane.  Returns (rank, local_rank, world).  `backend` is accepted for the callers' old signature."""
     rank, local_rank, world = env_rank()
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if not dist.is_initialized():
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world <= 1 or _state["sock"] is not None or _state["peers"] is not None:
+        return rank, local_rank, world
+    addr = os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    mport = int(os.environ.setdefault("MASTER_PORT", "29511"))
+    base = int(os.environ.get("VNR_RDZV_PORT", mport + 1))
+    key = _job_key(addr, mport, world)
+    deadline = time.monotonic() + timeout
+    _state.update(rank=rank, world=world)
+    if rank == 0:
+        srv = None
+        for p in range(base, base + _CANDIDATES):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost") else "", p))
+                s.listen(world + 8)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise RuntimeError("control plane: no free port in [%d, %d)" % (base, base + _CANDIDATES))
+        peers = {}
+        srv.settimeout(1.0)
+        while len(peers) < world - 1:
+            if time.monotonic() > deadline:
+                raise TimeoutError("control plane: %d of %d ranks joined within %.0f s" % (len(peers) + 1, world, timeout))
+            try:
+                c, _ = srv.accept()
+            except socket.timeout:
+                continue
+            try:
+                c.settimeout(3.0)
+                hello = _recv_exact(c, len(_MAGIC) + 16 + 4)
+                r = struct.unpack("<i", hello[-4:])[0]
+                if hello[:len(_MAGIC)] != _MAGIC or hello[len(_MAGIC):-4] != key or not (0 < r < world) or r in peers:
+                    c.close()
+                    continue
+                c.sendall(_MAGIC + key)
+                c.settimeout(None)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                peers[r] = c
+            except (OSError, ConnectionError, struct.error):
+                c.close()
+        srv.close()
+        _state.update(hub=True, peers=peers)
+    else:
+        sock = None
+        while sock is None:
+            if time.monotonic() > deadline:
+                raise TimeoutError("control plane: rank %d could not reach rank 0 at %s:%d+ within %.0f s" % (rank, addr, base, timeout))
+            for p in range(base, base + _CANDIDATES):
+                try:
+                    s = socket.create_connection((addr, p), timeout=2.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(3.0)
+                    s.sendall(_MAGIC + key + struct.pack("<i", rank))
+                    if _recv_exact(s, len(_MAGIC) + 16) == _MAGIC + key:
+                        s.settimeout(None)
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        sock = s
+                        break
+                    s.close()
+                except (OSError, ConnectionError):
+                    s.close()
+            if sock is None:
+                time.sleep(0.05)
+        _state.update(hub=False, sock=sock)
     return rank, local_rank, world
+
+
+def is_initialized():
+    return _state["peers"] is not None or _state["sock"] is not None
+
+
+def shutdown():
+    """Leave the control plane (after a final barrier by the caller)."""
+    if _state["peers"]:
+        for c in _state["peers"].values():
+            c.close()
+    if _state["sock"] is not None:
+        _state["sock"].close()
+    _state.update(hub=None, peers=None, sock=None, rank=0, world=1)
+
+
+def _exchange(payload, combine):
+    """Every rank contributes `payload` (bytes); rank 0 runs combine([payload of rank 0, 1, ...]) -> {rank: reply bytes} or one reply
+    for all; every rank returns its reply."""
+    if not is_initialized():
+        out = combine([payload])
+        return out[0] if isinstance(out, dict) else out
+    if _state["hub"]:
+        peers = _state["peers"]
+        parts = [payload] + [_recv(peers[r]) for r in range(1, _state["world"])]
+        out = combine(parts)
+        for r in range(1, _state["world"]):
+            _send(peers[r], out[r] if isinstance(out, dict) else out)
+        return out[0] if isinstance(out, dict) else out
+    _send(_state["sock"], payload)
+    return _recv(_state["sock"])
 
 
 def shard_bounds(n, rank, world):
@@ -42,46 +176,41 @@ def shard_batch(batch, rank, world):
 
 
 def barrier():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+    _exchange(b"", lambda parts: b"")
+
+
+def _reduce(x, fn):
+    def combine(parts):
+        return struct.pack("<d", fn([struct.unpack("<d", p)[0] for p in parts]))
+    return struct.unpack("<d", _exchange(struct.pack("<d", float(x)), combine))[0]
 
 
 def max_over_ranks(x):
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return _reduce(x, max)
+
+
+def mean_over_ranks(x):
+    return _reduce(x, lambda v: sum(v) / len(v))      # rank order: every rank gets the same float
 
 
 def gather_to_rank0(array):
     """Concatenate per-rank host arrays (equal trailing dims) on rank 0; None elsewhere."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    if not is_initialized():
         return array
-    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
-    dist.gather_object(array, out, dst=0)
-    return np.concatenate(out, 0) if out is not None else None
+    buf = io.BytesIO()
+    np.save(buf, np.ascontiguousarray(array), allow_pickle=False)
+    got = {}
+
+    def combine(parts):
+        got["all"] = np.concatenate([np.load(io.BytesIO(p), allow_pickle=False) for p in parts], 0)
+        return b""
+    _exchange(buf.getvalue(), combine)
+    return got.get("all")
 
 
 def broadcast_bytes(data, src=0):
     """Control-plane broadcast of a short byte string (the 128-byte RCCL unique id of data-parallel training)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    if not is_initialized():
         return data
-    box = [data if dist.get_rank() == src else None]
-    dist.broadcast_object_list(box, src=src)
-    return box[0]
-
-
-def mean_over_ranks(x):
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return float(x)
-    t = torch.tensor([float(x)], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item()) / dist.get_world_size()
+    me = _state["rank"]
+    return _exchange(bytes(data) if me == src else b"", lambda parts: parts[src])

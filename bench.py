@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--exact-fp32", action="store_true", help="disable the split-fp16 GEMM path (exact fp32 MFMA everywhere)")
+    ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra exact-fp32 pass (`exact_fp32` block)")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B switches), repeatable")
     ap.add_argument("--streams", type=int, default=1,
                     help="engine handles (= HIP streams) the K timed steps of `value` are dealt to.  1 (default) = the strictly "
@@ -246,6 +247,9 @@ def run_rank(args):
         "metric": "mel-frames/sec", "value": value, "unit": "mel-frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value_definition": "B * T_mel * n_gpus / (wall time of the K timed steps / K): K calls of VAENAR.inference issued one after another on one "
+                            "engine handle, token ids / lengths / noise resident in HBM, bracketed by barrier + stream synchronisation (the bench "
+                            "contract).  SURVEY D1 (ids on the host -> mel on the host, median of single calls) is `latency_host_to_host_ms`",
         "dtype": "f32" if args.exact_fp32 else split_note,
         "data": "synthetic",
         "config": {"workload": "S1 VAENAR.inference: B=16 per GPU, T_text=128, T_mel=800, 80-bin, rf=2, "
@@ -260,17 +264,25 @@ def run_rank(args):
         eng.profile(True)
         eng.profile_reset()
         launches0 = eng.launch_count()
+        eng.synchronize()
+        tp0 = time.perf_counter()
         for _ in range(args.profile_steps):
             run_on(lanes[0])
         eng.synchronize()
         ps = max(1, args.profile_steps)
+        profiled_ms_per_step = 1e3 * (time.perf_counter() - tp0) / ps      # the pass the per-kernel numbers come from (event-attached launches)
         launches = (eng.launch_count() - launches0) // ps
-        classes = ("chain", "gemm", "gemm_fp32", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc")
+        classes = ("chain", "chain_ali", "gemm", "gemm_fp32", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc")
         prof = {c: eng.profile_get(c) for c in classes}
         eng.profile(False)
         eng.profile_reset()
         traffic, traffic_note = load_traffic_record()
         kernel_ms = {c: p["ms"] / ps for c, p in prof.items()}
+        # the chain class = every panel_chain_kernel launch: the ones that also write the decoder alignments ("chain_ali") included
+        fused_ali = dict(prof["chain_ali"])
+        for k in ("ms", "launches", "flops"):
+            prof["chain"][k] += prof["chain_ali"][k]
+        prof["chain_ali"] = {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0}
         names = {"chain": "panel_chain_kernel (row-panel chains of the attention blocks: att_proj+LN -> query; att_proj+LN -> FFN -> LN "
                           "-> next Q|K|V / heads), 3-term split-fp16 MFMA 32x32x16",
                  "gemm": "gemm2_kernel family (LDS-DMA ring; Dense / concat / Conv1D / LN epilogues), 3-term split-fp16 MFMA 32x32x16",
@@ -305,6 +317,21 @@ def run_rank(args):
                 "frac_fp32_mfma_peak_algorithmic": sum(prof[c]["flops"] for c in mm) / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             }
         a = prof["attn_cross_ali"]
+        if not a["launches"] and fused_ali["launches"]:
+            # round 4: the decoder's cross-attention runs inside the block's chain launch, which writes the alignments itself -- there
+            # is no stand-alone (HBM-bound) cross-attention kernel left to price against 8 TB/s.  What the fused launch moves and takes:
+            n = fused_ali["launches"]
+            out["roofline_cross_attention"] = {
+                "kernel": "none: the decoder blocks' cross-attention (alignments included) is a phase of panel_chain_kernel<1> since round 4",
+                "fused_launch": {"launches_per_step": n // ps, "avg_launch_us": 1e3 * fused_ali["ms"] / n,
+                                 "algorithmic_tflops": fused_ali["flops"] / (fused_ali["ms"] * 1e-3) / 1e12,
+                                 "frac_f16_peak_executed": SPLIT_TERMS * fused_ali["flops"] / (fused_ali["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                 "attention_core_bytes_per_launch": fused_ali["bytes"] / n,
+                                 "alignment_bytes_per_launch": 4.0 * B * 4 * (Tm // rf) * Tt,
+                                 "note": "attention_core_bytes = Q + K,V + context + alignments as SURVEY D3 counts a stand-alone core (30.41 MB); "
+                                         "inside the launch Q and the context stay in LDS: only K,V images (4.2 MB) are read and the alignments "
+                                         "(13.1 MB) written for the attention phase"},
+                "bound": "mfma (the launch is a row-panel chain of 12+ dense stages)", "frac": None}
         if a["launches"]:
             gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             out["roofline_cross_attention"] = {
@@ -323,6 +350,7 @@ def run_rank(args):
             "kernel_launches_per_step": launches,
             "kernel_ms_per_step": kernel_ms,
             "kernel_ms_sum": sum(kernel_ms.values()),
+            "profiled_pass_ms_per_step": profiled_ms_per_step,      # wall time of the pass the per-kernel numbers were taken on (>= kernel_ms_sum)
         }
         out["device"] = eng.device_info()
         out["kernel_source_digest"] = kernel_source_digest()
@@ -341,6 +369,24 @@ def run_rank(args):
                                           "note": "SURVEY D1: one S1 batch, token ids and lengths uploaded, 4.1 MB of mels downloaded, "
                                                   "alignments not requested; PCIe-inclusive, never `value`"}
 
+    if rank == 0 and not args.exact_fp32 and not args.no_exact_pass:
+        # ---- the same step on exact fp32 MFMA (32x32x2), one pass: what the 22-bit split buys and costs -----------------------------
+        import numpy as _np
+        eng.set_option("split_fp16", 0)
+        for _ in range(2):
+            run_on(lanes[0])
+        eng.synchronize()
+        te = time.perf_counter()
+        ne = max(3, args.steps // 4)
+        for _ in range(ne):
+            mel_e, _ae = run_on(lanes[0])
+        eng.synchronize()
+        exact_ms = 1e3 * (time.perf_counter() - te) / ne
+        eng.set_option("split_fp16", 1)
+        out["exact_fp32"] = {"ms_per_step": exact_ms, "max_abs_mel_diff_vs_split": float(_np.abs(mel_e.numpy() - mel.numpy()).max()),
+                             "note": "engine option split_fp16=0: every GEMM / attention product on v_mfma_f32_32x32x2_f32; max_abs_mel_err "
+                                     "against the fp32 oracle is in `parity` (split path) and below (exact path)"}
+        out["_mel_exact"] = mel_e
     # ---- side block: several independent batches in flight on one GPU (every rank; rank 0 reports) --------------------------
     if args.in_flight > 1 and nstreams == 1:
         extra = [make_lane(si, True) for si in range(args.in_flight)]
@@ -355,8 +401,12 @@ def run_rank(args):
         for ln in extra:
             ln["model"].engine.close()
 
+    mel_exact = out.pop("_mel_exact", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out.update(cpu_baseline_block(args, hps, weights, batch, mel, value))
+        out.update(cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact))
+        if mel_exact is not None and "exact_fp32" in out and "_exact_err" in out:
+            out["exact_fp32"]["max_abs_mel_err"] = out.pop("_exact_err")
+    out.pop("_exact_err", None)
 
     if not args.no_train:
         for ln in lanes:
@@ -387,7 +437,7 @@ def run_rank(args):
         vdist.shutdown()
 
 
-def cpu_baseline_block(args, hps, weights, batch, mel, value):
+def cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact=None):
     """CPU baseline: stand-ins for the reference's TF2-CPU path (which cannot run: no TensorFlow) on this box's host cores."""
     import numpy as np
     from oracle.vaenar_numpy import Oracle
@@ -443,6 +493,8 @@ def cpu_baseline_block(args, hps, weights, batch, mel, value):
     }}
     got = mel.numpy()
     res["parity"] = {"max_abs_mel_err": float(np.abs(got - ref).max()), "against": "oracle fp32 on the same batch", "tolerance": 1e-3}
+    if mel_exact is not None:
+        res["_exact_err"] = float(np.abs(mel_exact.numpy() - ref).max())
     res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
     return res
 
@@ -485,13 +537,44 @@ def training_block(args, hps, device, rank, world):
         if world > 1:
             vdist.barrier()
         tdt = vdist.max_over_ranks((time.perf_counter() - t1) / nst)
+        rccl_ranks, rccl_rank = (tm.engine.comm_info() if world > 1 else (1, 0))        # what RCCL says (ncclCommCount / ncclCommUserRank)
+        # one more step with dispatch events on every heavy launch: executed matrix-pipe FLOPs and the dominant kernel class
+        tm.engine.profile(True); tm.engine.profile_reset()
+        tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=(2 + nst) * world + rank)
+        tm.engine.synchronize()
+        tcls = ("gemm", "gemm_fp32", "chain", "gemm_tn", "bwd_chain", "attn_bwd", "attn_self", "attn_cross")
+        tprof = {c: tm.engine.profile_get(c) for c in tcls}
+        tm.engine.profile(False); tm.engine.profile_reset()
+        exec_mult = {"gemm": SPLIT_TERMS, "chain": SPLIT_TERMS, "gemm_tn": SPLIT_TERMS, "bwd_chain": SPLIT_TERMS, "attn_bwd": SPLIT_TERMS,
+                     "attn_self": SPLIT_TERMS, "attn_cross": SPLIT_TERMS, "gemm_fp32": 1}
+        f16_flops = sum(tprof[c]["flops"] * exec_mult[c] for c in tcls if c != "gemm_fp32")
+        fp32_flops = tprof["gemm_fp32"]["flops"]
+        tdom = max((c for c in tcls if tprof[c]["launches"]), key=lambda c: tprof[c]["ms"], default=None)
+        troof = None
+        if tdom:
+            d = tprof[tdom]
+            troof = {
+                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_F16_MFMA_TFLOPS,
+                "achieved": f16_flops / tdt / 1e12, "frac": f16_flops / tdt / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                "definition": "EXECUTED f16 MFMA FLOPs of one step (3 x the algorithmic 2*M*N*K of every split-fp16 launch: forward / "
+                              "data-gradient GEMMs, forward and backward chains, kernel-gradient GEMMs, attention forward and backward) / "
+                              "step time / 2.5 PF; the exact-fp32 convolution forwards are listed apart",
+                "executed_f16_gflop_per_step": f16_flops / 1e9, "fp32_mfma_gflop_per_step": fp32_flops / 1e9,
+                "dominant_kernel": {"class": tdom, "launches_per_step": d["launches"], "ms_per_step_beside_the_other_stream": d["ms"],
+                                    "executed_tflops": exec_mult[tdom] * d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else None,
+                                    "frac_f16_peak": exec_mult[tdom] * d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS if d["ms"] > 0 else None},
+                "classes_ms": {c: tprof[c]["ms"] for c in tcls if tprof[c]["launches"]},
+                "note": "class times are durations beside the other stream (main chain and kernel-gradient stream overlap) and do not "
+                        "add up to the step; attn_bwd times the dQ kernel of each pair only",
+            }
         blk = {
             "workload": ("T1" if world == 1 else "T2") + " train_step (train.py:127-138): training-mode ELBO forward + backward of all 501 "
                         "variables + Adam, B=32 per GPU, T_text=128, T_mel=800, rf=2, LJHPS; forward / data-gradient GEMMs on the 3-term "
                         "split-fp16 path (convolution forward exact fp32), kernel gradients split-fp16; "
                         + ("1 GPU, no gradient all-reduce" if world == 1 else
                            "%d ranks, flat 138.9 MB fp32 gradient all-reduced with RCCL inside every step" % world),
-            "ms_per_step": 1e3 * tdt, "mel_frames_per_s": TB * Tm * world / tdt, "steps": nst, "rccl_ranks": world,
+            "ms_per_step": 1e3 * tdt, "mel_frames_per_s": TB * Tm * world / tdt, "steps": nst, "rccl_ranks": rccl_ranks, "rccl_rank": rccl_rank,
+            "world_size_env": world, "roofline": troof,
             "kernel_launches_per_step": (tm.engine.launch_count() - n0) // nst,
             "approx_tflops": 3.0 * ALG_GFLOP_S1 * (TB / S1["B"]) * world * 1e9 / tdt / 1e12,
             "loss": res[0], "mel_l2": res[1], "kl": res[2], "length_l2": res[3],

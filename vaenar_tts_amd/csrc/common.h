@@ -198,6 +198,8 @@ struct GemmArgs {
   // (x = hi + lo) -- the SAME 128 bytes per (row, tile) as fp32, so every address of the LDS-DMA (plain and conv tap walker) is
   // unchanged, but the consumer's k-loop needs no fp32 -> (hi, lo) conversion (which outweighed the MFMAs: the same element is
   // converted once per tap and per column tile, 40x for an encoder convolution).  Split path (Wsplit) only.
+  int nslice = 0;                   // tile raster: every XCD owns a slice of the N columns (all row tiles of tiles_n / 8 column tiles) instead of
+                                    // a run of row tiles -- for a weight panel that does not fit one XCD's L2 (set by launch_gemm2, see gemm2.hip)
   int a_split = 0;                  // A1 (and A2) are split rows
   int c_split = 0;                  // C is written as split rows (ldc = C columns, bytes per row = 4 * ldc)
 };
@@ -279,6 +281,17 @@ struct ChainArgs {
   int att_Tq, att_Tk, att_B;                   // rows per batch element, keys, batch
   float att_temp;
   int att_lds;                                 // (set by launch_panel_chain) byte offset of the merge scratch in LDS
+  float* att_ali;                              // alignments [B][H][Tq][Tk] fp32 (attention.py:242-246 `alignments`) or null: the decoder's blocks
+                                               // (decoder.py:188-192) leave them from the fused launch too (round 4; att_Tk % 4 == 0)
+  // Fused flow coupling (flow.py:223-239; round 4): stage `cpl_stage` (<= 0 = none) is the log_scale | shift head pair of a
+  // TransformerCoupling (n = 2 hc columns: log_scale, then shift).  Its epilogue applies the affine coupling to this panel's rows of z
+  // instead of storing the heads: zp' = sigmoid(log_scale + 2) * zp + shift on columns [cpl_zp_off, + hc) of cpl_z (row stride cpl_ld),
+  // written back in place, and leaves the whole new z (conditioning half | zp') in panel `st.dst` in split form -- the stages behind it
+  // are then the NEXT flow step's ActNorm o InvertibleLinear, pre_projection and first Q|K|V (or the decoder's pre_projection): the
+  // coupling kernel and the next step's pre-chain launch disappear.
+  int cpl_stage;
+  float* cpl_z; int cpl_ld, cpl_zp_off, cpl_cond_off;
+  int cpl_lds;                                 // (set by launch_panel_chain) byte offset of the shift exchange scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage

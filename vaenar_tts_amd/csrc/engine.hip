@@ -65,8 +65,12 @@ struct FlowStep {
 struct ProfRec { int cls; hipEvent_t e0, e1; double flops, bytes; };
 // "gemm": tiled GEMM launches on the split-fp16 path (3 f16 MFMA FLOPs per algorithmic FLOP); "gemm_fp32": tiled GEMM launches on
 // exact fp32 MFMA; "chain": panel_chain_kernel launches (always split)
-enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_GEMM_F32, CLS_CHAIN, CLS_COUNT };
-const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc", "gemm_fp32", "chain"};
+// "chain_ali": chain launches whose fused cross-attention also writes the alignments (the decoder's blocks since round 4)
+// training step only: "gemm_tn" kernel-gradient GEMMs (split), "bwd_chain" backward row-panel chains (split), "attn_bwd" attention backward (split)
+enum { CLS_GEMM = 0, CLS_ATTN_SELF, CLS_ATTN_CROSS, CLS_ATTN_CROSS_ALI, CLS_LN, CLS_MISC, CLS_GEMM_F32, CLS_CHAIN, CLS_CHAIN_ALI, CLS_GEMM_TN, CLS_BWD_CHAIN,
+       CLS_ATTN_BWD, CLS_COUNT };
+const char* kClsNames[CLS_COUNT] = {"gemm", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc", "gemm_fp32", "chain", "chain_ali", "gemm_tn",
+                                    "bwd_chain", "attn_bwd"};
 
 // Dropout sites (one mask stream per tf.keras.layers.Dropout instance of the path): encoder.py:70,87; utils.py:73,84
 // (prenet / postnet convolutions); utils.py:11-17 (posterior PreNet, two uses of one layer); posterior.py:99,122
@@ -261,6 +265,13 @@ bool split_lookup(vnr_handle h, const float* Wt, int K, int N, SplitRef& out) {
 }
 struct Tail { const float* wt; int n; const float* bias; float* out; int ldo; int qkv_T = 0, qkv_B = 0; };   // qkv_T > 0: a Q|K|V panel written as operand images (rows per batch element, batch)   // extra Dense(D -> n) on the block output
 
+struct PreStage { const float* wt; int K, N; int src, akt0; const float* bias; const float* pe; int pe_T; float pe_w;
+                  float* out; int ldo; int dst; int qkv_T = 0, qkv_B = 0; };
+// What follows the log_scale | shift heads of a flow step inside the SAME chain launch (ChainArgs::cpl_stage, gemm3.hip): the affine
+// coupling on z (in place) and the next pre-chain -- the next flow step's ActNorm o InvertibleLinear, pre_projection (+PE) and first
+// Q|K|V, or the decoder's pre_projection and first Q|K|V.  The coupled z sits in panel 1; `stages` name chain panels (0 .. 2).
+struct PostChain { float* z; int ld, zp_off, cond_off; std::vector<PreStage> stages; };
+
 // The chain kernel reads the epilogue parameters (bias | gamma | beta, 256 floats each, per stage) of its whole program
 // as ONE contiguous block: it is assembled once per distinct program (device-to-device copies, stream ordered) and cached.
 int chain_params(vnr_handle h, ChainArgs& g) {
@@ -293,7 +304,11 @@ int chain_params(vnr_handle h, ChainArgs& g) {
 int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   TRY(chain_params(h, g));
   g.rows64 = h->chain_rows64 ? 1 : 0;
-  ProfScope ps(h, CLS_CHAIN, flops, 0.0);
+  // bytes of a launch that also writes alignments: the attention core's own traffic as SURVEY D3 counts it (Q + K, V + context +
+  // alignments) -- Q and the context never reach HBM here, the figure is what a stand-alone core would move
+  const double ali_bytes = (g.att_stage > 0 && g.att_ali)
+      ? 4.0 * ((double)g.M * g.D * 2 + (double)g.att_B * g.att_Tk * g.D * 2) + 4.0 * (double)g.M * (g.D / 64) * g.att_Tk : 0.0;
+  ProfScope ps(h, ali_bytes > 0 ? CLS_CHAIN_ALI : CLS_CHAIN, flops, ali_bytes);
   hipError_t e = launch_panel_chain(g, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("panel chain launch: ") + hipGetErrorString(e));
   return VNR_OK;
@@ -513,7 +528,9 @@ const vnr_context::KvAoi* find_kv_aoi(vnr_handle h, const float* kv, int col, in
 // block's Q|K|V, the flow heads, the decoder out-projection, the posterior heads).
 int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const float* kv, int kv_ld,
              const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau,
-             float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails, bool self_aoi) {
+             float* ali, float* qkv, bool qkv_ready, const std::vector<Tail>& tails, bool self_aoi,
+             const PostChain* post = nullptr, bool* post_done = nullptr) {
+  if (post_done) *post_done = false;
   const int M = B * Tq, D = k.D, F = k.F;
   // cross K|V written as attention operand images (run_kv): the query is produced as an image too and attention3 runs
   int kv_blk = 0;
@@ -555,12 +572,31 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
   }
   const int PT = D / 32, nchunks = (F + 255) / 256;
   if (chain && 1 + 2 * nchunks + tail_stages > kMaxChainStages) chain = false;
+  // the coupling + next pre-chain behind the heads: needs the three panels of a 32-row workgroup, one tail of <= 256 columns that is
+  // the log_scale | shift pair, and split images of every appended layer
+  std::vector<SplitRef> r_p;
+  int post_stages = 0;
+  bool post_ok = chain && post && !h->chain_rows64 && tails.size() == 1 && !(tails[0].n & 63) && tails[0].n <= 256 && tails[0].qkv_T == 0;
+  static const bool no_post = getenv("VNR_NO_POSTCHAIN") != nullptr;      // A/B switch: coupling kernel + pre-chain launch per flow step
+  if (no_post) post_ok = false;
+  if (post_ok) {
+    r_p.resize(post->stages.size());
+    for (size_t i = 0; post_ok && i < post->stages.size(); ++i) {
+      const PreStage& ps = post->stages[i];
+      post_ok = !(ps.K & 31) && ps.K <= 256 && !(ps.N & 3) && !(ps.out && (ps.ldo & 3)) && !(ps.N > 256 && ps.dst >= 0) &&
+                split_lookup(h, ps.wt, ps.K, ps.N, r_p[i]) && r_p[i].opm;
+      post_stages += (ps.N + 255) / 256;
+    }
+  }
 
   // one launch for the whole block after the self-attention (chain B -> cross-attention -> chain C): the query projection leaves
   // q in LDS, the workgroup attends over the text K/V images itself and continues with the context in place (gemm3.hip,
   // ChainArgs::att_stage).  Needs the operand images of the memory, no alignment output, 32-row panels, four 64-wide heads.
-  const bool fused = chain && ka && !ali && h->fuse_xattn && !h->chain_rows64 && D == 256 && heads * 64 == D && Tt <= 128 &&
+  // (round 4: also when the alignments ARE requested -- the decoder's blocks, decoder.py:188-192: the workgroup writes its rows of them)
+  static const bool no_fuse_ali = getenv("VNR_NO_FUSE_ALI") != nullptr;      // A/B switch: chain B, attn3_kernel<true>, chain C as three launches
+  const bool fused = chain && ka && (!ali || (!(Tt & 3) && !no_fuse_ali)) && h->fuse_xattn && !h->chain_rows64 && D == 256 && heads * 64 == D && Tt <= 128 &&
                      3 + 2 * nchunks + tail_stages <= kMaxChainStages;
+  if (post_ok && (fused ? 3 : 1) + 2 * nchunks + tail_stages + post_stages > kMaxChainStages) post_ok = false;
   ChainArgs cb; memset(&cb, 0, sizeof(cb));
   if (chain) {
     // chain B: y = LN1(att_proj1(concat(x, sa)) + x) ; q = y . Wq
@@ -613,9 +649,10 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
       c.att_stage = 2;
       c.att_K = ka->d.qk + (size_t)kv_blk * ka->d.blk_bytes; c.att_V = ka->d.vt + (size_t)kv_blk * ka->d.blk_bytes;
       c.att_qlen = q_len; c.att_klen = m_len; c.att_Tq = Tq; c.att_Tk = Tt; c.att_B = B; c.att_temp = tau;
+      c.att_ali = ali;                                     // (then the context is left in panel 2: the alignment pass needs the queries once more)
     }
     ChainStage* s = &c.st[n++];
-    s->w = r_p2.opm; s->kt_total = r_p2.kt_total; s->kt0 = 0; s->nk = 2 * PT; s->n = D; s->a0 = 0; s->a1 = 1; s->asw = PT; s->bias = k.proj2_b; s->act = ACT_IDENTITY;
+    s->w = r_p2.opm; s->kt_total = r_p2.kt_total; s->kt0 = 0; s->nk = 2 * PT; s->n = D; s->a0 = 0; s->a1 = (fused && ali) ? 2 : 1; s->asw = PT; s->bias = k.proj2_b; s->act = ACT_IDENTITY;
     s->res = 0; s->gamma = k.ln2_g; s->beta = k.ln2_b; s->acc_mode = 0; s->out = nullptr; s->ldo = 0; s->dst = 0; s->scale = r_p2.scale;
     for (int ch = 0; ch < nchunks; ++ch) {                 // hidden columns [256*ch, 256*ch + w)
       const int c0 = ch * 256, w = (F - c0 < 256) ? F - c0 : 256;
@@ -645,6 +682,26 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
                                   s->aoi_img_bytes = aoi_img_bytes(tails[i].qkv_B, tails[i].qkv_T, tails[i].n / 3); }
         fl += 2.0 * M * D * (double)w;
       }
+    if (post_ok) {
+      // the heads stay on the CU: coupling in their epilogue, the coupled z in panel 1, then the appended pre-chain
+      ChainStage& hs = c.st[n - 1];
+      hs.out = nullptr; hs.ldo = 0; hs.dst = 1;
+      c.cpl_stage = n - 1; c.cpl_z = post->z; c.cpl_ld = post->ld; c.cpl_zp_off = post->zp_off; c.cpl_cond_off = post->cond_off;
+      for (size_t i = 0; i < post->stages.size(); ++i) {
+        const PreStage& ps = post->stages[i];
+        for (int c0 = 0; c0 < ps.N; c0 += 256) {
+          s = &c.st[n++];
+          s->w = r_p[i].opm + (size_t)(c0 / 32) * r_p[i].kt_total * 4096; s->kt_total = r_p[i].kt_total; s->kt0 = 0; s->nk = ps.K / 32;
+          s->n = ps.N - c0 < 256 ? ps.N - c0 : 256; s->a0 = ps.src; s->a1 = ps.src; s->asw = s->nk; s->akt0 = ps.akt0;
+          s->bias = ps.bias ? ps.bias + c0 : nullptr; s->act = ACT_IDENTITY; s->res = -1; s->acc_mode = 0;
+          s->pe = ps.pe; s->pe_T = ps.pe_T; s->pe_w = ps.pe_w;
+          s->out = ps.out ? ps.out + c0 : nullptr; s->ldo = ps.ldo; s->dst = ps.dst; s->scale = r_p[i].scale;
+          if (ps.out && ps.qkv_T > 0) { s->out = ps.out; s->out_fmt = 4; s->aoi_T = ps.qkv_T; s->aoi_D = ps.N / 3; s->aoi_c0 = c0; s->aoi_img_bytes = aoi_img_bytes(ps.qkv_B, ps.qkv_T, ps.N / 3); }
+          fl += 2.0 * M * (double)ps.K * s->n;
+        }
+      }
+      if (post_done) *post_done = true;
+    }
     c.nstages = n;
     TRY(run_chain(h, c, fl));
     return VNR_OK;
@@ -675,8 +732,6 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
 // InvertibleLinear -> pre_projection (+PE) on the conditioning half -> Q|K|V of the first block.  Every stage reads a
 // panel (optionally from a k-tile offset: a column window) and may write HBM and/or a panel; wide outputs are cut into
 // 256-column stages.  *done = false (nothing launched) when a split image is missing or a shape does not fit.
-struct PreStage { const float* wt; int K, N; int src, akt0; const float* bias; const float* pe; int pe_T; float pe_w;
-                  float* out; int ldo; int dst; int qkv_T = 0, qkv_B = 0; };
 int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const std::vector<PreStage>& stages, bool* done) {
   *done = false;
   static const bool off = getenv("VNR_NO_PRECHAIN") != nullptr;       // A/B switch
@@ -711,7 +766,9 @@ int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const
 // i+1's Q|K|V; `tails` are applied to the last block's output.  Returns the buffer holding the stack output.
 int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb, const float* kv, int kv_ld,
                const int32_t* q_len, const int32_t* m_len, int B, int Tq, int Tt, int heads, float tau, float* ali_base,
-               size_t ali_stride, const std::vector<Tail>& tails, float** result, float* qkv_pre = nullptr) {
+               size_t ali_stride, const std::vector<Tail>& tails, float** result, float* qkv_pre = nullptr,
+               const PostChain* post = nullptr, bool* post_done = nullptr) {
+  if (post_done) *post_done = false;
   const int M = B * Tq;
   float* xc = xa; float* xn = xb;
   if (blks.empty()) { *result = xc; return VNR_OK; }
@@ -727,8 +784,9 @@ int run_xstack(vnr_handle h, const std::vector<XBlk>& blks, float* xa, float* xb
     std::vector<Tail> t;
     if (b + 1 < blks.size()) t.push_back({blks[b + 1].qkv_wt, 3 * D, nullptr, qn, 3 * D, saoi ? Tq : 0, B});
     else t = tails;
+    const bool last = b + 1 == blks.size();
     TRY(run_xblk(h, blks[b], xc, xn, kv, kv_ld, q_len, m_len, B, Tq, Tt, heads, tau,
-                 ali_base ? ali_base + b * ali_stride : nullptr, qc, ready, t, saoi));
+                 ali_base ? ali_base + b * ali_stride : nullptr, qc, ready, t, saoi, last ? post : nullptr, last ? post_done : nullptr));
     ready = b + 1 < blks.size();      // (also true on the unfused path: the tails loop computed it)
     std::swap(xc, xn); std::swap(qc, qn);
   }
@@ -878,12 +936,17 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
   return VNR_OK;
 }
 
-// TransformerPrior.sample (prior.py:154-169); kv = prior cross K|V panel output [B*Tt, kv_ld]
+// TransformerPrior.sample (prior.py:154-169); kv = prior cross K|V panel output [B*Tt, kv_ld].
+// final_post / final_done: stages to run behind the LAST flow step's coupling inside its chain launch (the decoder's pre-chain in
+// vnr_inference; the coupled z is in panel 1) and whether that happened.
 int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B,
-               int Tz, int Tt, const float* eps, float* z_out, float* logprobs) {
+               int Tz, int Tt, const float* eps, float* z_out, float* logprobs, const std::vector<PreStage>* final_post = nullptr,
+               bool* final_done = nullptr) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
-  WS(za, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M);
+  if (final_done) *final_done = false;
+  WS(za, (size_t)M * C); WS(xa0, (size_t)M * D); WS(xa1, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M);
+  float* xas[2] = {xa0, xa1};
   if (eps) HIP_TRY(h, hipMemcpyAsync(za, eps, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
   else HIP_TRY(h, hipMemsetAsync(za, 0, (size_t)M * C * 4, h->stream));
   if (logprobs) RUN_MISC(h, launch_gauss_logprob(eps, z_len, B, Tz, C, logprobs, h->stream));
@@ -892,23 +955,38 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
   WS(zb, (size_t)M * C);
   float* zc = za;
   const int nsteps = (int)h->flow.size();
+  const bool saoi = self_aoi_on(h, D, c.prior_attention_heads);
+  // the pre-chain of flow step s on chain panels (p_in -> p_mid -> p_out): (ActNorm o InvertibleLinear) -> pre_projection +
+  // pos_weight * PE on the conditioning half -> Q|K|V of the first block
+  auto pre_stages = [&](int s, float* dst, float* xa, float* qkv_pre, int p_in, int p_mid, int p_out) {
+    const FlowStep& f = h->flow[s];
+    const int cond_off = (s % 2) == 0 ? 0 : half;
+    return std::vector<PreStage>{
+        PreStage{f.fold_wt, C, C, p_in, 0, f.fold_b, nullptr, 1, 0.f, dst, C, p_mid},
+        PreStage{f.pre_wt, half, D, p_mid, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, p_out},
+        PreStage{f.blks[0].qkv_wt, D, 3 * D, p_out, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}};
+  };
+  auto step_dst = [&](int s, float* cur) { return (s == nsteps - 1) ? z_out : (cur == za ? zb : za); };
+  auto chainable = [&](int s) { return !h->flow[s].blks.empty() && !(half & 31) && h->flow[s].blks[0].D == D; };
+  bool pre_done = false;                                  // this step's pre-chain ran at the end of the previous step's last chain launch
+  float* qkv_pre = nullptr;
+  float* dst = nullptr;
   for (int s = 0; s < nsteps; ++s) {
     const FlowStep& f = h->flow[s];
-    float* dst = (s == nsteps - 1) ? z_out : (zc == za ? zb : za);
+    if (!pre_done) dst = step_dst(s, zc);
+    float* xa = xas[s & 1];
     const bool upper = (s % 2) == 0;                      // prior.py:85-87
     const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;   // flow.py:227-228
     // one row-panel chain: (ActNorm o InvertibleLinear) -> pre_projection + pos_weight*PE on the conditioning half -> Q|K|V
     // of the first block (three launches otherwise)
-    bool fused = false;
-    float* qkv_pre = nullptr;
-    if (!f.blks.empty() && !(half & 31) && f.blks[0].D == D) {
-      const bool saoi = self_aoi_on(h, D, c.prior_attention_heads);
-      qkv_pre = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
-      if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
-      TRY(run_prechain(h, zc, C, C, M,
-                       {PreStage{f.fold_wt, C, C, 0, 0, f.fold_b, nullptr, 1, 0.f, dst, C, 1},
-                        PreStage{f.pre_wt, half, D, 1, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, 0},
-                        PreStage{f.blks[0].qkv_wt, D, 3 * D, 0, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}}, &fused));
+    bool fused = pre_done;
+    if (!pre_done) {
+      qkv_pre = nullptr;
+      if (chainable(s)) {
+        qkv_pre = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
+        if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+        TRY(run_prechain(h, zc, C, C, M, pre_stages(s, dst, xa, qkv_pre, 0, 1, 0), &fused));
+      }
     }
     GemmArgs g;
     if (!fused) {
@@ -921,17 +999,36 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
       TRY(run_gemm(h, g));
     }
     if (logprobs) RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)(-f.logdet_per_frame), B, h->stream));
+    // behind the heads of this step's last block, in the same chain launch: the coupling on dst and the NEXT pre-chain (the next flow
+    // step's, or the caller's after the last step).  Not when the log-determinants are wanted (the coupling kernel leaves them).
+    PostChain post; post.z = dst; post.ld = C; post.zp_off = zp_off; post.cond_off = cond_off;
+    float* next_dst = nullptr; float* next_qkv = nullptr;
+    bool want_post = !logprobs && chainable(s) && !(C & 63);
+    if (want_post && s + 1 < nsteps) {
+      if (chainable(s + 1)) {
+        next_dst = step_dst(s + 1, dst);
+        next_qkv = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
+        if (!next_qkv) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+        post.stages = pre_stages(s + 1, next_dst, xas[(s + 1) & 1], next_qkv, 1, 2, 0);
+      }
+    } else if (want_post && final_post) post.stages = *final_post;
     float* xc = nullptr;        // the log_scale | shift heads ride on the last block's chain (tail)
+    bool post_done = false;
     TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
-                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc, qkv_pre));
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc, qkv_pre, want_post ? &post : nullptr, &post_done));
     if (f.blks.empty()) {
       g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b;
       g.C = heads; g.ldc = C; g.M = M; g.N = C;
       TRY(run_gemm(h, g));
     }
-    RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, logprobs ? rowld : nullptr, h->stream));
-    if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));
+    if (!post_done) {
+      RUN_MISC(h, launch_coupling_fwd(heads, dst, M, half, zp_off, logprobs ? rowld : nullptr, h->stream));
+      if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, -1.0f, logprobs, 1, h->stream));
+    }
     zc = dst;
+    pre_done = post_done && !post.stages.empty() && s + 1 < nsteps;
+    if (pre_done) { dst = next_dst; qkv_pre = next_qkv; }
+    if (post_done && s + 1 == nsteps && final_post && !post.stages.empty() && final_done) *final_done = true;
   }
   if (nsteps == 0) HIP_TRY(h, hipMemcpyAsync(z_out, za, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
   return VNR_OK;
@@ -1001,24 +1098,33 @@ int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, co
 }
 
 // TransformerDecoder.call (decoder.py:181-199); kv = decoder cross K|V panel output
+// the decoder's pre-chain (pre_projection -> Q|K|V of the first block) on chain panels p_in -> p_mid
+std::vector<PreStage> decoder_pre_stages(vnr_handle h, int B, int Tz, float* xa, float* qkv_pre, int p_in, int p_mid) {
+  const vnr_config& c = h->cfg;
+  const int C = c.latent_dim, D = c.dec_attention_dim;
+  const bool saoi = self_aoi_on(h, D, c.dec_attention_heads);
+  return {PreStage{h->dec_pre_wt, C, D, p_in, 0, h->dec_pre_b, nullptr, 1, 0.f, xa, D, p_mid},
+          PreStage{h->dec_blks[0].qkv_wt, D, 3 * D, p_mid, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}};
+}
+// pre_xa / pre_qkv: the pre-chain already ran (behind the prior's last coupling, vnr_inference) into these buffers
 int decoder_body(vnr_handle h, const float* z, const float* kv, int kv_ld, const int32_t* z_len,
                  const int32_t* t_len, int B, int Tz, int Tt, int rf, float* initial, float* outputs,
-                 float* alignments) {
+                 float* alignments, float* pre_xa = nullptr, float* pre_qkv = nullptr) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, D = c.dec_attention_dim, od = c.output_dim;
   if (rf < 1 || rf > c.max_reduction_factor) return fail(h, VNR_ERR_ARG, "reduction_factor out of range");
-  WS(xa, (size_t)M * D); WS(xb, (size_t)M * D);
+  float* xa = pre_xa;
+  if (!xa) { xa = ws_alloc(h, (size_t)M * D); if (!xa) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed"); }
+  WS(xb, (size_t)M * D);
   GemmArgs g;
   // pre_projection -> Q|K|V of the first block as one row-panel chain (two launches otherwise)
-  bool fused = false;
-  float* qkv_pre = nullptr;
-  if (!h->dec_blks.empty() && h->dec_blks[0].D == D) {
+  bool fused = pre_xa && pre_qkv;
+  float* qkv_pre = pre_qkv;
+  if (!fused && !h->dec_blks.empty() && h->dec_blks[0].D == D) {
     const bool saoi = self_aoi_on(h, D, c.dec_attention_heads);
     qkv_pre = ws_alloc(h, qkv_floats(saoi, B, Tz, D));
     if (!qkv_pre) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
-    TRY(run_prechain(h, z, C, C, M,
-                     {PreStage{h->dec_pre_wt, C, D, 0, 0, h->dec_pre_b, nullptr, 1, 0.f, xa, D, 1},
-                      PreStage{h->dec_blks[0].qkv_wt, D, 3 * D, 1, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}}, &fused));
+    TRY(run_prechain(h, z, C, C, M, decoder_pre_stages(h, B, Tz, xa, qkv_pre, 0, 1), &fused));
   }
   if (!fused) {
     qkv_pre = nullptr;
@@ -1582,10 +1688,22 @@ int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_leng
     // cross-attention (the HBM-bound kernel of the path) then finds them in L2 / Infinity Cache (12.5 -> ? us per launch)
     WS(kvp, (size_t)B * Tt * h->prior_kv_n);
     TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n, kvp, h->cfg.prior_attention_dim));
-    TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kvp, h->prior_kv_n, B, Tz, Tt, d_eps, z, nullptr));
+    // the decoder's pre-chain rides behind the last flow step's coupling (same chain launch) when the shapes allow
+    const int Dd = h->cfg.dec_attention_dim;
+    std::vector<PreStage> dpre;
+    float *dxa = nullptr, *dqkv = nullptr;
+    if (!h->dec_blks.empty() && h->dec_blks[0].D == Dd && C <= 256 && !(C & 31)) {
+      dxa = ws_alloc(h, (size_t)B * Tz * Dd);
+      dqkv = ws_alloc(h, qkv_floats(self_aoi_on(h, Dd, h->cfg.dec_attention_heads), B, Tz, Dd));
+      if (!dxa || !dqkv) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+      dpre = decoder_pre_stages(h, B, Tz, dxa, dqkv, 1, 0);
+    }
+    bool dec_pre_done = false;
+    TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kvp, h->prior_kv_n, B, Tz, Tt, d_eps, z, nullptr, dpre.empty() ? nullptr : &dpre, &dec_pre_done));
     WS(kvd, (size_t)B * Tt * h->dec_kv_n);
     TRY(run_kv(h, text_embd, B, Tt, Dm, h->dec_kv_wt, h->dec_kv_n, kvd, h->cfg.dec_attention_dim));
-    return decoder_body(h, z, kvd, h->dec_kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, nullptr, d_mel, d_alignments);
+    return decoder_body(h, z, kvd, h->dec_kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, nullptr, d_mel, d_alignments,
+                        dec_pre_done ? dxa : nullptr, dec_pre_done ? dqkv : nullptr);
   }
   // every cross-attention K|V of the memory (all prior blocks + decoder blocks) in one GEMM
   const int kv_n = h->prior_kv_n + h->dec_kv_n;

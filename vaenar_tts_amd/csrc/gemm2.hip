@@ -78,7 +78,17 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  if (g.nslice && !(tiles_n & 7)) {
+    // N-sliced raster (tiles_n % 8 == 0): workgroup ids go round-robin over the 8 XCDs, so XCD x takes the column tiles
+    // [x c, (x + 1) c), c = tiles_n / 8, and walks them row tile by row tile -- its slice of the weight panel (c BN rows of K) stays in
+    // ITS L2 for the whole launch and every activation row tile is fetched once per XCD.  The default raster gives an XCD whole row
+    // tiles, i.e. the ENTIRE weight panel once per tiles_n workgroups: for the 14-block cross K | V projection (N = 7168 -> 12.6 MB
+    // of split weights against 4 MB of L2) that was 407 MB of fetches for 19 MB of operands (profiles/r03_hbm_traffic_pmc.txt).
+    const int c = tiles_n >> 3, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tm = idx / c;
+    tn = xcd * c + (idx - tm * c);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -769,7 +779,16 @@ bool gemm2_supported(const GemmArgs& g) {
 
 hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
   static const int force_tile = getenv("VNR_GEMM_TILE") ? atoi(getenv("VNR_GEMM_TILE")) : -1;
-  const GemmArgs& g = g_in;
+  GemmArgs g = g_in;
+  {
+    // N-sliced raster (see the kernel) when the split weight panel is larger than the activation panel and than half an XCD's L2, and
+    // the 64-column tiles divide evenly over the 8 XCDs.  VNR_GEMM_NSLICE=0 restores the row-major raster everywhere (A/B switch).
+    static const int ns_on = getenv("VNR_GEMM_NSLICE") ? atoi(getenv("VNR_GEMM_NSLICE")) : 1;
+    const size_t wbytes = (size_t)g.N * g.K * 4, abytes = (size_t)g.M * g.K * 4;
+    const bool wide = (g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128);       // (the launches that take 128-column tiles)
+    const int tn64 = (g.N + 63) / 64;
+    g.nslice = (ns_on && g.Wsplit && !g.ln_gamma && !wide && !(tn64 & 7) && wbytes > abytes && wbytes > ((size_t)2 << 20)) ? 1 : 0;
+  }
   static const int st = getenv("VNR_GEMM_STAGES") ? atoi(getenv("VNR_GEMM_STAGES")) : 0;   // measurement knob
   if (g.Wsplit) {   // split-fp16 variant (engine decides per call; weights were pre-split at finalize)
     if (g.ln_gamma) return g.N <= 128 ? launch2<32, 128, 1, 2, 3, true, 1>(g, s) : launch2<32, 256, 1, 4, 3, true, 1>(g, s);

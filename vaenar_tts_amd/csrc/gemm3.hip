@@ -189,6 +189,15 @@ panel_chain_kernel(const ChainArgs g) {
 
 #pragma unroll 1
   for (int si = 0; si < g.nstages; ++si) {
+    // Every lane-dependent address of a stage is re-derived from an opaque copy of the lane id: otherwise the compiler hoists dozens of
+    // loop-invariant offsets out of the stage loop, runs out of the 256 VGPRs and SPILLS them -- and a scratch reload in an epilogue
+    // is a vector-memory load like any other: its s_waitcnt drains the whole weight prefetch stream (measured: +15 % on every chain
+    // launch when one more epilogue variant pushed the kernel from 4 to 33 spilled registers).
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    const int half = lane_s >> 5, l31 = lane_s & 31;
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
     if (RT == 1 && g.att_stage > 0 && si == g.att_stage) {
       // ================= fused cross-attention of this panel (see ChainArgs::att_stage) ===================================
       // wave w: head = w >> 1, key blocks 2 (w & 1) and 2 (w & 1) + 1 (32 keys each, Tk <= 128).  Per block, as attn3_kernel:
@@ -203,6 +212,8 @@ panel_chain_kernel(const ChainArgs g) {
       int b_lo = m0 / g.att_Tq, b_hi = (m0 + 31 < g.M ? m0 + 31 : g.M - 1) / g.att_Tq;
       b_lo = __builtin_amdgcn_readfirstlane(b_lo); b_hi = __builtin_amdgcn_readfirstlane(b_hi);
       char* P1 = panel_ptr(1);
+      char* Pc = panel_ptr(g.att_ali ? 2 : 1);                        // the context: in place of the queries, or -- when the alignments are
+                                                                      // wanted, whose pass below multiplies K and Q once more -- in panel 2
       float* xs = reinterpret_cast<float*>(smem + g.att_lds);        // merge scratch: [4 heads][32 rows][64 + 2] floats
       const float c2 = (g.att_temp != 1.0f) ? 0.125f * 1.44269504088896340736f / g.att_temp : 0.125f * 1.44269504088896340736f;
       for (int bb = b_lo; bb <= b_hi; ++bb) {
@@ -220,8 +231,8 @@ panel_chain_kernel(const ChainArgs g) {
         for (int x = 0; x < 2; ++x) {
           const int kb = 2 * kp + x;
           if (32 * kb >= g.att_Tk) break;                             // (wave-uniform)
-          const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane * 16;
-          const char* vt = g.att_V + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane * 16;
+          const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
+          const char* vt = g.att_V + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
           h8a khi[4], klo[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) { khi[t] = *reinterpret_cast<const h8a*>(kt + 1024 * t); klo[t] = *reinterpret_cast<const h8a*>(kt + 4096 + 1024 * t); }
@@ -302,6 +313,7 @@ panel_chain_kernel(const ChainArgs g) {
           const float M = fmaxf(mfin, m1);
           const float f0 = __builtin_amdgcn_exp2f(mfin - M), f1 = __builtin_amdgcn_exp2f(m1 - M);
           const float linv = 1.0f / (l_run * f0 + l1 * f1);                                // softmax denominator, attention.py:242
+          if (g.att_ali && half == 0) { xh[l31 * 66 + 64] = M; xh[l31 * 66 + 65] = linv; }   // for the alignment pass of both waves (read behind the barrier)
           // the context replaces the queries of this lane's row in panel 1 (tiles 2 head, 2 head + 1: read by this head's two
           // waves only, and both are past their S^T products of this pass: the barrier above).  Rows of the other batch element of a
           // straddling panel keep their queries for the next pass.
@@ -318,12 +330,60 @@ panel_chain_kernel(const ChainArgs g) {
                   const _Float16 hh = (_Float16)xv; hi[e] = hh; lo[e] = (_Float16)(xv - (float)hh);
                 }
                 const int pcol = 8 * q + 4 * half;                     // column inside the 32-channel tile 2 head + nb
-                *reinterpret_cast<h16x4*>(P1 + panel_off(l31, 2 * head + nb, pcol >> 3) + (pcol & 4) * 2) = hi;
-                *reinterpret_cast<h16x4*>(P1 + panel_off(l31, 2 * head + nb, 4 + (pcol >> 3)) + (pcol & 4) * 2) = lo;
+                *reinterpret_cast<h16x4*>(Pc + panel_off(l31, 2 * head + nb, pcol >> 3) + (pcol & 4) * 2) = hi;
+                *reinterpret_cast<h16x4*>(Pc + panel_off(l31, 2 * head + nb, 4 + (pcol >> 3)) + (pcol & 4) * 2) = lo;
               }
           }
         }
         lds_barrier();                                                 // scratch free for the next pass; the context of this pass is in place
+        if (g.att_ali) {                                               // (workgroup-uniform)
+          // alignments = softmax(logits) of this head's rows (attention.py:242-246): every wave normalises its own two key blocks with
+          // the head's final (max, 1 / sum) and writes them as 128-byte row pieces after a wave-private 32 x 32 transpose through the
+          // merge scratch (free now) -- lane-per-query registers would leave 32-byte pieces, which the memory system takes at a
+          // tenth of the rate (profiles/r02_store_bw_probe.txt)
+          const float M_fin = xh[l31 * 66 + 64], linv_fin = xh[l31 * 66 + 65];      // left there by the kp = 0 wave (below the merge)
+          lds_barrier();                                               // both waves of the head hold them: the region may be overwritten
+          float* tb = xs + wave * (32 * 33);
+#pragma unroll 1
+          for (int x = 0; x < 2; ++x) {
+            const int kb = 2 * kp + x;
+            if (32 * kb >= g.att_Tk) break;                            // (wave-uniform)
+            // S^T of the block once more (K tile from L1 / L2, Q still in panel 1): holding both blocks' probabilities through P.V and
+            // the merge cost 32 registers the kernel does not have (20 spilled)
+            const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const h8a kh = *reinterpret_cast<const h8a*>(kt + 1024 * t), kl = *reinterpret_cast<const h8a*>(kt + 4096 + 1024 * t);
+              const h8a qh = *reinterpret_cast<const h8a*>(P1 + panel_off(l31, 2 * head + (t >> 1), 2 * (t & 1) + half));
+              const h8a ql = *reinterpret_cast<const h8a*>(P1 + panel_off(l31, 2 * head + (t >> 1), 4 + 2 * (t & 1) + half));
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sacc, 0, 0, 0);
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, sacc, 0, 0, 0);
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int j = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float sv = sacc[r] * c2;
+              sv = (qvalid && j < klen) ? sv : kMaskFill * 1.44269504088896340736f;         // attention.py:240
+              if (j >= g.att_Tk) sv = -INFINITY;
+              tb[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half] = __builtin_amdgcn_exp2f(sv - M_fin) * linv_fin;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int rr = 8 * it + (lane_s >> 3), k4 = (lane_s & 7) * 4;
+              const float4 pv = make_float4(tb[rr * 33 + k4], tb[rr * 33 + k4 + 1], tb[rr * 33 + k4 + 2], tb[rr * 33 + k4 + 3]);
+              const int rg = m0 + rr, tqr = rg - bb * g.att_Tq, key0 = 32 * kb + k4;
+              if (rg < g.M && tqr >= 0 && tqr < g.att_Tq && key0 < g.att_Tk)
+                *reinterpret_cast<float4*>(g.att_ali + (((size_t)(bb * H + head) * g.att_Tq + tqr) * g.att_Tk + key0)) = pv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          lds_barrier();                                               // the scratch is the next pass's merge area again
+        }
       }
     }
     const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
@@ -503,6 +563,61 @@ panel_chain_kernel(const ChainArgs g) {
         for (int r = 0; r < 16; ++r) v[rt][r] = fast_tanhf(v[rt][r]);
     }
     wstamp(si, 4);                                       // accumulators drained, bias / activation applied
+    if (g.cpl_stage > 0 && si == g.cpl_stage) {
+      // ================= fused affine coupling (see ChainArgs::cpl_stage; the arithmetic of misc.hip: coupling_fwd_kernel) ============
+      // v = [log_scale (hc columns) | shift (hc columns)].  The active waves park v in LDS ([ROWS][2 hc + 4] floats) and are done with their
+      // accumulators; after the barrier ALL threads share the elementwise work, one 4-column piece of zp and one of the conditioning
+      // half per thread and trip: zp' = sigmoid(log_scale + 2) * zp + shift goes back to z and, like the conditioning half, into the
+      // destination panel in split form (what any stage output looks like).
+      const int cst = st.n + 4;
+      float* cx = reinterpret_cast<float*>(smem + g.cpl_lds);
+      if (wave_on) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(cx + (32 * rt + l31) * cst + 32 * wave + 8 * q + 4 * half) =
+                make_float4(v[rt][4 * q], v[rt][4 * q + 1], v[rt][4 * q + 2], v[rt][4 * q + 3]);
+      }
+      lds_barrier();
+      {
+        // hc = 64 (checked by the launcher): thread -> (row tid >> 4, 4-column piece tid & 15), first the transformed half, then the
+        // conditioning half
+        char* Dp = panel_ptr(st.dst);
+        const int c = (tid_s & 15) * 4;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int prow = 32 * rt + (tid_s >> 4), row = m0 + prow;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            const int zoff = which ? g.cpl_cond_off : g.cpl_zp_off;
+            float* zp = g.cpl_z + (size_t)row * g.cpl_ld + zoff + c;
+            const float4 zo = row < g.M ? *reinterpret_cast<const float4*>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float o[4] = {zo.x, zo.y, zo.z, zo.w};
+            if (which == 0) {
+              const float4 ls = *reinterpret_cast<const float4*>(cx + prow * cst + c), sh = *reinterpret_cast<const float4*>(cx + prow * cst + 64 + c);
+              const float lv[4] = {ls.x, ls.y, ls.z, ls.w}, sv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float scale = 1.0f / (1.0f + expf(-(lv[e] + 2.0f)));                    // tf.math.sigmoid(log_scale + 2), flow.py:231
+                o[e] = scale * o[e] + sv[e];                                                  // _affine, flow.py:216
+              }
+              if (row < g.M) out_store4(zp, o[0], o[1], o[2], o[3]);
+            }
+            h16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)o[e]; hi[e] = hh; lo[e] = (_Float16)(o[e] - (float)hh); }
+            const int kt = (zoff + c) >> 5, p = (zoff + c) & 31;
+            *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
+            *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
+          }
+        }
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int row = m0 + 32 * rt + l31, prow = 32 * rt + l31;
@@ -733,13 +848,27 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     if (all_sync) for (int i = 0; i < g.nstages; ++i) g.st[i].sync_after = 1;
   }
   const int prm_bytes = (g.nstages * 256 + nln * 512) * 4;
+  if (g.cpl_stage > 0) {                                // fused coupling: the head pair of a flow step, z rows 16-byte addressable
+    if (g.cpl_stage >= g.nstages || g.rows64) return hipErrorInvalidValue;
+    const ChainStage& cs = g.st[g.cpl_stage];
+    if (cs.n != 128 || cs.dst < 0 || cs.out || cs.gamma || cs.pe || cs.res >= 0 || cs.acc_mode != 0 || cs.act != ACT_IDENTITY || !g.cpl_z ||
+        (g.cpl_ld & 3) || (g.cpl_zp_off & 31) || (g.cpl_cond_off & 31) || g.cpl_zp_off + cs.n / 2 > 256 || g.cpl_cond_off + cs.n / 2 > 256)
+      return hipErrorInvalidValue;
+  }
   if (g.rows64) { if (g.att_stage > 0) return hipErrorInvalidValue; return launch_chain_rt<2>(g, ChainLds<2>::PRM_OFF + prm_bytes, s); }
   int lds = ChainLds<1>::PRM_OFF + prm_bytes;
   if (g.att_stage > 0) {                                // merge scratch of the fused cross-attention: [D / 64 heads][32 rows][66 floats]
     if (g.att_stage >= g.nstages || g.D != 256 || !g.att_K || !g.att_V || g.att_Tk <= 0 || g.att_Tk > 128 || g.att_Tq <= 0) return hipErrorInvalidValue;
+    if (g.att_ali && ((g.att_Tk & 3) || ((size_t)g.att_ali & 15))) return hipErrorInvalidValue;
     g.att_lds = (lds + 15) & ~15;
     lds = g.att_lds + (g.D >> 6) * 32 * 66 * 4;
   }
+  if (g.cpl_stage > 0) {                                // head exchange [32 rows][2 hc + 4] floats: the attention's merge scratch is free by then
+    const int need = 32 * (g.st[g.cpl_stage].n + 4) * 4;
+    if (g.att_stage > 0 && g.cpl_stage > g.att_stage && need <= (g.D >> 6) * 32 * 66 * 4) g.cpl_lds = g.att_lds;
+    else { g.cpl_lds = (lds + 15) & ~15; lds = g.cpl_lds + need; }
+  }
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   return launch_chain_rt<1>(g, lds, s);
 }
 

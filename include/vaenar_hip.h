@@ -47,7 +47,8 @@ enum { VNR_ACT_IDENTITY = 0, VNR_ACT_RELU = 1, VNR_ACT_TANH = 2 };
 
 /* Hyper-parameters read by the reference constructor models/models.py:10-65
  * (values: configs/hparams.py:233-348).  The engine requires head width 64
- * (attention_dim / heads), odd conv kernels and channel counts divisible by 4. */
+ * (attention_dim / heads), odd conv kernels, channel counts divisible by 4 and enc_pre_hidden
+ * divisible by 32 (vnr_create says which one it is when a configuration does not fit). */
 typedef struct vnr_config {
   int32_t abi_version;                 /* = VNR_ABI_VERSION */
   /* Common (hparams.py:284-289) */
@@ -197,7 +198,8 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t *d_ids, const int32_t *d_text_lengt
  * attention.py:410-412,440-449): C = epilogue(A1.W[0:K1] + A2.W[K1:K] + bias).
  * d_w is the Keras kernel [K,N] row-major.  Epilogue order: +bias -> activation ->
  * *bn_scale+bn_shift -> +pe_weight*pe[m % pe_T] -> +residual -> LayerNorm(gamma,beta,eps 1e-3).
- * Any optional pointer may be NULL. */
+ * Any optional pointer may be NULL.  Shape limits (checked, VNR_ERR_ARG with a message): k1, k2 and the row strides multiples of 4
+ * floats; with a second panel (k2 > 0) k1 a multiple of 32; every operand below 2 GiB. */
 typedef struct vnr_dense_desc {
   const float *d_a1; int32_t lda1; int32_t k1;
   const float *d_a2; int32_t lda2; int32_t k2;

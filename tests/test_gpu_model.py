@@ -125,7 +125,7 @@ def test_inference_matches_oracle(setup, fused, temperature):
                          ids=["default", "cross-fp32", "self-fp32", "kv-early", "no-chain", "throughput-tiles"])
 def test_inference_long_text_and_ab_switches(opts):
     """T_text = 150 > 128: the cross-attention leaves the operand-image kernel (attention3, Tk <= 128) for the fp32-operand
-    kernels (attention2, and the first-generation kernel for the alignments); T_z = 45 is not a multiple of 16, so the V stage
+    kernel (attention2: stored probabilities up to 512 keys, the two-pass form beyond); T_z = 45 is not a multiple of 16, so the V stage
     of the chain tails takes the generic image scatter.  Every A/B switch of the attention path gives the same mels."""
     hps, model, oracle = _setup("tiny")
     try:
@@ -438,3 +438,33 @@ def test_full_size_s1_properties():
         assert np.abs(a[5, :, :int((b["mel_lengths"][5] + 1) // 2), tl:]).max() == 0.0      # masked keys get exactly zero weight
     finally:
         model.engine.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "lj"])
+def test_self_attention_block_alone(name):
+    """SelfAttentionBLK (attention.py:392-415) as a block: the same encoder with n_blk = 0 and n_blk = 1 on the same variables.  The
+    n_blk = 0 engine's output IS the block's input (prenet -> projection + PE); the oracle's self_attention_blk applied to exactly
+    that input must give the n_blk = 1 engine's output -- attention core over the key AND query masks, att_proj on concat(x, att),
+    LayerNorm, FFN, LayerNorm, with nothing of the rest of the encoder in the comparison.  (lj: width 512, the LayerNorm-after-GEMM
+    path; tiny: width 96, LayerNorm in the GEMM epilogue.)"""
+    import copy
+    hps1 = copy.deepcopy(tiny_hps() if name == "tiny" else LJHPS)
+    hps1.Encoder.Transformer.n_blk = 1
+    hps0 = copy.deepcopy(hps1)
+    hps0.Encoder.Transformer.n_blk = 0
+    w1 = init_weights(hps1, seed=77, mode="synthetic", include_posterior=False)
+    w0 = {k: v for k, v in w1.items() if "/self_attentions/" not in k}
+    b = make_batch(3, 37 if name == "lj" else 13, 40, vocab_size=hps1.Encoder.Transformer.vocab_size, latent_dim=hps1.Common.latent_dim,
+                   ragged=True, text_step=6 if name == "lj" else 4, mel_step=7)
+    m0, m1 = VAENAR(hps0, weights=w0), VAENAR(hps1, weights=w1)
+    try:
+        x = m0.text_encoder(b["ids"], b["text_lengths"], pos_step=2.0).numpy()
+        y = m1.text_encoder(b["ids"], b["text_lengths"], pos_step=2.0).numpy()
+    finally:
+        m0.engine.close(); m1.engine.close()
+    e = hps1.Encoder.Transformer
+    ref = Oracle(hps1, w1, np.float64).self_attention_blk("text_encoder/self_attentions/0", x.astype(np.float64), b["text_lengths"],
+                                                          e.attention_heads, e.attention_temperature)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.abs(y - x).max() > 0.1                                   # the block does something
+    assert np.abs(y - ref).max() < 5e-5, np.abs(y - ref).max()

@@ -324,3 +324,47 @@ def test_restore_refuses_a_bundle_that_does_not_match(tmp_path):
         warnings.simplefilter("always")
         weights, opt = tc.check_training_checkpoint(tc.load_training_checkpoint(mo), hps, mo)
     assert opt is None and set(weights) == set(w) and any("no optimizer slots" in str(r.message) for r in rec)
+
+
+def test_multi_shard_bundles_and_stale_state_entries(tmp_path):
+    """`bundle_is_complete` honours BundleHeaderProto.num_shards / BundleEntryProto.shard_id (TensorFlow writes
+    several shards for large models); the `checkpoint` state file's entries are checked like the fallback listing; temporary files
+    of a save that died are removed; re-saving a prefix never leaves the old index pointing at new data."""
+    import glob
+    import struct
+    from vaenar_tts_amd import tf_checkpoint as tc
+    from vaenar_tts_amd.tf_record_utils import _field, _ld, _varint
+    d = str(tmp_path)
+    # a hand-made two-shard bundle: header num_shards = 2, one float32 tensor per shard
+    a, b = np.arange(6, dtype=np.float32), np.arange(4, dtype=np.float32) + 10
+    def entry(arr, shard):
+        raw = arr.tobytes()
+        shape = _ld(2, _field(1, 0, _varint(arr.shape[0])))
+        e = _field(1, 0, _varint(1)) + _ld(2, shape)               # DT_FLOAT
+        if shard:
+            e += _field(3, 0, _varint(shard))
+        return e + _field(5, 0, _varint(len(raw))) + _field(6, 5, struct.pack("<I", tc._mask(tc.crc32c(raw))))
+    prefix = os.path.join(d, "two")
+    items = [(b"", _field(1, 0, _varint(2)) + _ld(3, _field(1, 0, _varint(1)))), (b"a", entry(a, 0)), (b"b", entry(b, 1))]
+    tc._write_table(prefix + ".index", items)
+    open(prefix + ".data-00000-of-00002", "wb").write(a.tobytes())
+    assert not tc.bundle_is_complete(prefix)                          # second shard missing
+    open(prefix + ".data-00001-of-00002", "wb").write(b.tobytes()[:8])
+    assert not tc.bundle_is_complete(prefix)                          # second shard truncated
+    open(prefix + ".data-00001-of-00002", "wb").write(b.tobytes())
+    assert tc.bundle_is_complete(prefix)
+    got = tc.read_checkpoint(prefix)
+    assert np.array_equal(got["a"], a) and np.array_equal(got["b"], b)
+    # state file naming a truncated bundle + a leftover temporary file
+    mdir = os.path.join(d, "m"); os.makedirs(mdir)
+    tc.write_checkpoint(os.path.join(mdir, "ckpt-1"), {"x": a})
+    tc.write_checkpoint(os.path.join(mdir, "ckpt-2"), {"x": b})
+    with open(os.path.join(mdir, "ckpt-2.data-00000-of-00001"), "wb") as f:
+        f.write(b"\0")                                                # a save that died inside the data file
+    open(os.path.join(mdir, "ckpt-3.tmp123.index"), "wb").write(b"junk")
+    open(os.path.join(mdir, "checkpoint"), "w").write('model_checkpoint_path: "ckpt-2"\nall_model_checkpoint_paths: "ckpt-1"\nall_model_checkpoint_paths: "ckpt-2"\n')
+    m = tc.CheckpointManager(mdir)
+    assert m.latest_checkpoint.endswith("ckpt-1") and not glob.glob(os.path.join(mdir, "*.tmp*"))
+    # re-saving an existing prefix: whole again afterwards, and the index is replaced only behind the data
+    tc.write_checkpoint(os.path.join(mdir, "ckpt-1"), {"x": b})
+    assert tc.bundle_is_complete(os.path.join(mdir, "ckpt-1")) and np.array_equal(tc.read_checkpoint(os.path.join(mdir, "ckpt-1"))["x"], b)

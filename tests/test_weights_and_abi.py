@@ -99,3 +99,24 @@ def test_config_struct_carries_the_hparams():
     c = _lib.config_from_hps(LJHPS)
     assert (c.latent_dim, c.output_dim, c.enc_vocab_size, c.prior_n_blk, c.dec_post_n_conv) == (128, 80, 43, 6, 5)
     assert c.enc_pre_activation == 1 and c.lenpred_activation == 0 and c.enc_bn_before_act == 0
+
+
+def test_training_noise_schedule_is_restart_safe():
+    """train.py: the reparameterisation-noise stream and the dropout seeds are a pure function of (seed, world, rank, iteration) --
+    a run restarted from a checkpoint continues the stream instead of replaying it, shards never share noise."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vnr_train_script", os.path.join(ROOT, "train.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    seen = {}
+    for world in (1, 2, 8):
+        for rank in range(world):
+            for it in range(1, 6):
+                ns, off, ds = tr.noise_schedule(1234, world, rank, it)
+                assert (ns, off, ds) == tr.noise_schedule(1234, world, rank, it)            # no hidden state: a restart at `it` draws the same
+                assert off == it * tr.NOISE_STRIDE and off + 32 * 1 * 400 * 128 // 4 <= (it + 1) * tr.NOISE_STRIDE   # a T1 shard's draw fits its range
+                seen.setdefault(world, set()).add((ns, off))
+                if rank:
+                    assert ns != tr.noise_schedule(1234, world, 0, it)[0] and ds != tr.noise_schedule(1234, world, 0, it)[2]
+        assert len(seen[world]) == world * 5                                              # every (rank, iteration) has its own counter range
+    assert tr.NOISE_STRIDE * 4 >= 32 * 4 * 400 * 128                                      # room for n_sample = 4 at T1 size

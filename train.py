@@ -43,6 +43,15 @@ def synthetic_batches(hps, n_batches, batch_size, t_text, t_mel, seed):
 NOISE_STRIDE = 1 << 26          # Philox counter blocks (4 normals each) reserved per training iteration: 2.7e8 draws
 
 
+def noise_schedule(seed, world, rank, it):
+    """(noise_seed, noise_offset, dropout_seed) of Adam iteration ``it`` (1-based) on ``rank``: the reparameterisation noise
+    (posterior.py:35) is one Philox stream per rank keyed by seed * world + rank, iteration ``it`` owns the counter blocks
+    [it, it + 1) * NOISE_STRIDE (4 normals each), the Dropout masks are keyed by (seed + 7919 it) * world + rank.  Pure function of
+    (seed, world, rank, it): a run restarted from a checkpoint at iteration k draws for k + 1 exactly what the uninterrupted run
+    would, shards never share noise, and no iteration replays an earlier one."""
+    return seed * world + rank, it * NOISE_STRIDE, (seed + 7919 * it) * world + rank
+
+
 def get_reduction_factor(hps, ep):                          # train.py:236-243
     intervals, rfs = hps.Train.reduce_interval, hps.Train.reduction_factors
     i = 0
@@ -63,6 +72,9 @@ def main():
     ap.add_argument('--t_text', type=int, default=128)
     ap.add_argument('--t_mel', type=int, default=800)
     ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--deterministic', type=int, default=1,
+                    help="1 (default, like the reference's TF_DETERMINISTIC_OPS=1 + pinned seeds, train.py:17-32): every gradient is "
+                         "accumulated in a fixed order, two runs with the same seed give the same bits; 0: float atomics (about 20 %% faster)")
     args = ap.parse_args()
     hps = {'ljspeech': LJHPS, 'databaker': DataBakerHPS, 'tiny': tiny_hps()}[args.dataset]
     rank, local_rank, world = vdist.init()
@@ -95,6 +107,7 @@ def main():
     manager = CheckpointManager(args.model_dir, max_to_keep=20)
     latest = manager.latest_checkpoint                        # the state file's entry (numeric order of the files without one)
     model = VAENAR(hps, device=local_rank, weights=init_weights(hps, seed=seed, mode='reference'))
+    model.engine.set_option("deterministic", 1 if args.deterministic else 0)
     step = 0
     if latest:                                                # every rank restores variables, Adam slots and counters itself
         step = model.restore_checkpoint(latest)
@@ -144,9 +157,8 @@ def main():
         for s, b in enumerate(train):                         # train_one_epoch, train.py:181-204
             ts = time.time()
             it += 1
-            model.prior.noise_offset = it * NOISE_STRIDE
-            out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw, rf,
-                                   dropout_seed=(seed + 7919 * it) * world + rank)
+            model.prior.noise_seed, model.prior.noise_offset, dseed = noise_schedule(seed, world, rank, it)
+            out = model.train_step(b["ids"], b["mels"], b["text_lengths"], b["mel_lengths"], kw, rf, dropout_seed=dseed)
             out = [vdist.mean_over_ranks(x) for x in out]
             acc += out
             if rank == 0:

@@ -1308,6 +1308,9 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
       (cfg->dec_post_conv_filters & 3) || (cfg->post_pre_hidden & 3))
     return bad("channel counts must be multiples of 4 (latent_dim of 8)");
   if (cfg->enc_n_conv < 1) return bad("the encoder prenet needs at least one conv layer");
+  // tf.concat([x, ctx], -1) -> Dense (attention.py:410-412,440-449) runs as two K panels behind one descriptor: the panel switch must
+  // fall on a 32-column k-tile boundary (gemm2.hip; the register-staged kernel that took any multiple of 4 was retired in round 3)
+  if (cfg->enc_pre_hidden & 31) return bad("enc_pre_hidden must be a multiple of 32 (first panel of the encoder blocks' concat -> att_proj)");
   if (!(cfg->enc_conv_kernel & 1) || !(cfg->dec_post_conv_kernel & 1)) return bad("conv kernels must be odd");
   if (cfg->post_pre_hidden != cfg->post_attention_dim) return bad("posterior pre_hidden must equal attention_dim");
   int n = 0;
@@ -2015,6 +2018,11 @@ int vnr_op_dense(vnr_handle h, const vnr_dense_desc* d) {
   HIP_TRY(h, hipSetDevice(h->device));
   const int K = d->k1 + d->k2;
   if (!d->d_a1 || !d->d_w || !d->d_c || d->m <= 0 || d->n <= 0 || K <= 0) return fail(h, VNR_ERR_ARG, "bad dense descriptor");
+  if (d->k2 > 0 && (d->k1 & 31)) return fail(h, VNR_ERR_ARG, "vnr_op_dense: with a second input panel (k2 > 0) k1 must be a multiple of 32");
+  if ((d->k1 & 3) || (d->k2 & 3) || (d->lda1 & 3) || (d->k2 > 0 && (d->lda2 & 3)))
+    return fail(h, VNR_ERR_ARG, "vnr_op_dense: k1, k2 and the row strides must be multiples of 4 floats (16-byte rows)");
+  if (((size_t)d->m * d->lda1 + K) * 4 >= ((size_t)1 << 31) || ((size_t)d->n * K + K) * 4 >= ((size_t)1 << 31))
+    return fail(h, VNR_ERR_ARG, "vnr_op_dense: an operand spans 2 GiB or more (one buffer descriptor per operand)");
   ws_reset(h);
   WS(wt, (size_t)K * d->n);
   RUN_MISC(h, launch_transpose(d->d_w, K, d->n, wt, K, h->stream));

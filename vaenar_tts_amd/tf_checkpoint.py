@@ -34,6 +34,7 @@ PARITY UNPINNED against bundles written by real TensorFlow (none exist in this e
 the reference are behind a Google-Drive link, README.md:4): the format statements above are the published ones, pinned by
 tests/test_tf_formats.py (independent hand-assembled table, CRC known answers, round trips).
 """
+import os
 import struct
 
 import numpy as np
@@ -245,6 +246,22 @@ def _write_table(path, items, block_size=4096):
     out.extend(footer + bytes(40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC))
     with open(path, "wb") as f:
         f.write(bytes(out))
+        f.flush()
+        os.fsync(f.fileno())              # the rename that publishes this file must not overtake its contents
+
+
+def _fsync_dir(path):
+    """Make the renames in ``path`` durable (POSIX: fsync of the directory); best effort elsewhere."""
+    try:
+        fd = os.open(path or ".", os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        os.fsync(fd)
+    except OSError:
+        pass
+    finally:
+        os.close(fd)
 
 
 def write_checkpoint(prefix, tensors):
@@ -284,23 +301,40 @@ def write_checkpoint(prefix, tensors):
         f.flush()
         os.fsync(f.fileno())
     _write_table(tmp + ".index", items)
+    # Re-saving an EXISTING prefix: the old index must never describe the new data (offsets and checksums would not match), so it
+    # goes first; a crash between the steps then leaves no `<prefix>.index` at all (a restart skips the prefix) instead of a
+    # bundle that fails its checksums.  Every step is made durable before the next (fsync of files above, of the directory here).
+    d = os.path.dirname(os.path.abspath(prefix))
+    if os.path.exists(prefix + ".index"):
+        os.remove(prefix + ".index")
+        _fsync_dir(d)
     os.replace(tmp + ".data-00000-of-00001", prefix + ".data-00000-of-00001")
+    _fsync_dir(d)
     os.replace(tmp + ".index", prefix + ".index")
+    _fsync_dir(d)
 
 
 def bundle_is_complete(prefix):
-    """True when ``<prefix>.index`` is a whole table (footer magic, every block checksum) and every data shard it names is
-    there with at least the bytes the entries address -- what a restart checks before it trusts a file it merely found."""
+    """True when ``<prefix>.index`` is a whole table (footer magic, every block checksum) and every data shard it names
+    (``BundleHeaderProto.num_shards``, ``BundleEntryProto.shard_id``: TensorFlow writes several shards for large models) is there
+    with at least the bytes its entries address -- what a restart checks before it trusts a file it merely found."""
     import os
     try:
         entries = read_index(prefix + ".index", verify=True)
-        need = 0
+        num_shards = 1
+        for num, _, val in _parse(entries.get(b"", b"")):
+            if num == 1:
+                num_shards = val
+        need = {}
         for k, v in entries.items():
             if k == b"":
                 continue
             e = _parse_entry(v)
-            need = max(need, e["offset"] + e["size"])
-        return os.path.getsize(prefix + ".data-00000-of-00001") >= need
+            need[e["shard_id"]] = max(need.get(e["shard_id"], 0), e["offset"] + e["size"])
+        for sid, n in need.items():
+            if sid >= num_shards or os.path.getsize("%s.data-%05d-of-%05d" % (prefix, sid, num_shards)) < n:
+                return False
+        return True
     except Exception:
         return False
 
@@ -472,6 +506,12 @@ class CheckpointManager:
         import os
         self.directory, self.max_to_keep, self.name = directory, max_to_keep, checkpoint_name
         os.makedirs(directory, exist_ok=True)
+        import glob
+        for f in glob.glob(os.path.join(directory, checkpoint_name + "-*.tmp*")):      # leftovers of a save that died before its renames
+            try:
+                os.remove(f)
+            except OSError:
+                pass
         self.checkpoints = self._read_state()
 
     def _state_path(self):
@@ -487,7 +527,8 @@ class CheckpointManager:
                 m = re.match(r'\s*all_model_checkpoint_paths:\s*"(.*)"', line)
                 if m:
                     names.append(m.group(1))
-        found = [n for n in names if os.path.exists(os.path.join(self.directory, os.path.basename(n) + ".index"))]
+        # (the state file may name a bundle whose save died half way: only whole bundles count, as in the fallback listing below)
+        found = [n for n in names if bundle_is_complete(os.path.join(self.directory, os.path.basename(n)))]
         if not found:      # no (usable) state file: fall back to the files themselves, ordered by their NUMERIC counter
             pat = re.compile(r"^%s-(\d+)\.index$" % re.escape(self.name))
             nums = sorted(int(m.group(1)) for m in (pat.match(f) for f in os.listdir(self.directory)) if m)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r04
 for rep in 1 2; do
 for cfg in "$@"; do
   IFS='|' read -r label envs bargs <<< "$cfg"
-  line=$(env $envs python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train --in-flight 0 $bargs 2>&1 | grep '^{' | tail -1)
+  line=$(env $envs python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train --no-exact-pass --in-flight 0 $bargs 2>&1 | grep '^{' | tail -1)
   echo "$line" > gpurun_out/r04/ab_${label}_$rep.json
   python - "$label" "$rep" <<PY
 import json, sys

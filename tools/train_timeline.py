@@ -59,6 +59,18 @@ def main(path):
         if r[1] > prev:
             gl.append((r[1] - prev, r[0] + "   <- after #%d %s at +%.2f ms" % (i, prev_name.replace("void ", "").replace("vnr::", "").split("(")[0], (r[1] - t0) / 1e6)))
         prev = max(prev, r[2]); prev_name = r[0]
+    # the longest gap of the main stream: what the other streams ran meanwhile
+    if gl:
+        prev = t0
+        big = (0, 0, 0)
+        for r in rs:
+            if r[1] - prev > big[0]:
+                big = (r[1] - prev, prev, r[1])
+            prev = max(prev, r[2])
+        win = [r for r in step if r[2] > big[1] - 100000 and r[1] < big[2] + 100000]
+        print("# the main stream's longest gap: +%.2f .. +%.2f ms; launches of all streams around it (first 60):" % ((big[1] - t0) / 1e6, (big[2] - t0) / 1e6))
+        for r in win[:60]:
+            print("#   stream %s  +%8.3f .. +%8.3f ms  %s" % (r[3], (r[1] - t0) / 1e6, (r[2] - t0) / 1e6, r[0].replace("void ", "").replace("vnr::", "").split("(")[0][:60]))
     gl.sort(reverse=True)
     tot_gap = sum(g for g, _ in gl)
     print("# main stream: %d gaps, %.2f ms in total; gaps > 20 us: %d (%.2f ms); the ten longest (us, kernel that followed):" % (

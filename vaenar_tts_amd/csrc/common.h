@@ -452,7 +452,7 @@ hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, 
 hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s);
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
                               const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw, float* g_post, float* g_prior,
-                              float* cg, float* scalars, hipStream_t s);
+                              float* cg, float* scalars, hipStream_t s, int part = 0);
 hipError_t launch_axpy_dev(float* y, const float* x, const float* cg, float alpha, int n, hipStream_t s);
 struct TransposeJobHost { const float* in; float* out; int rows, cols; };      // same layout as the device-side job record
 hipError_t launch_transpose_batch(const void* jobs_device, int njobs, hipStream_t s);

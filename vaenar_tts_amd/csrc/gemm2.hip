@@ -800,6 +800,14 @@ hipError_t launch_gemm2(const GemmArgs& g_in, hipStream_t s) {
     // With several batches in flight (wide_tiles) the 64x128 tile wins everywhere: +4 % aggregate throughput (tools/ab_tiles.sh)
     if (t < 0) t = ((g.taps > 0 && g.M >= 8192 && g.N >= 128) || (g.wide_tiles && g.N >= 128)) ? 1 : 2;
     if ((t == 3 || t == 4) && (g.M < 8192 || g.N < 128)) t = (g.taps > 0 && g.M >= 8192 && g.N >= 128) ? 1 : 2;   // (the 8-wave 128x128 experiment: large-M launches only)
+    // 64 x 256 tiles (8 waves of 32 x 64; round 4 experiment, VNR_SPLIT_TILE=5 / VNR_GEMM_ROWTILE=1): one workgroup per 64 rows takes ALL 256
+    // columns -- the PostNet convolutions (M = 12800, N = 256) become 200 workgroups on 256 CUs in ONE round instead of 400 in 1.6
+    static const int rowtile = getenv("VNR_GEMM_ROWTILE") ? atoi(getenv("VNR_GEMM_ROWTILE")) : 0;
+    if ((t == 5 || rowtile) && g.taps > 0 && g.M >= 8192 && g.N == 256 && !g.wide_tiles) {
+      if (g.a_split) { if (!((g.K & 31) || (g.K1 & 31) || (g.conv_C & 31) || g.a_absmax)) return launch2<64, 256, 2, 4, 3, false, 2>(g, s); }
+      else return launch2<64, 256, 2, 4, 3, false, 1>(g, s);
+    }
+    if (t == 5) t = 1;
     // Ring depth by how many workgroups share a CU.  A k-tile of a 64x64 workgroup is 16 KB and arrives ~2 kcyc after its DMA was
     // issued: with three stages (two tiles in flight) ONE workgroup per CU streams 32 KB per latency -- a quarter of what the
     // CU's vector-memory path delivers (64 B/clk) -- so its k-loop runs at the memory latency, not at any bandwidth.  Co-resident

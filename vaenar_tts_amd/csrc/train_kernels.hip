@@ -2613,28 +2613,38 @@ hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha,
 // scalars[0..3] = mel_l2, kl, length_l2, total loss
 __global__ void train_seeds_kernel(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll,
                                    const float* post_lp, const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw,
-                                   float* g_post, float* g_prior, float* cg, float* scalars) {
-  // B = utterances x samples (the rows of the decoder / prior terms), Bl = utterances (the rows of the length loss): models.py:67-103
+                                   float* g_post, float* g_prior, float* cg, float* scalars, int part) {
+  // B = utterances x samples (the rows of the decoder / prior terms), Bl = utterances (the rows of the length loss): models.py:67-103.
+  // part 0: everything; 1: the seeds of the backward pass and the kl / length scalars only (the L2 sums come from the decoder
+  // branch, which may still be running on its own stream); 2: the L2 term and the total, from the stored kl / length scalars
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double l2 = 0.0, kl = 0.0, l = 0.0;
-  for (int b = 0; b < B; ++b) {
-    l2 += ((double)sum_out[b] + (double)sum_init[b]) / (double)mel_len[b];
-    kl += (double)post_lp[b] - (double)prior_lp[b];
+  if (part != 1) for (int b = 0; b < B; ++b) l2 += ((double)sum_out[b] + (double)sum_init[b]) / (double)mel_len[b];
+  l2 /= B;
+  if (part != 2) {
+    for (int b = 0; b < B; ++b) kl += (double)post_lp[b] - (double)prior_lp[b];
+    for (int b = 0; b < Bl; ++b) l += (double)ll[b];
+    kl /= B; l /= Bl;
+    const float gk = kl > 0.0 ? kw / (float)B : 0.f;
+    double c = 0.0;
+    for (int b = 0; b < B; ++b) { g_post[b] = gk; g_prior[b] = -gk; c += (double)(-gk) * (double)red_len[b]; }
+    cg[0] = (float)c;
+    scalars[1] = (float)kl; scalars[2] = (float)l;
+    // (the double-precision values for part 2, which must add exactly what part 0 would have added)
+    reinterpret_cast<double*>(scalars + 4)[0] = kl; reinterpret_cast<double*>(scalars + 4)[1] = l;
+  } else {
+    kl = reinterpret_cast<const double*>(scalars + 4)[0]; l = reinterpret_cast<const double*>(scalars + 4)[1];
   }
-  for (int b = 0; b < Bl; ++b) l += (double)ll[b];
-  l2 /= B; kl /= B; l /= Bl;
-  const float gk = kl > 0.0 ? kw / (float)B : 0.f;
-  double c = 0.0;
-  for (int b = 0; b < B; ++b) { g_post[b] = gk; g_prior[b] = -gk; c += (double)(-gk) * (double)red_len[b]; }
-  cg[0] = (float)c;
-  scalars[0] = (float)l2; scalars[1] = (float)kl; scalars[2] = (float)l;
-  scalars[3] = (float)(l2 + (double)kw * (kl > 0.0 ? kl : 0.0) + (double)lw * l);
+  if (part != 1) {
+    scalars[0] = (float)l2;
+    scalars[3] = (float)(l2 + (double)kw * (kl > 0.0 ? kl : 0.0) + (double)lw * l);
+  }
 }
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
                               const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw, float* g_post, float* g_prior,
-                              float* cg, float* scalars, hipStream_t s) {
+                              float* cg, float* scalars, hipStream_t s, int part) {
   vnr_launch(train_seeds_kernel, dim3(1), dim3(64), 0, s, sum_out, sum_init, mel_len, ll, post_lp, prior_lp, red_len, B, Bl, kw, lw,
-                     g_post, g_prior, cg, scalars);
+                     g_post, g_prior, cg, scalars, part);
   return hipGetLastError();
 }
 // y[i] += alpha * cg[0] * x[i]   and   y[i] += alpha * x[i] (cg null)

@@ -273,7 +273,12 @@ def run_rank(args):
         profiled_ms_per_step = 1e3 * (time.perf_counter() - tp0) / ps      # the pass the per-kernel numbers come from (event-attached launches)
         launches = (eng.launch_count() - launches0) // ps
         classes = ("chain", "chain_ali", "gemm", "gemm_fp32", "attn_self", "attn_cross", "attn_cross_ali", "layer_norm", "misc")
-        prof = {c: eng.profile_get(c) for c in classes}
+        def _get(c):
+            try:
+                return eng.profile_get(c)
+            except Exception:                        # (a library build without this class: A/B runs against older builds)
+                return {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0}
+        prof = {c: _get(c) for c in classes}
         eng.profile(False)
         eng.profile_reset()
         traffic, traffic_note = load_traffic_record()
@@ -537,6 +542,7 @@ def training_block(args, hps, device, rank, world):
         if world > 1:
             vdist.barrier()
         tdt = vdist.max_over_ranks((time.perf_counter() - t1) / nst)
+        launches_per_step = (tm.engine.launch_count() - n0) // nst
         rccl_ranks, rccl_rank = (tm.engine.comm_info() if world > 1 else (1, 0))        # what RCCL says (ncclCommCount / ncclCommUserRank)
         # one more step with dispatch events on every heavy launch: executed matrix-pipe FLOPs and the dominant kernel class
         tm.engine.profile(True); tm.engine.profile_reset()
@@ -575,7 +581,7 @@ def training_block(args, hps, device, rank, world):
                            "%d ranks, flat 138.9 MB fp32 gradient all-reduced with RCCL inside every step" % world),
             "ms_per_step": 1e3 * tdt, "mel_frames_per_s": TB * Tm * world / tdt, "steps": nst, "rccl_ranks": rccl_ranks, "rccl_rank": rccl_rank,
             "world_size_env": world, "roofline": troof,
-            "kernel_launches_per_step": (tm.engine.launch_count() - n0) // nst,
+            "kernel_launches_per_step": launches_per_step,
             "approx_tflops": 3.0 * ALG_GFLOP_S1 * (TB / S1["B"]) * world * 1e9 / tdt / 1e12,
             "loss": res[0], "mel_l2": res[1], "kl": res[2], "length_l2": res[3],
         }

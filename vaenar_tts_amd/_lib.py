@@ -124,6 +124,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share one serialise.  Every engine handle
+    # owns a stream (several handles = several batches in flight) and a training handle three more (kernel gradients, decoder branch,
+    # RCCL): with the default, a fourth handle already lands on the queue of another one -- three batches in flight took 2.2 ms per
+    # S1 batch instead of 1.6 as soon as a fourth engine existed in the process (profiles/r04_experiments.txt).  Read by the HIP runtime
+    # when it initialises, i.e. at the first engine; a value the caller has set wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not os.path.exists(LIB_PATH):
         raise VnrError(
             "libvaenar_hip.so not found at %s -- build it with `python __graft_entry__.py` or "

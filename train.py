@@ -13,7 +13,7 @@ the variables, Adam's slots and counters and the epoch counter, plus the ``check
 (vaenar_tts_amd/tf_checkpoint.py, no TensorFlow); a restart restores all three, so Adam resumes with its moments and bias correction.
 With torchrun (WORLD_SIZE > 1) the run is data-parallel: the batch is sharded by utterance over the ranks, every rank
 holds a replica, and the flat gradient is all-reduced with RCCL over xGMI inside vnr_train_step (one exchange per step);
-the host control plane (gloo) only carries the RCCL id, barriers and the averaged log scalars.
+the host control plane (vaenar_tts_amd/dist.py: TCP to rank 0, standard library) only carries the RCCL id, barriers and the averaged log scalars.
 """
 import argparse
 import os

@@ -120,3 +120,20 @@ def test_training_noise_schedule_is_restart_safe():
                     assert ns != tr.noise_schedule(1234, world, 0, it)[0] and ds != tr.noise_schedule(1234, world, 0, it)[2]
         assert len(seen[world]) == world * 5                                              # every (rank, iteration) has its own counter range
     assert tr.NOISE_STRIDE * 4 >= 32 * 4 * 400 * 128                                      # room for n_sample = 4 at T1 size
+
+
+def test_build_record_shows_spill_free_chain_kernels():
+    """__graft_entry__.build() records the registers / spills hipcc reports for the hot kernels (BUILD_RECORD.json, tracked).  The
+    row-panel chain kernels must not spill vector registers: a scratch reload inside a stage epilogue drains the weight prefetch
+    stream (33 spilled VGPRs cost 15 % of every chain launch).  Checked when the record belongs to these sources."""
+    import json
+    import bench
+    path = os.path.join(ROOT, "vaenar_tts_amd", "BUILD_RECORD.json")
+    rec = json.load(open(path))
+    assert rec["abi_version"] == _lib.ABI_VERSION and rec["arch"] == "gfx950"
+    if rec["kernel_source_digest"] != bench.kernel_source_digest():
+        pytest.skip("BUILD_RECORD.json is from other kernel sources (run __graft_entry__.build())")
+    res = rec["kernel_resources"]
+    for k in ("panel_chain_kernel<1>", "panel_chain_kernel<2>", "bwd_chain_kernel<1>", "bwd_chain_kernel<2>"):
+        assert res[k]["vgpr_spill"] == 0 and res[k]["scratch_bytes_per_lane"] == 0, (k, res[k])
+        assert res[k]["waves_per_simd"] >= 2, (k, res[k])

@@ -576,6 +576,8 @@ static hipError_t launch_tn_cfg(const float* A, int lda, const float* B, int ldb
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                                  int shift, const unsigned* b_absmax, hipStream_t s) {
   static const int target = getenv("VNR_GEMM_TN_WGS") ? atoi(getenv("VNR_GEMM_TN_WGS")) : 1024;     // measurement knob
+  static const bool skip_all = getenv("VNR_TRAIN_SKIP_TN") != nullptr;      // measurement only (WRONG gradients): the step without its kernel-gradient GEMMs = the main chain alone
+  if (skip_all) return hipSuccess;
   static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
   if (v1) {
     const int tk = (K + 63) / 64, tn = (N + 63) / 64;

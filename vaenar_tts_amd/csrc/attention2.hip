@@ -543,7 +543,15 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
       FILE* f = fopen(p, "ab"); if (f) { int hdr[8] = {a->B, a->H, a->Tq, a->Tk, a->causal, a->ali ? 1 : 0, (int)(n / 8), nqb}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); } } } dump{ts_path, dts, nts, s, &a, nqb};
   const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
   dim3 grid(nqb * a.H * a.B);
-  if (a.ali && a.Tk > 256) {
+  if (a.ali && a.Tk > 256 && a.Tk <= 384) {          // (six / seven tiles: 16 / 32 logit registers less than the eight-tile form, which spills 8 VGPRs)
+    auto k = attn2_kernel<true, 6>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
+  } else if (a.ali && a.Tk > 384 && a.Tk <= 448) {
+    auto k = attn2_kernel<true, 7>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
+  } else if (a.ali && a.Tk > 256) {
     auto k = attn2_kernel<true, 8>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     vnr_launch(k, grid, dim3(256), lds, s, a, nqb);

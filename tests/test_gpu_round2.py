@@ -205,6 +205,41 @@ def test_databaker_inference_and_train_step():
     assert not bad, bad[:10]
 
 
+def test_databaker_data_parallel_rank_shape_with_rccl_bound():
+    """BASELINE config 5 as ONE rank sees it: DataBakerHPS, global batch 32 over 8 ranks = 4 utterances per rank, the RCCL communicator
+    bound (one rank here: no multi-GPU box), deterministic accumulation as train.py runs it.  Every gradient against the float64
+    autograd restatement; the communicator reports its own size and rank; the all-reduced gradient of a one-rank job is the local one."""
+    from oracle.vaenar_torch import TorchOracle
+    hps = DataBakerHPS
+    B, Tt, Tm = 4, 24, 96                                        # (mel / text ratio 4.21 -> ~4 frames per token)
+    w = init_weights(hps, seed=77, mode="synthetic")
+    b = make_batch(B, Tt, Tm, vocab_size=39, latent_dim=hps.Common.latent_dim, ragged=True, seed=5, text_step=3, mel_step=7)
+    r = np.random.Generator(np.random.PCG64(9))
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, Tm // 2, hps.Common.latent_dim)).astype(np.float32)
+    model = VAENAR(hps, weights=w)
+    try:
+        model.engine.set_option("deterministic", 1)
+        args = (b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2)
+        model.train_step(*args, eps=eps, dropout_seed=11, apply_update=False)
+        g_local = model.gradients()
+        model.engine.comm_init(1, 0, model.engine.comm_unique_id())
+        assert model.engine.comm_info() == (1, 0)                # ncclCommCount / ncclCommUserRank of the bound communicator
+        model.engine.comm_broadcast_weights()
+        loss, mel_l2, kl, len_l2 = model.train_step(*args, eps=eps, dropout_seed=11, apply_update=False)
+        got = model.gradients()
+        model.engine.comm_destroy()
+    finally:
+        model.engine.close()
+    for k in got:                                                # deterministic mode: the exchange of one rank changes no bit
+        assert np.array_equal(got[k], g_local[k]), k
+    refg, sc = TorchOracle(hps, w).gradients(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, kl_weight=1.0,
+                                             length_weight=hps.Train.length_weight, dropout_seed=11)
+    assert abs(loss - sc["loss"]) < 1e-4 * max(1, abs(sc["loss"]))
+    bad = [k for k in refg if np.abs(got[k] - refg[k]).max() > 2e-3 * np.abs(refg[k]).max() + 1e-7]
+    assert not bad, bad[:10]
+
+
 # ---- BASELINE config 3 at FULL size: T1 = train step B=32, T_text=128, T_mel=800 ---------------------------------------------
 @pytest.mark.parametrize("rf", [2, 5])
 def test_t1_full_size_train_step_properties(rf):

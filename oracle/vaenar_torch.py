@@ -25,17 +25,33 @@ def _t(a):
     return torch.as_tensor(np.asarray(a, np.float64), dtype=_DT[0])
 
 
-def dense(x, kernel, bias=None, activation=None):
+# ReLU sites.  A hidden unit whose pre-activation lies within float32 rounding of zero has no well-defined mask for an fp32 implementation
+# (it follows the last bits of the forward pass), and one flipped mask changes that layer's kernel gradients by ~4e-3 of their maximum
+# and everything upstream by ~1e-3.  So that tests can tell such a flip from a defect, the oracle (i) records the pre-activations of
+# every ReLU site it evaluates, keyed by the path of the bias that feeds the site, and (ii) can be run with chosen units' masks
+# inverted (`relu_flips` = {site: [flat indices]}): the gradient an implementation with THAT mask computes (oracle/kinks.py).
+_RELU = {"pre": None, "flips": None}
+
+
+def dense(x, kernel, bias=None, activation=None, site=None):
     y = x @ kernel
     if bias is not None:
         y = y + bias
-    return act(y, activation)
+    return act(y, activation, site)
 
 
-def act(x, name):
+def act(x, name, site=None):
     if name is None or name == "identity":
         return x
     if name == "relu":
+        if site is not None and _RELU["pre"] is not None:
+            _RELU["pre"][site] = x.detach()
+            flips = (_RELU["flips"] or {}).get(site)
+            if flips:
+                mask = (x.detach() > 0).reshape(-1).clone()
+                idx = torch.as_tensor(list(flips), dtype=torch.long)
+                mask[idx] = ~mask[idx]
+                return x * mask.reshape(x.shape).to(x.dtype)
         return torch.relu(x)
     if name == "tanh":
         return torch.tanh(x)
@@ -121,7 +137,7 @@ class TorchOracle:
         # fp32 implementation (tests relax the comparison of exactly that layer's gradients, see test_gpu_train.py)
         pre = x @ self._g(f"{p}/dense1/kernel") + self._g(f"{p}/dense1/bias")
         self.last.setdefault("relu_margin", {})[p] = float(pre.detach().abs().min())
-        h = dense(x, self._g(f"{p}/dense1/kernel"), self._g(f"{p}/dense1/bias"), "relu")
+        h = dense(x, self._g(f"{p}/dense1/kernel"), self._g(f"{p}/dense1/bias"), "relu", site=f"{p}/dense1/bias")
         o = dense(h, self._g(f"{p}/dense2/kernel"), self._g(f"{p}/dense2/bias"))
         return layer_norm(o + x, self._g(f"{p}/layer_norm/gamma"), self._g(f"{p}/layer_norm/beta"))
 
@@ -144,7 +160,7 @@ class TorchOracle:
     # utils.py:76-85
     def conv_bn(self, p, x, activation, training, bn_before_act=False):
         assert not bn_before_act
-        y = act(conv1d_same(x, self._g(f"{p}/conv1d/kernel"), self._g(f"{p}/conv1d/bias")), activation)
+        y = act(conv1d_same(x, self._g(f"{p}/conv1d/kernel"), self._g(f"{p}/conv1d/bias")), activation, site=f"{p}/conv1d/bias")
         g, b = self._g(f"{p}/bn/gamma"), self._g(f"{p}/bn/beta")
         if training:
             mean = y.mean((0, 1))
@@ -275,9 +291,11 @@ class TorchOracle:
     # posterior.py:115-130
     def posterior(self, mels, text_embd, text_lengths, target_lengths, training=False):
         q = self.hps.Posterior.Transformer
-        x = dense(mels, self._g("posterior/prenet/dense1/kernel"), self._g("posterior/prenet/dense1/bias"), q.pre_activation)
+        x = dense(mels, self._g("posterior/prenet/dense1/kernel"), self._g("posterior/prenet/dense1/bias"), q.pre_activation,
+                  site="posterior/prenet/dense1/bias")
         x = self._drop(x, "posterior/prenet/dropout1", training)
-        x = dense(x, self._g("posterior/prenet/dense2/kernel"), self._g("posterior/prenet/dense2/bias"), q.pre_activation)
+        x = dense(x, self._g("posterior/prenet/dense2/kernel"), self._g("posterior/prenet/dense2/bias"), q.pre_activation,
+                  site="posterior/prenet/dense2/bias")
         x = self._drop(x, "posterior/prenet/dropout2", training)
         T, D = x.shape[1], x.shape[2]
         x = x + self._g("posterior/pos_weight") * self._pe(T, D, 1.0)
@@ -331,11 +349,18 @@ class TorchOracle:
         loss = mel_l2 + kl_weight * torch.clamp(kl_m, min=0.0) + length_weight * len_l2
         return loss, mel_l2, kl_m, len_l2
 
-    def gradients(self, *args, **kwargs):
-        """{path: dloss/dvariable} for every trainable variable (zeros where the graph does not reach)."""
+    def gradients(self, *args, relu_flips=None, **kwargs):
+        """{path: dloss/dvariable} for every trainable variable (zeros where the graph does not reach).  self.last["relu_pre"] =
+        {bias path of the site: pre-activations} of every ReLU the forward evaluated; relu_flips = {site: [flat indices]} inverts the
+        masks of those units (see _RELU above)."""
         for t in self.w.values():
             t.grad = None
-        loss, mel_l2, kl, len_l2 = self.train_loss(*args, **kwargs)
+        _RELU["pre"], _RELU["flips"] = {}, relu_flips
+        try:
+            loss, mel_l2, kl, len_l2 = self.train_loss(*args, **kwargs)
+            self.last["relu_pre"] = _RELU["pre"]
+        finally:
+            _RELU["pre"], _RELU["flips"] = None, None
         loss.backward()
         g = {k: (t.grad.numpy().copy() if t.grad is not None else np.zeros(tuple(t.shape)))
              for k, t in self.w.items() if t.requires_grad}

@@ -83,3 +83,27 @@ def test_torch_inference_equals_numpy_oracle():
     got32 = TorchOracle(hps, w, torch.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, z_eps).numpy()
     np.testing.assert_allclose(got32, ref, atol=2e-4)
     TorchOracle(hps, w)          # back to the float64 working dtype for the other tests
+
+
+def test_kink_aware_comparison_accepts_a_flipped_unit_and_rejects_a_defect():
+    """oracle/kinks.py on the CPU: an "implementation" whose gradient is the oracle's with the ONE hidden unit closest to its ReLU kink on
+    the other side (+ rounding noise) passes and the unit is named; the plain criterion alone would have failed it; a gradient with one
+    tensor off by 1 % is rejected, with and without such a unit."""
+    from oracle import kinks
+    hps, w, b, mels, eps = _case()
+    run = kinks.torch_oracle_run(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, 1.0, 11)
+    g0, sc, pre = run(None)
+    margin, site, idx = min((float(np.abs(v).min()), k, int(np.abs(v).reshape(-1).argmin())) for k, v in pre.items() if k.endswith("ffn/dense1/bias"))
+    g1 = run({site: [idx]})[0]
+    r = np.random.Generator(np.random.PCG64(1))
+    impl = {k: v + 1e-6 * np.abs(v).max() * r.standard_normal(v.shape) for k, v in g1.items()}
+    assert kinks._bad(impl, g0, 2e-3, 1e-7), "the flip of the closest unit is invisible at 2e-3: choose another case"
+    sc2, flipped = kinks.compare(impl, run, tau=2 * margin + 1e-12)
+    assert sc2 == sc and [(s, i) for s, i, _ in flipped] == [(site, idx)]
+    clean = {k: v + 1e-6 * np.abs(v).max() * r.standard_normal(v.shape) for k, v in g0.items()}
+    assert kinks.compare(clean, run) == (sc, [])
+    victim = "posterior/attentions/0/att_proj2/kernel"
+    for base in (clean, impl):
+        broken = dict(base); broken[victim] = base[victim] * 1.01
+        with pytest.raises(AssertionError):
+            kinks.compare(broken, run, tau=2 * margin + 1e-12)

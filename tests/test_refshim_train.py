@@ -119,17 +119,34 @@ def test_hip_training_step_matches_reference_python(name):
             model.engine.close()
         ref = g[tag + "/scalars"]                                  # loss, mel_l2, kl, length_l2 ; train_step returns (loss, mel_l2, kl, length_l2)
         np.testing.assert_allclose(out, ref, rtol=2e-4)
-        bad = []
-        for k in grads:
-            d, rd = digest(grads[k]), g[tag + "/gdig/" + k]
-            mx = max(rd[18], 1e-30)
-            ok = (np.abs(d[:16] - rd[:16]).max() <= 2e-3 * mx + 1e-7 and abs(d[17] - rd[17]) <= 2e-3 * rd[17] + 1e-7
-                  and abs(d[18] - rd[18]) <= 2e-3 * mx + 1e-7)
-            if ok and ("kw1/grad/" + k) in g and tag == "kw1":
-                full = g["kw1/grad/" + k]
-                ok = np.abs(grads[k] - full).max() <= 2e-3 * np.abs(full).max() + 1e-7
-            if not ok:
-                bad.append(k)
+
+        def mismatches(grads):
+            bad = []
+            for k in grads:
+                d, rd = digest(grads[k]), g[tag + "/gdig/" + k]
+                mx = max(rd[18], 1e-30)
+                ok = (np.abs(d[:16] - rd[:16]).max() <= 2e-3 * mx + 1e-7 and abs(d[17] - rd[17]) <= 2e-3 * rd[17] + 1e-7
+                      and abs(d[18] - rd[18]) <= 2e-3 * mx + 1e-7)
+                if ok and ("kw1/grad/" + k) in g and tag == "kw1":
+                    full = g["kw1/grad/" + k]
+                    ok = np.abs(grads[k] - full).max() <= 2e-3 * np.abs(full).max() + 1e-7
+                if not ok:
+                    bad.append(k)
+            return bad
+        bad = mismatches(grads)
+        if bad:
+            # a hidden unit within float32 rounding of its ReLU kink (oracle/kinks.py)?  The restatement -- equal to the reference's Python to
+            # 1e-9, test above -- names the units and supplies what their flipped masks add; the REFERENCE's gradients stay the yardstick
+            from oracle import kinks
+            run = kinks.torch_oracle_run(hps, w, g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], rf, g["eps"],
+                                         float(g[tag + "/kl_weight"]), seed)
+            _, flipped = kinks.compare(grads, run)
+            assert 0 < len(flipped) <= 3, (tag, bad[:10], flipped)
+            flips = {}
+            for site, i, _ in flipped:
+                flips.setdefault(site, []).append(i)
+            g0, g1 = run(None)[0], run(flips)[0]
+            bad = mismatches({k: grads[k] - (g1[k] - g0[k]) for k in grads})
         assert not bad, (tag, bad[:10])
         for k, v in moving.items():
             np.testing.assert_allclose(v, g["moving/" + k], rtol=2e-5, atol=2e-6, err_msg=k)

@@ -596,7 +596,10 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   static const int force = getenv("VNR_GEMM_TN_TILE") ? atoi(getenv("VNR_GEMM_TN_TILE")) : 0;
   static const bool no3 = getenv("VNR_GEMM_TN_V2") != nullptr;      // A/B switch: the second-generation kernel everywhere
   static const int target3 = getenv("VNR_GEMM_TN3_WGS") ? atoi(getenv("VNR_GEMM_TN3_WGS")) : 128;   // measurement knob (128 against 192: T1 step 22.50 -> 22.37 ms at rf 2, 16.8 -> 16.1 at rf 5: longer row ranges amortise the 8 kcyc prologue)
-  if (!no3 && K >= 128 && N >= 128 && !(lda & 3) && !(ldb & 3) && !(K & 3) && !(N & 3) && !((size_t)A & 15) && !((size_t)B & 15) && M >= 256) {
+  // (narrow kernels too since round 4 -- the 80 / 160 / 400-column mel projections, the 64-column coupling heads, K = 64 pre-projections:
+  //  columns beyond K / N are out-of-range reads = zeros and are not stored; the 64 x 64 kernel spent 44 us on each of those 25 launches)
+  static const int min3 = getenv("VNR_GEMM_TN3_MIN") ? atoi(getenv("VNR_GEMM_TN3_MIN")) : 32;      // A/B switch: 128 = rounds 2-3
+  if (!no3 && K >= min3 && N >= min3 && !(lda & 3) && !(ldb & 3) && !(K & 3) && !(N & 3) && !((size_t)A & 15) && !((size_t)B & 15) && M >= 256) {
     const int tk = (K + 127) / 128, tn = (N + 127) / 128;
     int splits = target3 / (tk * tn); if (splits < 1) splits = 1;
     int max_splits = M / 128; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;

@@ -2696,8 +2696,27 @@ __global__ void __launch_bounds__(256)
 split_batch_kernel(const SplitJob* jobs, float scale) {
   const SplitJob j = jobs[blockIdx.y];
   const int KT = (j.cols + 31) >> 5;
-  const size_t n = (size_t)j.rows * KT * 32;
   _Float16* out = reinterpret_cast<_Float16*>(j.dst);
+  if (!(j.cols & 31) && !((size_t)j.src & 15)) {
+    // fast path (every kernel of the model): one thread per (row, k-tile, 8-element group): two 16-byte loads, two 16-byte stores; the
+    // (row, k-tile) pair of a 4-thread group by 32-bit arithmetic (the generic path below spends its time in 64-bit divisions)
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const unsigned groups = (unsigned)j.rows * (unsigned)KT * 4u;
+    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += gridDim.x * blockDim.x) {
+      const unsigned q = g & 3u, nk = g >> 2, kt = nk % (unsigned)KT, r = nk / (unsigned)KT;
+      const float4* src = reinterpret_cast<const float4*>(j.src + (size_t)r * j.cols + kt * 32 + q * 8);
+      const float4 a = src[0], b = src[1];
+      const float w[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+      h8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)w[e]; hi[e] = hh; lo[e] = (_Float16)(w[e] - (float)hh); }
+      const size_t o = (j.dst_kt ? (size_t)r * (size_t)j.dst_kt + kt : (size_t)nk) * 64 + q * 8;
+      *reinterpret_cast<h8*>(out + o) = hi;
+      *reinterpret_cast<h8*>(out + o + 32) = lo;
+    }
+    return;
+  }
+  const size_t n = (size_t)j.rows * KT * 32;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
     const int p = (int)(idx & 31);
     const size_t nk = idx >> 5;
@@ -2731,19 +2750,29 @@ opmajor_batch_kernel(const OpmJob* jobs, float scale) {
   const int KT = (j.K + 31) >> 5, NB = (j.N + 31) >> 5;
   const size_t total = (size_t)NB * KT * 128;                 // one thread per (column block, k-tile, k16 step, lane)
   _Float16* out = reinterpret_cast<_Float16*>(j.dst);
+  const bool fast = !(j.K & 31) && !(j.N & 31) && !((size_t)j.src & 15) && total < 0xffffffffull;      // (every kernel of the model)
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int lane = (int)(idx & 63), t = (int)((idx >> 6) & 1);
     const size_t blk = idx >> 7;
-    const int kt = (int)(blk % KT);
-    const size_t nb = blk / KT;
+    int kt; size_t nb;
+    if (fast) { const unsigned b32 = (unsigned)blk; kt = (int)(b32 % (unsigned)KT); nb = b32 / (unsigned)KT; }
+    else { kt = (int)(blk % KT); nb = blk / KT; }
     const int n = (int)nb * 32 + (lane & 31), k0 = kt * 32 + 16 * t + 8 * (lane >> 5);
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     h8 hi, lo;
+    if (fast) {
+      const float4* src = reinterpret_cast<const float4*>(j.src + (size_t)n * j.K + k0);
+      const float4 a = src[0], b = src[1];
+      const float w[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = (n < j.N && k0 + e < j.K) ? j.src[(size_t)n * j.K + k0 + e] * scale : 0.f;
-      const _Float16 hh = (_Float16)w;
-      hi[e] = hh; lo[e] = (_Float16)(w - (float)hh);
+      for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)w[e]; hi[e] = hh; lo[e] = (_Float16)(w[e] - (float)hh); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = (n < j.N && k0 + e < j.K) ? j.src[(size_t)n * j.K + k0 + e] * scale : 0.f;
+        const _Float16 hh = (_Float16)w;
+        hi[e] = hh; lo[e] = (_Float16)(w - (float)hh);
+      }
     }
     _Float16* ph = out + ((blk * 4 + 2 * t) * 512) + lane * 8;
     *reinterpret_cast<h8*>(ph) = hi;

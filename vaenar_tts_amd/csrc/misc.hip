@@ -561,6 +561,16 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
       else if (act == ACT_TANH) { v.x *= 1.f - y.x * y.x; v.y *= 1.f - y.y * y.y; v.z *= 1.f - y.z * y.z; v.w *= 1.f - y.w * y.w; }
     };
     if (yact) {                                                // (the activation output is a contiguous [M][C] block)
+      // (a lane walks ~25 rows of a T1-sized gradient: with two rows in flight the kernel was latency-bound at 0.9 TB/s; four rows = 8 loads)
+      for (; m + 3 * step < M; m += 4 * step) {
+        float4* p[4]; float4 v[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p[u] = reinterpret_cast<float4*>(x + (size_t)(m + u * step) * ld + c); v[u] = *p[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = *reinterpret_cast<const float4*>(yact + (size_t)(m + u * step) * C + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dact(v[u], y[u]); *p[u] = v[u]; add(v[u]); }
+      }
       for (; m + step < M; m += 2 * step) {
         float4* p0 = reinterpret_cast<float4*>(x + (size_t)m * ld + c);
         float4* p1 = reinterpret_cast<float4*>(x + (size_t)(m + step) * ld + c);
@@ -578,6 +588,13 @@ __global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* me
         add(v0);
       }
     } else {
+    for (; m + 7 * step < M; m += 8 * step) {                  // eight rows in flight (see above)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(x + (size_t)(m + u * step) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) add(v[u]);
+    }
     for (; m + step < M; m += 2 * step) {
       const float4 v0 = *reinterpret_cast<const float4*>(x + (size_t)m * ld + c);
       const float4 v1 = *reinterpret_cast<const float4*>(x + (size_t)(m + step) * ld + c);

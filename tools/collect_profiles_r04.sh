@@ -29,6 +29,7 @@ for PP in "$P1" "$P2" "$P3"; do
   echo >> $O/chain_pmc.txt
   rm -rf $O/p$i
 done
+python3 tools/trim_chain_pmc.py $O/chain_pmc.txt $(python3 -c 'import bench; print(bench.kernel_source_digest())') > $O/chain_pmc_trimmed.txt
 rm -f /tmp/cts.bin; VNR_CHAIN_TS=/tmp/cts.bin VNR_CHAIN_TS_STAGE=1 python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/chain_timeline.py /tmp/cts.bin > $O/chain_rows32_timeline.txt 2>&1
 rm -f /tmp/g.ts; VNR_GEMM_TS=/tmp/g.ts python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/gemm_timeline.py /tmp/g.ts > $O/gemm_timeline.txt 2>&1
 rocprofv3 --kernel-trace -d $O/sq -o s -- python3 bench.py --steps 6 --warmup 3 --profile-steps 0 $P > $O/sq.log 2>&1; python3 tools/launch_sequence.py $(ls $O/sq/*.db $O/sq/*/*.db 2>/dev/null | head -1) > $O/launch_sequence.txt; rm -rf $O/sq

@@ -274,6 +274,10 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * (cross-attention with T_text <= 128 / every self-attention); 0 = fp32 Q, K, V and the in-kernel split.
  * "op_attn_presplit" (default 0): vnr_op_attention converts its fp32 operands to images and takes that kernel (tests).
  * "late_dec_kv" (default 1): vnr_inference computes the decoder's cross K|V right before the decoder.
+ * "prior_inverse" (default 0): Prior.Transformer.inverse = True (/root/reference/modules/prior.py:81-99: every flow of the prior is built
+ *    with the flag, and BaseFlow.call / fwd_pass / bwd_pass, flow.py:36-113, swap _forward and _backward).  vnr_prior_sample,
+ *    vnr_prior_log_probability, vnr_prior_init, vnr_inference, vnr_elbo_fwd and vnr_init then follow that dispatch (one launch per
+ *    operation; neither LJHPS nor DataBakerHPS sets it); vnr_train_step refuses.
  * "chain_rows64" (default 0): 64-row panels in the chain kernel -- half the workgroups, half the weight stream per row; slower
  * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams).
  * "gemm_wide_tiles" (default 0): the same trade for the tiled GEMM kernel (64x128 workgroup tiles wherever N >= 128).

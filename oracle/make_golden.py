@@ -230,6 +230,41 @@ def build_ref_b2():
     return out
 
 
+def build_ref_inverse():
+    """tests/golden/refshim_inverse.npz -- Prior.Transformer.inverse = True (prior.py:81-99; BaseFlow.call / fwd_pass / bwd_pass swap
+    _forward and _backward, flow.py:36-113), which neither LJHPS nor DataBakerHPS uses (hparams.py:344,462): the reference's own Python
+    on the shims, tiny configuration: VAENAR.inference, VAENAR.call (evaluation mode), prior.sample / call / log_probability / init."""
+    from oracle.run_reference_on_shim import reference_call, reference_inference, reference_module_methods
+    hps = tiny_hps()
+    hps.Prior.Transformer.inverse = True
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    B, Tt, Tm, rf = 3, 11, 40, 2
+    b = make_batch(B, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, seed=19,
+                   text_step=3, mel_step=7, temperature=1.0)
+    r = np.random.Generator(np.random.PCG64(43))
+    C, Tz = hps.Common.latent_dim, (Tm + rf - 1) // rf
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    zl = ((b["mel_lengths"].astype(np.int64) + rf - 1) // rf).astype(np.int32)
+    eps_post = r.standard_normal((B, 1, Tz, C)).astype(np.float32)
+    eps_prior = r.standard_normal((B, int(zl.max()), C)).astype(np.float32)
+    eps_init = r.standard_normal((B, int(zl.max()), C)).astype(np.float32)
+    out = dict(ids=b["ids"], text_lengths=b["text_lengths"], mel_lengths=b["mel_lengths"], z_lengths=zl, mels=mels, eps=b["eps"],
+               eps_post=eps_post, eps_prior=eps_prior, eps_init=eps_init, reduction_factor=np.int64(rf),
+               weights_sha256=np.frombuffer(weights_digest(w).encode(), np.uint8))
+    mel, ali, _, _ = reference_inference(hps, w, b["ids"], b["mel_lengths"], b["text_lengths"], b["eps"])
+    out["mel"] = np.asarray(mel, np.float32)
+    for k, v in ali.items():
+        out["ali_" + k] = np.asarray(v, np.float32)
+    outs, l2, kl, ll, _ = reference_call(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], eps_post)
+    out.update(call_outs=np.asarray(outs, np.float32), call_l2=np.asarray(l2, np.float64), call_kl=np.asarray(kl, np.float64),
+               call_length=np.asarray(ll, np.float64))
+    mm = reference_module_methods(hps, w, b["ids"], b["text_lengths"], mels[:, ::rf], zl, eps_post, eps_prior, eps_init, 11)
+    for k, v in mm.items():
+        if k.startswith("prior_") or k.startswith("init/") or k == "text_embd":
+            out["mod/" + k] = np.asarray(v, np.float64)
+    return out
+
+
 def digest(a):
     """[16 samples at fixed strided flat positions | sum | l2 norm | max abs] of an array, float64."""
     f = np.asarray(a, np.float64).reshape(-1)
@@ -250,6 +285,8 @@ def main():
             np.savez_compressed(os.path.join(d, name + ".npz"), **build_ref(name))
             print("wrote", name, os.path.getsize(os.path.join(d, name + ".npz")) // 1024, "KiB (reference's own Python over the tf shim)")
         np.savez_compressed(os.path.join(d, "refshim_nsample2.npz"), **build_ref_nsample(2))
+        np.savez_compressed(os.path.join(d, "refshim_inverse.npz"), **build_ref_inverse())
+        print("wrote refshim_inverse", os.path.getsize(os.path.join(d, "refshim_inverse.npz")) // 1024, "KiB")
         print("wrote refshim_nsample2", os.path.getsize(os.path.join(d, "refshim_nsample2.npz")) // 1024, "KiB (reference's own Python, num_samples = 2)")
         np.savez_compressed(os.path.join(d, "refshim_b2.npz"), **build_ref_b2())
         print("wrote refshim_b2", os.path.getsize(os.path.join(d, "refshim_b2.npz")) // 1024, "KiB (reference's own Python: module-level methods, num_samples = 2 training step)")

@@ -422,39 +422,50 @@ class Oracle:
         mask = sequence_mask(lengths)[:, :, None].astype(self.dtype)
         return eps, (mask * logp).sum((1, 2))
 
+    def _inverse_flows(self):
+        """Prior.Transformer.inverse (prior.py:81,88-99): every flow of the prior is built with this flag, and BaseFlow.call / fwd_pass /
+        bwd_pass (flow.py:36-47,76-113) swap _forward and _backward when it is set."""
+        return bool(getattr(self.hps.Prior.Transformer, "inverse", False))
+
     def prior_sample(self, lengths, cond, cond_lengths, eps):
-        """TransformerPrior.sample (prior.py:154-169)."""
+        """TransformerPrior.sample (prior.py:154-169) = TransformerPrior.call (prior.py:101-117): actnorm(z), linear(z) are BaseFlow.call,
+        the coupling runs fwd_pass -- with inverse=True flows all three are the _backward passes, in the same step order."""
+        inv = self._inverse_flows()
         z, logp = self.initial_sample(lengths, eps)
         for s in range(self.hps.Prior.Transformer.n_blk):
             p = f"prior/glow/{s}"
-            z, ld = self.actnorm_forward(f"{p}/0", z, lengths); logp = logp - ld
-            z, ld = self.invlinear_forward(f"{p}/1", z, lengths); logp = logp - ld
-            z, ld = self.coupling(f"{p}/2", s % 2 == 0, z, cond, lengths, cond_lengths)
+            z, ld = (self.actnorm_backward if inv else self.actnorm_forward)(f"{p}/0", z, lengths); logp = logp - ld
+            z, ld = (self.invlinear_backward if inv else self.invlinear_forward)(f"{p}/1", z, lengths); logp = logp - ld
+            z, ld = self.coupling(f"{p}/2", s % 2 == 0, z, cond, lengths, cond_lengths, backward=inv)
             logp = logp - ld
             self.last[f"prior_z_{s}"] = z
         return z, logp
 
     def prior_init(self, lengths, cond, cond_lengths, eps):
-        """TransformerPrior.init (prior.py:171-186): data-dependent ActNorm init."""
+        """TransformerPrior.init (prior.py:171-186): data-dependent ActNorm init.  actnorm.init and coupling.init are called directly
+        (flow.py:189-196: statistics, then _forward; flow.py:259-262: _forward) whatever `inverse` says; linear(z) is BaseFlow.call."""
+        inv = self._inverse_flows()
         z, logp = self.initial_sample(lengths, eps)
         for s in range(self.hps.Prior.Transformer.n_blk):
             p = f"prior/glow/{s}"
             z, ld = self.actnorm_init(f"{p}/0", z, lengths); logp = logp - ld
-            z, ld = self.invlinear_forward(f"{p}/1", z, lengths); logp = logp - ld
+            z, ld = (self.invlinear_backward if inv else self.invlinear_forward)(f"{p}/1", z, lengths); logp = logp - ld
             z, ld = self.coupling(f"{p}/2", s % 2 == 0, z, cond, lengths, cond_lengths)
             logp = logp - ld
         return z, logp
 
     def prior_log_probability(self, z, cond, z_lengths, cond_lengths):
-        """TransformerPrior.log_probability (prior.py:119-152)."""
+        """TransformerPrior.log_probability (prior.py:119-152): bwd_pass of every flow, steps reversed -- _backward passes, or with
+        inverse=True flows the _forward passes."""
+        inv = self._inverse_flows()
         eps = z
         accum = np.zeros(z.shape[0], self.dtype)
         for s in reversed(range(self.hps.Prior.Transformer.n_blk)):
             p = f"prior/glow/{s}"
             eps, ld = self.coupling(f"{p}/2", s % 2 == 0, eps, cond, z_lengths, cond_lengths,
-                                    backward=True); accum = accum + ld
-            eps, ld = self.invlinear_backward(f"{p}/1", eps, z_lengths); accum = accum + ld
-            eps, ld = self.actnorm_backward(f"{p}/0", eps, z_lengths); accum = accum + ld
+                                    backward=not inv); accum = accum + ld
+            eps, ld = (self.invlinear_forward if inv else self.invlinear_backward)(f"{p}/1", eps, z_lengths); accum = accum + ld
+            eps, ld = (self.actnorm_forward if inv else self.actnorm_backward)(f"{p}/0", eps, z_lengths); accum = accum + ld
         logp = -0.5 * (LOG_2PI + eps ** 2)
         mask = sequence_mask(z_lengths, z.shape[1])[:, :, None].astype(self.dtype)
         return (mask * logp).sum((1, 2)) + accum

@@ -312,3 +312,96 @@ def test_training_flag_does_not_stick_after_a_failing_call(b2_model):
               training=True, eps=np.zeros((2, 1, 1, hps.Common.latent_dim), np.float32))
     mel1, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, eps=b["eps"])
     assert np.array_equal(mel0.numpy(), mel1.numpy())
+
+
+# ---- Prior.Transformer.inverse = True (prior.py:81-99; flow.py:36-113): the reference's own Python on the shims ---------------------------
+def _load_inverse():
+    with np.load(os.path.join(GOLD, "refshim_inverse.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    hps = tiny_hps()
+    hps.Prior.Transformer.inverse = True
+    w = init_weights(hps, seed=SEED, mode="synthetic")
+    assert weights_digest(w) == bytes(g["weights_sha256"]).decode(), "synthetic weight generator changed"
+    return g, hps, w
+
+
+def test_oracle_follows_the_reference_with_inverse_flows():
+    """BaseFlow.call / fwd_pass / bwd_pass swap _forward and _backward when the prior is built with inverse=True: sample / call run the
+    _backward passes, log_probability the _forward passes, init mixes them (actnorm.init and coupling.init are called directly)."""
+    from oracle.vaenar_numpy import Oracle
+    g, hps, w = _load_inverse()
+    o = Oracle(hps, {k: np.asarray(v, np.float64) for k, v in w.items()}, np.float64)
+    mel, ali = o.inference(g["ids"], g["mel_lengths"], g["text_lengths"], 2, g["eps"].astype(np.float64))
+    assert np.abs(mel - g["mel"]).max() < 2e-6
+    for k in ali:
+        assert np.abs(ali[k] - g["ali_" + k]).max() < 1e-6
+    outs, l2, kl, ll, _ = o.call(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], 2, False, False, g["eps_post"].astype(np.float64))
+    assert np.abs(outs - g["call_outs"]).max() < 2e-6
+    np.testing.assert_allclose(l2, g["call_l2"], rtol=1e-6)
+    np.testing.assert_allclose(kl, g["call_kl"], rtol=1e-6, atol=2e-2)
+    text, zl, tl = g["mod/text_embd"], g["z_lengths"], g["text_lengths"]
+    z, lp = o.prior_sample(zl, text, tl, g["eps_prior"].astype(np.float64))
+    assert np.abs(z - g["mod/prior_sample_z_eval"]).max() < 2e-6 and np.array_equal(g["mod/prior_call_z_eval"], g["mod/prior_sample_z_eval"])
+    np.testing.assert_allclose(lp, g["mod/prior_sample_lp_eval"], rtol=1e-7)
+    np.testing.assert_allclose(o.prior_log_probability(z, text, zl, tl), g["mod/prior_logprob_eval"], rtol=1e-7)
+    # the two directions are inverses of each other whatever they are called: log p(sample) is the sample's own log-probability
+    np.testing.assert_allclose(g["mod/prior_logprob_eval"], g["mod/prior_sample_lp_eval"], rtol=1e-6)
+    zi, lpi = o.prior_init(zl, text, tl, g["eps_init"].astype(np.float64))
+    assert np.abs(zi - g["mod/prior_init_z"]).max() < 2e-6
+    np.testing.assert_allclose(lpi, g["mod/prior_init_lp"], rtol=1e-7)
+    for k in g:
+        if k.startswith("mod/init/"):
+            np.testing.assert_allclose(o.w[k[9:]], g[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    # and it is NOT what the forward-flow model computes on the same weights
+    hps0 = tiny_hps()
+    z0, _ = Oracle(hps0, {k: np.asarray(v, np.float64) for k, v in w.items()}, np.float64).prior_sample(zl, text, tl, g["eps_prior"].astype(np.float64))
+    assert np.abs(z0 - z).max() > 1e-2
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference tree is only present in the build container")
+def test_inverse_fixture_is_reproducible_from_the_reference():
+    from oracle.make_golden import build_ref_inverse
+    g, _, _ = _load_inverse()
+    fresh = build_ref_inverse()
+    assert sorted(fresh) == sorted(g)
+    for k in g:
+        assert np.array_equal(np.asarray(fresh[k]), g[k]), k
+
+
+@pytest.mark.gpu
+def test_hip_inverse_flows_match_the_reference_python():
+    """Engine option "prior_inverse" (set by TransformerPrior(inverse=True)): inference, the ELBO forward, prior.sample / call /
+    log_probability / init against the reference-made fixture; the training step refuses."""
+    from vaenar_tts_amd._lib import VnrError
+    from vaenar_tts_amd.models import VAENAR
+    g, hps, w = _load_inverse()
+    model = VAENAR(hps, weights=w)
+    try:
+        assert model.prior.inverse
+        mel, ali = model.inference(g["ids"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, eps=g["eps"])
+        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-4
+        for k in ali:
+            assert np.abs(ali[k].numpy() - g["ali_" + k]).max() < 1e-4
+        outs, l2, kl, ll, _ = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,
+                                    reduce_loss=False, eps=g["eps_post"])
+        assert np.abs(outs.numpy() - g["call_outs"]).max() < 2e-4
+        np.testing.assert_allclose(l2.numpy(), g["call_l2"], rtol=2e-5)
+        np.testing.assert_allclose(kl.numpy(), g["call_kl"], rtol=2e-4, atol=5e-2)
+        text, zl, tl = g["mod/text_embd"].astype(np.float32), g["z_lengths"], g["text_lengths"]
+        z, lp = model.prior.sample(zl, text, tl, training=False, eps=g["eps_prior"])
+        assert np.abs(z.numpy() - g["mod/prior_sample_z_eval"]).max() < 5e-5
+        np.testing.assert_allclose(lp.numpy(), g["mod/prior_sample_lp_eval"], rtol=2e-5)
+        z2, lp2 = model.prior(text, zl, tl, eps=g["eps_prior"])
+        assert np.array_equal(z2.numpy(), z.numpy())
+        lq = model.prior.log_probability(g["mod/prior_sample_z_eval"].astype(np.float32), text, z_lengths=zl, condition_lengths=tl)
+        np.testing.assert_allclose(lq.numpy(), g["mod/prior_logprob_eval"], rtol=2e-5)
+        with pytest.raises(VnrError):
+            model.train_step(g["ids"], g["mels"], g["text_lengths"], g["mel_lengths"], 1.0, 2, eps=g["eps_post"][:, 0])
+        zi, lpi = model.prior.init(text, zl, tl, eps=g["eps_init"])
+        assert np.abs(zi.numpy() - g["mod/prior_init_z"]).max() < 1e-4
+        np.testing.assert_allclose(lpi.numpy(), g["mod/prior_init_lp"], rtol=3e-5)
+        got = model.get_weights([k[9:] for k in g if k.startswith("mod/init/")])
+        for k, v in got.items():
+            np.testing.assert_allclose(v, g["mod/init/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
+    finally:
+        model.engine.close()

@@ -450,6 +450,7 @@ hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float
 hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float* const* WinvT, float* const* lad, int n, int C, hipStream_t s);
 hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, float* sc, float* sh, float* lssum, hipStream_t s);
 hipError_t launch_axpy_len_dev(float* y, const int32_t* len, const float* alpha, float sign, int B, hipStream_t s);
+hipError_t launch_actnorm_fwd_params(const float* ls, int C, float* sc, float* lssum, hipStream_t s);      // sc = exp(ls), *lssum = sum(ls)
 hipError_t launch_train_seeds(const float* sum_out, const float* sum_init, const int32_t* mel_len, const float* ll, const float* post_lp,
                               const float* prior_lp, const int32_t* red_len, int B, int Bl, float kw, float lw, float* g_post, float* g_prior,
                               float* cg, float* scalars, hipStream_t s, int part = 0);

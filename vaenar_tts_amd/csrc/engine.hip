@@ -130,6 +130,7 @@ struct vnr_context {
   bool in_train_step = false;    // set by vnr_train_step around its launches (GemmArgs::no_loader_waves)
   bool gemm_wide_tiles = false;  // engine option "gemm_wide_tiles": 64x128 tiles for every split GEMM with N >= 128 (see chain_rows64)
   bool chain_rows64 = false;     // engine option "chain_rows64": 64-row panels in the chain kernel (half the workgroups, half the weight stream per row)
+  bool prior_inverse = false;    // engine option "prior_inverse": Prior.Transformer.inverse = True (prior_inverse_body); inference / evaluation / init only
   bool late_dec_kv = true;       // engine option "late_dec_kv": vnr_inference computes the decoder's cross K|V right before the decoder
   int train_chain_bwd = 1;           // engine option "train_chain_bwd": the backward of the same blocks as two backward-chain launches (gemm3b.hip)
   int train_chain = 1;               // engine option "train_chain" (train.inc: xblk_chain): 0 off, 1 auto, 2 / 3 force 64- / 32-row panels
@@ -939,12 +940,126 @@ int encoder_body_impl(vnr_handle h, const int32_t* ids, const int32_t* lens, int
 // TransformerPrior.sample (prior.py:154-169); kv = prior cross K|V panel output [B*Tt, kv_ld].
 // final_post / final_done: stages to run behind the LAST flow step's coupling inside its chain launch (the decoder's pre-chain in
 // vnr_inference; the coupled z is in panel 1) and whether that happened.
+// ---- Prior.Transformer.inverse = True (prior.py:81-99; engine option "prior_inverse") ------------------------------------------------
+// Every flow of the prior is then built with inverse = True and BaseFlow.call / fwd_pass / bwd_pass (flow.py:36-47,76-113) swap
+// _forward and _backward:
+//   mode 0  sample / call (prior.py:101-117,154-169): steps 0 .. n-1, each ActNorm._backward -> InvertibleLinear._backward ->
+//           coupling._backward, logprobs -= logdet;
+//   mode 1  log_probability (prior.py:119-152): steps n-1 .. 0, each coupling._forward -> InvertibleLinear._forward -> ActNorm._forward,
+//           accumulated logdet + the Gaussian of the result;
+//   mode 2  init (prior.py:171-186): ActNorm.init (statistics, then _forward -- called directly, flow.py:189-196) ->
+//           InvertibleLinear._backward (BaseFlow.call) -> coupling.init = _forward (flow.py:259-262).
+// Neither LJHPS nor DataBakerHPS sets the flag (hparams.py:344,462): one unfused launch per operation, inv(W) by the in-LDS float64
+// Gauss-Jordan kernel of the training step; the coupling networks run on the same block launches as everywhere else.
+int prior_inverse_body(vnr_handle h, int mode, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B, int Tz, int Tt,
+                       const float* zin, float* z_out, float* logprobs) {
+  const vnr_config& c = h->cfg;
+  const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  const int nsteps = (int)h->flow.size();
+  if (nsteps > 8 || C > 128) return fail(h, VNR_ERR_ARG, "inverse flows: at most 8 flow steps of at most 128 channels");
+  WS(za, (size_t)M * C); WS(zb, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C);
+  WS(stat, (size_t)4 * C + C); WS(wt, (size_t)C * C); WS(rowld, (size_t)M); WS(prm, (size_t)64 + 2 * C); WS(base, (size_t)B);
+  float* sc = prm + 64; float* sh = prm + 64 + C; float* lssum = prm;
+  const float* Wsrc[8]; float* Winv[8]; float* WinvT[8]; float* lad[8];
+  for (int s = 0; s < nsteps; ++s) {
+    Wsrc[s] = h->flow[s].lin_w; Winv[s] = ws_alloc(h, (size_t)C * C); WinvT[s] = ws_alloc(h, (size_t)C * C); lad[s] = ws_alloc(h, 64);
+    if (!Winv[s] || !WinvT[s] || !lad[s]) return fail(h, VNR_ERR_NOMEM, "workspace allocation failed");
+  }
+  if (mode != 1) RUN_MISC(h, launch_invert_batch(Wsrc, Winv, WinvT, lad, nsteps, C, h->stream));
+  if (zin) HIP_TRY(h, hipMemcpyAsync(za, zin, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  else HIP_TRY(h, hipMemsetAsync(za, 0, (size_t)M * C * 4, h->stream));
+  if (logprobs) {
+    if (mode == 1) HIP_TRY(h, hipMemsetAsync(logprobs, 0, (size_t)B * 4, h->stream));
+    else RUN_MISC(h, launch_gauss_logprob(za, z_len, B, Tz, C, logprobs, h->stream));                  // _initial_sample (prior.py:36-41)
+  }
+  const float* pe = nullptr;
+  TRY(get_pe(h, Tz, D, 1.0f, &pe));
+  float* zc = za; float* zn = zb;
+  auto dense_cc = [&](const float* Wt_nk) -> int {          // zn = zc . W on the exact fp32 path, Wt_nk = W^T [N][K]
+    GemmArgs g;
+    g.A1 = zc; g.lda1 = C; g.K1 = C; g.K = C; g.Wt = Wt_nk; g.ldw = C; g.C = zn; g.ldc = C; g.M = M; g.N = C;
+    const bool saved = h->split_scope; h->split_scope = false;
+    const int rc = run_gemm(h, g);
+    h->split_scope = saved;
+    if (rc == VNR_OK) std::swap(zc, zn);
+    return rc;
+  };
+  auto coupling = [&](int s, bool backward, float sign) -> int {     // on zc, in place; logprobs += sign * sum_valid log(scale)
+    const FlowStep& f = h->flow[s];
+    const bool upper = (s % 2) == 0;
+    const int cond_off = upper ? 0 : half, zp_off = upper ? half : 0;
+    GemmArgs g;
+    g.A1 = zc + cond_off; g.lda1 = C; g.K1 = half; g.K = half; g.Wt = f.pre_wt; g.ldw = half; g.bias = f.pre_b;
+    g.pe = pe; g.pe_T = Tz; g.pe_w = f.pos_weight; g.C = xa; g.ldc = D; g.M = M; g.N = D;
+    TRY(run_gemm(h, g));
+    float* xc = nullptr;
+    TRY(run_xstack(h, f.blks, xa, xb, kv, kv_ld, z_len, t_len, B, Tz, Tt, c.prior_attention_heads, c.prior_temperature,
+                   nullptr, 0, {Tail{f.heads_wt, C, f.heads_b, heads, C}}, &xc));
+    if (f.blks.empty()) {
+      g = GemmArgs(); g.A1 = xc; g.lda1 = D; g.K1 = D; g.K = D; g.Wt = f.heads_wt; g.ldw = D; g.bias = f.heads_b; g.C = heads; g.ldc = C; g.M = M; g.N = C;
+      TRY(run_gemm(h, g));
+    }
+    if (backward) RUN_MISC(h, launch_coupling_bwd(heads, zc, M, half, zp_off, rowld, h->stream));
+    else RUN_MISC(h, launch_coupling_fwd(heads, zc, M, half, zp_off, rowld, h->stream));
+    if (logprobs) RUN_MISC(h, launch_masked_row_reduce(rowld, z_len, B, Tz, sign, logprobs, 1, h->stream));
+    return VNR_OK;
+  };
+  for (int i = 0; i < nsteps; ++i) {
+    const int s = mode == 1 ? nsteps - 1 - i : i;
+    const FlowStep& f = h->flow[s];
+    if (mode == 0) {
+      // ActNorm._backward (flow.py:177-187): (z - b) / (exp(ls) + 1e-8), logdet = -len * sum(ls)
+      RUN_MISC(h, launch_actnorm_inv_params(f.an_log_scale, f.an_bias, C, sc, sh, lssum, h->stream));
+      RUN_MISC(h, launch_rowop(zc, M, C, sc, sh, nullptr, 1, 0.f, 0.f, 0u, zc, h->stream));
+      if (logprobs) RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lssum, 1.f, B, h->stream));
+      // InvertibleLinear._backward (flow.py:137-150): z . inv(W), logdet = len * log|det inv(W)|
+      TRY(dense_cc(WinvT[s]));
+      if (logprobs) RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lad[s], -1.f, B, h->stream));
+      TRY(coupling(s, true, 1.0f));                          // logdet = -sum log(scale): logprobs -= logdet
+    } else if (mode == 1) {
+      TRY(coupling(s, false, 1.0f));                         // logdet = +sum log(scale), accumulated
+      RUN_MISC(h, launch_transpose(f.lin_w, C, C, wt, C, h->stream));
+      TRY(dense_cc(wt));                                     // InvertibleLinear._forward: z . W, logdet = len * log|det W|
+      if (logprobs) RUN_MISC(h, launch_axpy_len(logprobs, z_len, (float)f.lin_logdet, B, h->stream));
+      // ActNorm._forward (flow.py:166-175): z * exp(ls) + b, logdet = len * sum(ls)
+      RUN_MISC(h, launch_actnorm_fwd_params(f.an_log_scale, C, sc, lssum, h->stream));
+      RUN_MISC(h, launch_rowop(zc, M, C, sc, f.an_bias, nullptr, 1, 0.f, 0.f, 0u, zc, h->stream));
+      if (logprobs) RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lssum, 1.f, B, h->stream));
+    } else {
+      // ActNorm.init: per-channel mean / population std over ALL B*Tz rows (padding included), then the forward (flow.py:189-196)
+      double* mean = reinterpret_cast<double*>(stat);
+      double* sq = mean + C;
+      float* isc = stat + 4 * C;
+      HIP_TRY(h, hipMemsetAsync(stat, 0, (size_t)4 * C * sizeof(float), h->stream));
+      RUN_MISC(h, launch_col_sum(zc, M, C, C, nullptr, mean, h->stream));
+      RUN_MISC(h, launch_scale_d(mean, C, 1.0 / (double)M, h->stream));
+      RUN_MISC(h, launch_col_sum(zc, M, C, C, mean, sq, h->stream));
+      RUN_MISC(h, launch_actnorm_init_finish(mean, sq, M, C, f.an_log_scale, f.an_bias, isc, h->stream));
+      RUN_MISC(h, launch_rowop(zc, M, C, isc, f.an_bias, nullptr, 1, 0.f, 0.f, 0u, zc, h->stream));
+      if (logprobs) {
+        RUN_MISC(h, launch_actnorm_fwd_params(f.an_log_scale, C, sc, lssum, h->stream));
+        RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lssum, -1.f, B, h->stream));
+      }
+      TRY(dense_cc(WinvT[s]));                               // linear(z) is BaseFlow.call -> _backward
+      if (logprobs) RUN_MISC(h, launch_axpy_len_dev(logprobs, z_len, lad[s], -1.f, B, h->stream));
+      TRY(coupling(s, false, -1.0f));                        // coupling.init = _forward: logprobs -= sum log(scale)
+    }
+  }
+  if (mode == 1 && logprobs) {
+    RUN_MISC(h, launch_gauss_logprob(zc, z_len, B, Tz, C, base, h->stream));     // -0.5 (log 2pi + eps^2), masked (prior.py:147-150)
+    RUN_MISC(h, launch_masked_row_reduce(base, nullptr, B, 1, 1.0f, logprobs, 1, h->stream));
+  }
+  if (z_out) HIP_TRY(h, hipMemcpyAsync(z_out, zc, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
+  return VNR_OK;
+}
+
 int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const float* kv, int kv_ld, int B,
                int Tz, int Tt, const float* eps, float* z_out, float* logprobs, const std::vector<PreStage>* final_post = nullptr,
                bool* final_done = nullptr) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
   if (final_done) *final_done = false;
+  if (h->prior_inverse) return prior_inverse_body(h, 0, z_len, t_len, kv, kv_ld, B, Tz, Tt, eps, z_out, logprobs);
   WS(za, (size_t)M * C); WS(xa0, (size_t)M * D); WS(xa1, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M);
   float* xas[2] = {xa0, xa1};
   if (eps) HIP_TRY(h, hipMemcpyAsync(za, eps, (size_t)M * C * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -1041,6 +1156,7 @@ int prior_init_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, co
                     int Tz, int Tt, const float* eps, float* z_out, float* logprobs = nullptr) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  if (h->prior_inverse) return prior_inverse_body(h, 2, z_len, t_len, kv, kv_ld, B, Tz, Tt, eps, z_out, logprobs);
   WS(za, (size_t)M * C); WS(zb, (size_t)M * C); WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C);
   WS(stat, (size_t)4 * C + C); WS(wt, (size_t)C * C); WS(rowld, (size_t)M); WS(lsum, (size_t)64 + 2 * C);
   if (logprobs) RUN_MISC(h, launch_gauss_logprob(eps, z_len, B, Tz, C, logprobs, h->stream));      // _initial_sample (prior.py:36-41)
@@ -1205,6 +1321,7 @@ int prior_logprob_body(vnr_handle h, float* z, const int32_t* z_len, const int32
                        int B, int Tz, int Tt, float* logprobs) {
   const vnr_config& c = h->cfg;
   const int M = B * Tz, C = c.latent_dim, half = C / 2, D = c.prior_attention_dim;
+  if (h->prior_inverse) return prior_inverse_body(h, 1, z_len, t_len, kv, kv_ld, B, Tz, Tt, z, nullptr, logprobs);
   WS(xa, (size_t)M * D); WS(xb, (size_t)M * D); WS(heads, (size_t)M * C); WS(rowld, (size_t)M); WS(zb, (size_t)M * C);
   HIP_TRY(h, hipMemsetAsync(logprobs, 0, (size_t)B * 4, h->stream));
   const float* pe = nullptr;
@@ -1862,6 +1979,7 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
   if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
   HIP_TRY(h, hipSetDevice(h->device));
   if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
+  if (h->prior_inverse) return fail(h, VNR_ERR_ARG, "the training step does not cover inverse = True flows (engine option prior_inverse): inference, the ELBO forward and init do");
   if (!d_ids || !d_text_lengths || !d_mel_targets || !d_mel_lengths || !d_reduced_lengths || !d_eps || B <= 0 || Tt <= 0 || Tm <= 0 || rf < 1)
     return fail(h, VNR_ERR_ARG, "bad argument");
   if (h->cfg.num_mels != h->cfg.output_dim) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");
@@ -2186,6 +2304,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "gemm_wide_tiles")) { h->gemm_wide_tiles = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_rows64")) { h->chain_rows64 = value != 0; return VNR_OK; }
   if (!strcmp(name, "late_dec_kv")) { h->late_dec_kv = value != 0; return VNR_OK; }
+  if (!strcmp(name, "prior_inverse")) { h->prior_inverse = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }

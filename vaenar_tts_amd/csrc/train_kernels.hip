@@ -2604,6 +2604,21 @@ hipError_t launch_actnorm_inv_params(const float* ls, const float* bias, int C, 
   vnr_launch(actnorm_inv_params_kernel, dim3(1), dim3(128), 0, s, ls, bias, C, sc, sh, lssum);
   return hipGetLastError();
 }
+// ActNorm forward parameters: sc = exp(ls);  *lssum = sum(ls)   (inverse = True flows: prior_inverse_body, engine.hip)
+__global__ void actnorm_fwd_params_kernel(const float* ls, int C, float* sc, float* lssum) {
+  __shared__ float red[128];
+  const int c = threadIdx.x;
+  float v = 0.f;
+  if (c < C) { sc[c] = expf(ls[c]); v = ls[c]; }
+  red[c] = v;
+  __syncthreads();
+  if (c == 0) { float t = 0.f; for (int i = 0; i < C; ++i) t += red[i]; *lssum = t; }
+}
+hipError_t launch_actnorm_fwd_params(const float* ls, int C, float* sc, float* lssum, hipStream_t s) {
+  if (C > 128) return hipErrorInvalidValue;
+  vnr_launch(actnorm_fwd_params_kernel, dim3(1), dim3(128), 0, s, ls, C, sc, lssum);
+  return hipGetLastError();
+}
 // y[b] += alpha[0] * len[b]   (alpha on the device)
 __global__ void axpy_len_dev_kernel(float* y, const int32_t* len, const float* alpha, float sign, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -10,9 +10,12 @@ class TransformerPrior(EngineModule):
     def __init__(self, n_blk, channels, n_transformer_blk, attention_dim, attention_heads,
                  temperature, ffn_hidden, inverse=False, name='GlowPrior', engine=None, **kwargs):
         super().__init__(name, engine)
-        if inverse:
-            raise NotImplementedError("inverse=True flows (flow.py:39-44 dispatch call -> _backward) are not built: "
-                                      "LJHPS / DataBakerHPS use inverse=False (hparams.py:344)")
+        # inverse=True (prior.py:88-99: every flow is built with the flag; BaseFlow.call / fwd_pass / bwd_pass, flow.py:36-113, then swap
+        # _forward and _backward): sample / call / init / log_probability, VAENAR.inference and the ELBO forward run that way (engine
+        # option "prior_inverse"); the training step does not cover it.  LJHPS / DataBakerHPS use inverse=False (hparams.py:344,462).
+        self.inverse = bool(inverse)
+        if self.inverse:
+            self.engine.set_option("prior_inverse", 1)
         self.channels = channels
         self.noise_seed = 0          # seed / running offset of the device generator (vnr_random_normal): tf.random.normal's role
         self.noise_offset = 0
@@ -61,8 +64,8 @@ class TransformerPrior(EngineModule):
         return B, Tz, Tt, zl, cond, tl, eps_d
 
     def __call__(self, inputs, targets_lengths, condition_lengths, training=None, temperature=1.0, eps=None):
-        """TransformerPrior.call (prior.py:101-117): ``inputs`` are the condition inputs; with inverse=False every flow runs its
-        forward pass (flow.py:39-44), i.e. the same arithmetic as ``sample`` with the arguments in this order."""
+        """TransformerPrior.call (prior.py:101-117): ``inputs`` are the condition inputs; the same arithmetic as ``sample`` (every flow
+        through BaseFlow.call / fwd_pass, flow.py:36-47,76-91) with the arguments in this order."""
         return self.sample(targets_lengths, inputs, condition_lengths, training=training, temperature=temperature, eps=eps)
 
     call = __call__

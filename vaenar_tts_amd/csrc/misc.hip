@@ -534,7 +534,7 @@ __global__ void col_sum_kernel(const float* x, int M, int C, int ld, const doubl
 // columns of a row, the block's 4 waves take rows m, m+1, m+2, m+3 of a stride-(4 gridDim.y) walk with two loads in flight.
 // yact != null: x is a gradient dy and yact the OUTPUT of an activation (act_bwd_kernel's job folded into this pass: dy *= act'(y) is
 // written back in place before it enters the sums) -- one launch and one pass over dy less per activated Dense / Conv1D layer.
-__global__ void col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act,
+__global__ void __launch_bounds__(256) col_sum4_kernel(float* x, int M, int C, int ld, const double* mean, double* out, unsigned* amax, float* fout, const float* yact, int act,
                                 double* out2, double* det) {      // out2 != null (mean == null): also out2[c] += sum_m x^2 -- both BatchNorm sums in ONE pass
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   const int rg = threadIdx.x >> 6;

@@ -431,7 +431,7 @@ hipError_t launch_axpby2d(const float* x, int ldx, float a, float* y, int ldy, i
 hipError_t launch_add_d2f(float* g, const double* sum, int n, float a, hipStream_t s);
 hipError_t launch_bn_bwd(const float* d, const float* x, const double* mean, const double* sq, const float* gamma, int M, int C,
                          double* s1, double* s2, float* dx, float* dgamma, float* dbeta, hipStream_t s);
-hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s);
+hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s, int V = 0);   // V: rows of the table (deterministic mode's chunked form)
 hipError_t launch_pe_weight_bwd(const float* d, const float* pe, int M, int C, int T, float* out, hipStream_t s);
 hipError_t launch_coupling_inv(const float* heads, float* z, int M, int half, int zp_off, float* zp_in, float* rowld, hipStream_t s);
 hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len, int M,

@@ -2205,8 +2205,32 @@ __global__ void embed_bwd_ordered_kernel(const float* d, const int32_t* ids, int
   if (c >= C) return;
   for (int m = 0; m < M; ++m) dE[(size_t)ids[m] * C + c] += d[(size_t)m * C + c];
 }
-hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s) {
+// the same order in two levels (round 4: the one-level walk above took 1 ms at the tail of every deterministic step): workgroup (column
+// block, row chunk) accumulates its rows in row order into a [V][64] table in LDS and leaves it as partial `chunk`; the chunks are then
+// added in chunk order by det_finish_kernel.  Fixed shape = the same bits every run.
+__global__ void __launch_bounds__(64) embed_bwd_chunk_kernel(const float* d, const int32_t* ids, int M, int C, int V, int rows_per_chunk, float* part) {
+  extern __shared__ float etab[];                          // [V][64]
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  for (int v = 0; v < V; ++v) etab[v * 64 + threadIdx.x] = 0.f;
+  const int m0 = blockIdx.y * rows_per_chunk, m1 = min(M, m0 + rows_per_chunk);
+  if (c < C)
+    for (int m = m0; m < m1; ++m) {
+      const int v = ids[m];                                // (wave-uniform)
+      if (v >= 0 && v < V) etab[v * 64 + threadIdx.x] += d[(size_t)m * C + c];
+    }
+  if (c < C)
+    for (int v = 0; v < V; ++v) part[((size_t)blockIdx.y * V + v) * C + c] = etab[v * 64 + threadIdx.x];
+}
+hipError_t launch_embed_bwd(const float* d, const int32_t* ids, int M, int C, float* dE, hipStream_t s, int V) {
   if (g_det) {
+    const int rpc = 64, nchunk = (M + rpc - 1) / rpc;
+    if (V > 0 && (size_t)V * 64 * sizeof(float) <= 64 * 1024 && nchunk > 1) {
+      float* part = static_cast<float*>(det_scratch(s, (size_t)nchunk * V * C * sizeof(float)));
+      if (part) {
+        vnr_launch(embed_bwd_chunk_kernel, dim3((C + 63) / 64, nchunk), dim3(64), (unsigned)((size_t)V * 64 * sizeof(float)), s, d, ids, M, C, V, rpc, part);
+        return launch_det_finish_ff(part, nchunk, (size_t)V * C, dE, s);
+      }
+    }
     vnr_launch(embed_bwd_ordered_kernel, dim3((C + 63) / 64), dim3(64), 0, s, d, ids, M, C, dE);
     return hipGetLastError();
   }
@@ -2807,27 +2831,43 @@ hipError_t launch_split_batch(const void* jobs_device, int njobs, float scale, h
 
 
 // ---- deterministic accumulation: ordered sums of per-workgroup partials (common.h: DetState) ---------------------------------------
+// Two levels of a FIXED shape: 16 outputs x 16 part groups per workgroup; a thread adds its group's parts [g c, (g + 1) c), c = ceil(nparts / 16),
+// in part order, thread 0 of an output adds the 16 group sums in group order.  The shape depends on nparts only, so the result is the same
+// bits on every run -- and a column-sum finish over 100 ... 400 parts is no longer ONE workgroup walking them one after another (round 4:
+// 27 - 56 us per launch, 116 launches per deterministic step; now a few us).
 template <typename P, typename O>
-__global__ void det_finish_kernel(const P* __restrict__ part, int nparts, size_t n, O* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  P acc = part[i];
-  for (int p = 1; p < nparts; ++p) acc += part[(size_t)p * n + i];
-  out[i] += (O)acc;
+__global__ void __launch_bounds__(256) det_finish_kernel(const P* __restrict__ part, int nparts, size_t n, O* __restrict__ out) {
+  __shared__ P red[16][17];
+  const int ox = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + ox;
+  const int chunk = (nparts + 15) >> 4;
+  P acc = (P)0;
+  if (i < n) {
+    const int p0 = g * chunk, p1 = min(nparts, p0 + chunk);
+    for (int p = p0; p < p1; ++p) acc += part[(size_t)p * n + i];
+  }
+  red[g][ox] = acc;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    P t = red[0][ox];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][ox];
+    out[i] += (O)t;
+  }
 }
 hipError_t launch_det_finish_dd(const double* part, int nparts, size_t n, double* out, hipStream_t s) {
   if (!n || nparts <= 0) return hipSuccess;
-  vnr_launch(det_finish_kernel<double, double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  vnr_launch(det_finish_kernel<double, double>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, nparts, n, out);
   return hipGetLastError();
 }
 hipError_t launch_det_finish_df(const double* part, int nparts, size_t n, float* out, hipStream_t s) {
   if (!n || nparts <= 0) return hipSuccess;
-  vnr_launch(det_finish_kernel<double, float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  vnr_launch(det_finish_kernel<double, float>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, nparts, n, out);
   return hipGetLastError();
 }
 hipError_t launch_det_finish_ff(const float* part, int nparts, size_t n, float* out, hipStream_t s) {
   if (!n || nparts <= 0) return hipSuccess;
-  vnr_launch(det_finish_kernel<float, float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, nparts, n, out);
+  vnr_launch(det_finish_kernel<float, float>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, part, nparts, n, out);
   return hipGetLastError();
 }
 // kernel-gradient GEMMs: C[k][n] += sum over the row splits, in split order (16-byte accesses when N and ldc allow)

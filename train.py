@@ -74,7 +74,7 @@ def main():
     ap.add_argument('--seed', type=int, default=None)
     ap.add_argument('--deterministic', type=int, default=1,
                     help="1 (default, like the reference's TF_DETERMINISTIC_OPS=1 + pinned seeds, train.py:17-32): every gradient is "
-                         "accumulated in a fixed order, two runs with the same seed give the same bits; 0: float atomics (about 20 %% faster)")
+                         "accumulated in a fixed order, two runs with the same seed give the same bits; 0: float atomics (about 10 %% faster)")
     args = ap.parse_args()
     hps = {'ljspeech': LJHPS, 'databaker': DataBakerHPS, 'tiny': tiny_hps()}[args.dataset]
     rank, local_rank, world = vdist.init()

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.vaenar_numpy import Oracle  # noqa: E402
-from vaenar_tts_amd.configs import LJHPS, tiny_hps  # noqa: E402
+from vaenar_tts_amd.configs import DataBakerHPS, LJHPS, tiny_hps  # noqa: E402
 from vaenar_tts_amd.synthetic import make_batch  # noqa: E402
 from vaenar_tts_amd.weights import init_weights  # noqa: E402
 
@@ -63,6 +63,8 @@ def build(name):
 REF_CASES = {
     "refshim_tiny": (tiny_hps, dict(B=3, T_text=11, T_mel=40, ragged=True, temperature=1.0, text_step=3, mel_step=7), 7),
     "refshim_lj": (lambda: LJHPS, dict(B=2, T_text=19, T_mel=50, ragged=True, temperature=1.0, text_step=6, mel_step=13), 11),
+    # BASELINE config 5's model: the reference's DataBakerHPS (hparams.py:351-474: vocabulary 39, mel / text length ratio 4.21)
+    "refshim_databaker": (lambda: DataBakerHPS, dict(B=2, T_text=17, T_mel=46, ragged=True, temperature=1.0, text_step=5, mel_step=11), 13),
 }
 
 

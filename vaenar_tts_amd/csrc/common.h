@@ -294,10 +294,13 @@ struct ChainArgs {
   int cpl_lds;                                 // (set by launch_panel_chain) byte offset of the shift exchange scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
+  int vt_lds;                   // (set by launch_panel_chain, waves4 only) byte offset of the V-stage transpose scratch [4 waves][32][33] fp32 in LDS
+  int waves4;                   // 1: the one-wave-per-SIMD kernel (gemm3c.hip: 4 waves x 64 columns, 8 k-tiles in flight; 32-row panels only), 0: panel_chain_kernel
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage
   ChainStage st[kMaxChainStages];
 };
 hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);
+hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s);      // gemm3c.hip; called by launch_panel_chain (which validates the program and lays out the LDS)
 
 hipError_t launch_gemm(const GemmArgs& g, hipStream_t s);
 bool gemm2_supported(const GemmArgs& g);          // LDS-DMA ring kernel (gemm2.hip) can take it

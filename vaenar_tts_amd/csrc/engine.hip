@@ -135,6 +135,7 @@ struct vnr_context {
   int train_chain_bwd = 1;           // engine option "train_chain_bwd": the backward of the same blocks as two backward-chain launches (gemm3b.hip)
   int train_chain = 1;               // engine option "train_chain" (train.inc: xblk_chain): 0 off, 1 auto, 2 / 3 force 64- / 32-row panels
   bool attn_bwd_recompute = false;   // engine option "attn_bwd_recompute" (train.inc: attn)
+  bool chain_waves4 = false;     // engine option "chain_waves4": 32-row chain launches on the one-wave-per-SIMD kernel (gemm3c.hip); 0 = the 8-wave kernel of rounds 1-4
   bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
   bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
@@ -305,6 +306,7 @@ int chain_params(vnr_handle h, ChainArgs& g) {
 int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   TRY(chain_params(h, g));
   g.rows64 = h->chain_rows64 ? 1 : 0;
+  g.waves4 = (h->chain_waves4 && !h->chain_rows64) ? 1 : 0;
   // bytes of a launch that also writes alignments: the attention core's own traffic as SURVEY D3 counts it (Q + K, V + context +
   // alignments) -- Q and the context never reach HBM here, the figure is what a stand-alone core would move
   const double ali_bytes = (g.att_stage > 0 && g.att_ali)
@@ -1437,7 +1439,8 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
   vnr_handle h = new vnr_context();
   h->cfg = *cfg;
   h->device = device;
-  if (const char* e = getenv("VNR_CHAIN_ROWS64")) h->chain_rows64 = atoi(e) != 0;      // test / measurement override of the option's default
+  if (const char* e = getenv("VNR_CHAIN_ROWS64")) h->chain_rows64 = atoi(e) != 0;
+  if (const char* e = getenv("VNR_CHAIN_WAVES4")) h->chain_waves4 = atoi(e) != 0;      // test / measurement override of the option's default
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return fail(nullptr, VNR_ERR_HIP, "hipSetDevice / hipStreamCreate failed");
@@ -2307,6 +2310,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "prior_inverse")) { h->prior_inverse = value != 0; return VNR_OK; }
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
+  if (!strcmp(name, "chain_waves4")) { h->chain_waves4 = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain_bwd")) { h->train_chain_bwd = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain")) { if (value < 0 || value > 3) return fail(h, VNR_ERR_ARG, "train_chain: 0..3"); h->train_chain = value; return VNR_OK; }

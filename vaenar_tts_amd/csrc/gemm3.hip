@@ -868,7 +868,21 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     if (g.att_stage > 0 && g.cpl_stage > g.att_stage && need <= (g.D >> 6) * 32 * 66 * 4) g.cpl_lds = g.att_lds;
     else { g.cpl_lds = (lds + 15) & ~15; lds = g.cpl_lds + need; }
   }
+  if (g.waves4) {                                       // gemm3c.hip turns the V-type stages of a Q|K|V tail through LDS: wave-private 32 x 33 floats
+    bool anyv = false;
+    for (int i = 0; i < g.nstages; ++i) {
+      const ChainStage& st = g.st[i];
+      anyv = anyv || (st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) && st.acc_mode == 0 &&
+                      st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY);
+    }
+    g.vt_lds = 0;
+    if (anyv) {
+      if (g.att_stage > 0) g.vt_lds = g.att_lds;          // (the attention phase is over by then; its scratch is twice the size)
+      else { g.vt_lds = (lds + 15) & ~15; lds = g.vt_lds + 4 * 32 * 33 * 4; }
+    }
+  }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (g.waves4) return launch_chain4(g, lds, s);
   return launch_chain_rt<1>(g, lds, s);
 }
 

@@ -1,0 +1,722 @@
+// Row-panel chain kernel, second generation (round 5): ONE wave per SIMD.  Same programs, same stage descriptors, same LDS panels
+// and the same arithmetic as panel_chain_kernel<1> (gemm3.hip) -- the per-row dense chains of a CrossAttentionBLK
+// (modules/attention.py:440-452), its FFN (modules/utils.py:48-53), the fused cross-attention (attention.py:224-246), the flow
+// coupling (modules/flow.py:216-239) and the pre-chains behind it -- but a workgroup is 4 waves of 64 output columns instead of
+// 8 waves of 32:
+//   * a wave owns a SIMD and its whole 512-entry register file: EIGHT k-tiles of weight operands (a complete K = 256 stage,
+//     64 one-KiB loads) are in flight per wave instead of four half-sized ones, so the next stage's weights stream in THROUGH the
+//     epilogue / LayerNorm / attention phases of the current one;
+//   * the A operands (activations from the LDS panel) are read once per k-tile for both column tiles of the wave: half the LDS reads;
+//   * consecutive MFMAs go to alternating accumulators with the refill loads between them: the k-loop free-runs at the
+//     vector-memory path's 512 clk per k-tile round (tools/probes/chain_b_probe.hip, profiles/r05_chain_b_probe.txt: a stage of
+//     8 rounds + a short epilogue 5.7 kcyc against 7.1 for the 8-wave layout, whose younger wave of every SIMD pair finishes each
+//     k-loop ~2 kcyc after the older one);
+//   * the fused cross-attention needs no merge: a wave IS a head and walks all key blocks itself (no LDS exchange, no barrier
+//     inside the phase).
+// Selected by ChainArgs::waves4 (engine option "chain_waves4", default on; 32-row panels only).
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace vnr {
+
+namespace {
+constexpr unsigned kOob3 = 0x80000000u;
+typedef __attribute__((address_space(3))) void* lds3_t;
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+// LDS map (identical to ChainLds<1> of gemm3.hip, so launch_panel_chain's size arithmetic serves both kernels):
+//   [0, 2048)              LayerNorm exchange scratch [2][32][4] fp32 (half used)
+//   [2048, + 3 x 32 KiB)   the activation panels: 32 rows x 8 k-tiles x 128 B
+//   then                   bias of every stage [nstages][256] fp32, then (gamma | beta) [256 + 256] fp32 of every LayerNorm stage
+constexpr int kRows = 32, kPanelBytes = 32768, kPOff = 2048, kPrmOff = kPOff + 3 * kPanelBytes;
+constexpr int kNW = 4;              // waves per workgroup
+constexpr int kDepth = 8;           // weight k-tiles in flight per wave = one trip of the k-loop
+
+__device__ __forceinline__ void lds_barrier4() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int panel_off4(int r, int kt, int c) { return r * 1024 + ((((kt << 3) + c) ^ (r & 15)) << 4); }
+// split-fp16 store of 4 consecutive columns [p, p + 4) (p % 4 == 0) of k-tile kt, row r
+__device__ __forceinline__ void panel_put4(char* P, int r, int kt, int p, const float* x) {
+  h16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+  *reinterpret_cast<h16x4*>(P + panel_off4(r, kt, p >> 3) + (p & 4) * 2) = hi;
+  *reinterpret_cast<h16x4*>(P + panel_off4(r, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256)
+panel_chain4_kernel(const ChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * kRows;
+  auto panel_ptr = [&](int i) -> char* { return smem + kPOff + i * kPanelBytes; };
+  float* scratch = reinterpret_cast<float*>(smem);
+  float* prm = reinterpret_cast<float*>(smem + kPrmOff);
+  unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 128 : nullptr;
+  auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
+  auto wstamp = [&](int si, int i) { if (ts && si == g.dbg_stage && lane == 0) ts[64 + wave * 8 + i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // ---- the weight stream --------------------------------------------------------------------------------------------
+  // Operand-major images as in gemm3.hip: block (32-column block, k-tile) = 4 x 1 KiB pieces (piece 2t + part: k16 step t, hi / lo);
+  // a wave owns column blocks 2 wave and 2 wave + 1.  The k-tiles of all stages form one flat sequence of TRIPS of 8 k-tiles
+  // (a stage is padded to whole trips; padding tiles, tiles of column blocks a stage does not have, and the tail after the last
+  // stage are out-of-range buffer reads: zeros, no traffic).  Slot u of the register ring always holds k-tile u of the trip being
+  // multiplied; each of its 8 pieces is re-requested for the NEXT trip right behind the last MFMA that read it -- the fetch cursor
+  // (fs, fk) therefore runs exactly one trip ahead of the multiplier, across stage boundaries, and every wait is a static vmcnt.
+  h16x8 wreg[kDepth][2][4];
+  int fs = 0, fk = 0, fnk = 0, fpad = 0;
+  unsigned fvoff0 = kOob3, fvoff1 = kOob3;
+  __amdgpu_buffer_rsrc_t frs;
+  auto open_stage = [&](int s_) {
+    const ChainStage& st = g.st[s_];
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(st.w), 0, 0x40000000, 0x00020000);
+    fnk = st.nk;
+    fpad = (st.nk + kDepth - 1) / kDepth * kDepth;
+    fvoff0 = (64 * wave < st.n) ? (unsigned)(((2 * wave) * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
+    fvoff1 = (64 * wave + 32 < st.n) ? (unsigned)(((2 * wave + 1) * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
+  };
+  auto piece = [&](int u, int j, int i) {
+    const int kt = fk + u;
+    const unsigned vo = (kt < fnk) ? (j ? fvoff1 : fvoff0) : kOob3;
+    // (measurement only, VNR_CHAIN_PRIO=9: every weight read goes to the stage's first k-tile -- L1-resident, wrong results)
+    wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, (g.prio_mode == 9 ? 0 : kt * 4096) + i * 1024, 0));
+  };
+  auto advance = [&]() {
+    fk += kDepth;
+    if (fk >= fpad) {
+      fk = 0;
+      if (fs + 1 < g.nstages) { ++fs; open_stage(fs); } else { fnk = 0; }
+    }
+  };
+  open_stage(0);
+#pragma unroll
+  for (int u = 0; u < kDepth; ++u)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) piece(u, j, i);
+  advance();
+
+  // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (stage s by wave s mod 4) ----------------------------------
+  if (g.prm) {
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
+    for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(s_ * 3072 + lane * 16), 0, 0, 0);
+      const int lo = g.st[s_].lds_ln;
+      if (lo >= 0) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(s_ * 3072 + 1024 + lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(s_ * 3072 + 2048 + lane * 16), 0, 0, 0);
+      }
+    }
+  } else {
+    for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
+      const float* bp = g.st[s_].bias; const float* gp = g.st[s_].gamma; const float* ep = g.st[s_].beta;
+      const unsigned nb = (unsigned)g.st[s_].n * 4u;
+      const bool skip = g.st[s_].acc_mode == 1 || g.st[s_].acc_mode == 2;
+      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp ? bp : g.in0), 0, (bp && !skip) ? nb : 0u, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+      const int lo = g.st[s_].lds_ln;
+      if (lo >= 0) {
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0, nb, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep ? ep : gp), 0, ep ? nb : 0u, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(lane * 16), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+      }
+    }
+  }
+  // ---- input panels (fp32 rows in HBM -> split fp16 panel): all reads issued first, rows beyond M read as zeros --------
+  {
+    const int q4 = g.D >> 2;                                       // float4 per row (<= 64)
+    float4 x[2][8];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      const float* src = pi == 0 ? g.in0 : g.in1;
+      const int ld = pi == 0 ? g.ld0 : g.ld1;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = tid + 256 * it, r = e / q4, j = e - r * q4;
+        x[pi][it] = (src && r < kRows && m0 + r < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + 4 * j)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      if (!(pi == 0 ? g.in0 : g.in1)) continue;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = tid + 256 * it, r = e / q4, j = e - r * q4;
+        if (r >= kRows) continue;
+        const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
+        panel_put4(panel_ptr(pi), r, j >> 3, (j & 7) * 4, xv);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // parameter DMA landed (the first trip of weights too: issued first)
+  lds_barrier4();
+  stamp(1);
+
+  f32x16 accF[2];                                       // persistent accumulators of the FFN second layer
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accF[j][r] = 0.f;
+
+#pragma unroll 1
+  for (int si = 0; si < g.nstages; ++si) {
+    // every lane-dependent address of a stage is re-derived from an opaque copy of the lane id (gemm3.hip: otherwise the compiler
+    // hoists dozens of loop-invariant offsets out of the stage loop and spills them)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    const int half = lane_s >> 5, l31 = lane_s & 31;
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
+    if (g.att_stage > 0 && si == g.att_stage) {
+      // ================= fused cross-attention of this panel (ChainArgs::att_stage) ========================================
+      // wave = head (D = 256: four heads).  Per 32-key block, as attn3_kernel: S^T = K.Q^T (lane = query row: softmax statistics
+      // in-lane + one half swap), logits in the log2 domain, online softmax over the blocks, O^T += V^T.P^T.  The context replaces
+      // this head's queries in panel 1 (tiles 2 head, 2 head + 1: nobody else reads them) -- or goes to panel 2 when the
+      // alignments are wanted, whose pass multiplies K and Q once more.  A flat 32-row panel can straddle two batch elements:
+      // then the computation runs once per element and every lane keeps the pass of its own row.
+      const int head = wave;
+      const int H = g.D >> 6, TTk = (g.att_Tk + 31) >> 5;
+      const int row = m0 + l31;
+      int b_lo = m0 / g.att_Tq, b_hi = (m0 + 31 < g.M ? m0 + 31 : g.M - 1) / g.att_Tq;
+      b_lo = __builtin_amdgcn_readfirstlane(b_lo); b_hi = __builtin_amdgcn_readfirstlane(b_hi);
+      char* P1 = panel_ptr(1);
+      char* Pc = panel_ptr(g.att_ali ? 2 : 1);
+      float* xs = reinterpret_cast<float*>(smem + g.att_lds);        // transpose scratch of the alignment pass: [4 waves][32][33] floats
+      const float c2 = (g.att_temp != 1.0f) ? 0.125f * 1.44269504088896340736f / g.att_temp : 0.125f * 1.44269504088896340736f;
+      for (int bb = b_lo; bb <= b_hi; ++bb) {
+        const int qlen = g.att_qlen ? g.att_qlen[bb] : g.att_Tq, klen = g.att_klen ? g.att_klen[bb] : g.att_Tk;
+        const int tq = row - bb * g.att_Tq;
+        const bool mine = row < g.M && tq >= 0 && tq < g.att_Tq;
+        const bool qvalid = mine && tq < qlen;
+        f32x16 O[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < TTk; ++kb) {
+          const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
+          const char* vt = g.att_V + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
+          h16x8 khi[4], klo[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { khi[t] = *reinterpret_cast<const h16x8*>(kt + 1024 * t); klo[t] = *reinterpret_cast<const h16x8*>(kt + 4096 + 1024 * t); }
+          f32x16 sacc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const h16x8 qh = *reinterpret_cast<const h16x8*>(P1 + panel_off4(l31, 2 * head + (t >> 1), 2 * (t & 1) + half));
+            const h16x8 ql = *reinterpret_cast<const h16x8*>(P1 + panel_off4(l31, 2 * head + (t >> 1), 4 + 2 * (t & 1) + half));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[t], qh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo[t], qh, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi[t], ql, sacc, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);               // (the K registers are dead: V lands in them)
+          h16x8 vhi[2][2], vlo[2][2];
+#pragma unroll
+          for (int y = 0; y < 4; ++y) { vhi[y >> 1][y & 1] = *reinterpret_cast<const h16x8*>(vt + 1024 * y); vlo[y >> 1][y & 1] = *reinterpret_cast<const h16x8*>(vt + 4096 + 1024 * y); }
+          const int kb0 = 32 * kb;
+          float mt = -INFINITY;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = kb0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float sv = sacc[r] * c2;
+            sv = (qvalid && j < klen) ? sv : kMaskFill * 1.44269504088896340736f;     // attention.py:240
+            if (j >= g.att_Tk) sv = -INFINITY;                                             // key does not exist
+            sacc[r] = sv;
+            mt = fmaxf(mt, sv);
+          }
+          mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+          const float m_new = fmaxf(fmaxf(m_run, mt), -3.0e38f);
+          const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                      // 0 on the first block
+          float ps = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float pr = __builtin_amdgcn_exp2f(sacc[r] - m_new); sacc[r] = pr; ps += pr; }
+          ps += __shfl_xor(ps, 32, 64);
+          l_run = l_run * alpha + ps;
+          if (kb > 0) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) O[nb][r] *= alpha;
+          }
+          m_run = m_new;
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            if (kb0 + 32 > g.att_Tk) {                                 // positions past Tk hold whatever the workspace held
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int key = kb0 + 16 * tp + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (key >= g.att_Tk) { vhi[tp][0][e] = vhi[tp][1][e] = vlo[tp][0][e] = vlo[tp][1][e] = (_Float16)0.f; }
+              }
+            }
+            h16x8 phi, plo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)sacc[8 * tp + e]; phi[e] = hh; plo[e] = (_Float16)(sacc[8 * tp + e] - (float)hh); }
+            O[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][0], phi, O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][1], phi, O[1], 0, 0, 0);
+            O[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[tp][0], phi, O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[tp][1], phi, O[1], 0, 0, 0);
+            O[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][0], plo, O[0], 0, 0, 0);
+            O[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][1], plo, O[1], 0, 0, 0);
+          }
+        }
+        const float M_fin = fmaxf(m_run, -3.0e38f);
+        const float linv = 1.0f / l_run;                                                   // softmax denominator, attention.py:242
+        // the context: O^T layout -- lane = query l31, register r of block nb = channel 32 nb + (r & 3) + 8 (r >> 2) + 4 half
+        if (mine) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float xv[4] = {O[nb][4 * q] * linv, O[nb][4 * q + 1] * linv, O[nb][4 * q + 2] * linv, O[nb][4 * q + 3] * linv};
+              panel_put4(Pc, l31, 2 * head + nb, 8 * q + 4 * half, xv);
+            }
+        }
+        if (g.att_ali) {                                               // (workgroup-uniform)
+          // alignments = softmax(logits) of this head's rows (attention.py:242-246): S^T of every block once more (K tile from L1 / L2,
+          // Q still in panel 1), normalised with the final (max, 1 / sum), written as 128-byte row pieces after a wave-private
+          // 32 x 32 transpose through LDS (lane-per-query registers would leave 32-byte pieces: a tenth of the store rate)
+          float* tb = xs + wave * (32 * 33);
+#pragma unroll 1
+          for (int kb = 0; kb < TTk; ++kb) {
+            const char* kt = g.att_K + ((size_t)(bb * H + head) * TTk + kb) * kAoiTile + lane_s * 16;
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const h16x8 kh = *reinterpret_cast<const h16x8*>(kt + 1024 * t), kl = *reinterpret_cast<const h16x8*>(kt + 4096 + 1024 * t);
+              const h16x8 qh = *reinterpret_cast<const h16x8*>(P1 + panel_off4(l31, 2 * head + (t >> 1), 2 * (t & 1) + half));
+              const h16x8 ql = *reinterpret_cast<const h16x8*>(P1 + panel_off4(l31, 2 * head + (t >> 1), 4 + 2 * (t & 1) + half));
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, sacc, 0, 0, 0);
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, sacc, 0, 0, 0);
+              sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, sacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int j = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float sv = sacc[r] * c2;
+              sv = (qvalid && j < klen) ? sv : kMaskFill * 1.44269504088896340736f;         // attention.py:240
+              if (j >= g.att_Tk) sv = -INFINITY;
+              tb[l31 * 33 + (r & 3) + 8 * (r >> 2) + 4 * half] = __builtin_amdgcn_exp2f(sv - M_fin) * linv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int rr = 8 * it + (lane_s >> 3), k4 = (lane_s & 7) * 4;
+              const float4 pv = make_float4(tb[rr * 33 + k4], tb[rr * 33 + k4 + 1], tb[rr * 33 + k4 + 2], tb[rr * 33 + k4 + 3]);
+              const int rg = m0 + rr, tqr = rg - bb * g.att_Tq, key0 = 32 * kb + k4;
+              if (rg < g.M && tqr >= 0 && tqr < g.att_Tq && key0 < g.att_Tk)
+                *reinterpret_cast<float4*>(g.att_ali + (((size_t)(bb * H + head) * g.att_Tq + tqr) * g.att_Tk + key0)) = pv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+        }
+      }
+      lds_barrier4();                                                  // the context panel is complete for every wave
+    }
+    const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
+    const bool wave_on = 64 * wave < st.n;               // this wave owns output columns 64w .. 64w+63 (column blocks 2w, 2w+1)
+    const char* const Ap0 = panel_ptr(st.a0);
+    const char* const Ap1 = panel_ptr(st.a1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // a stage that holds only V columns of a Q|K|V panel: its V-image units are 8 consecutive KEYS of one channel (common.h), i.e. the
+    // transpose of what a lane holds; the 8-wave kernel multiplies such a stage with its operands swapped, here (one k-loop instance)
+    // the epilogue turns each 32 x 32 block through LDS and stores the same coalesced 1 KiB pieces
+    const bool vstage = st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) &&
+                       st.acc_mode == 0 && st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY;
+    wstamp(si, 0);
+    const int npad = (st.nk + kDepth - 1) / kDepth * kDepth;
+    h16x8 afr[2][4];                                     // activation operands, ONE k-tile ahead: [set][2 t + (hi | lo)]
+    auto read_a = [&](int kt, int set) {
+      const int kc = kt < st.nk ? kt : st.nk - 1;
+      const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
+      const int akt = (kc < st.asw) ? kc + st.akt0 : kc - st.asw;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        afr[set][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off4(l31, akt, 2 * t + half));
+        afr[set][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off4(l31, akt, 4 + 2 * t + half));
+      }
+    };
+    // One trip = 8 slots, ONE instance of the loop (a second instantiation -- an idle-wave form, the operand-swapped form of the
+    // 8-wave kernel's V stages, a short form for K <= 128 -- makes every wreg element a phi of the variants and the kernel spills
+    // ~150 registers): waves without columns and padding k-tiles multiply the zeros their out-of-range refills returned.
+    // Consecutive MFMAs alternate between the two accumulators; the refill of a piece follows the last MFMA that read it.
+    read_a(0, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < npad; kb += kDepth) {
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        read_a(kb + u + 1, (u + 1) & 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const h16x8 ah = afr[u & 1][2 * t], al = afr[u & 1][2 * t + 1];
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], ah, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], ah, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], al, acc[0], 0, 0, 0);
+          piece(u, 0, 2 * t);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], al, acc[1], 0, 0, 0);
+          piece(u, 1, 2 * t);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t + 1], ah, acc[0], 0, 0, 0);
+          piece(u, 0, 2 * t + 1);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t + 1], ah, acc[1], 0, 0, 0);
+          piece(u, 1, 2 * t + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      advance();
+    }
+    stamp(2 + 2 * si);
+    wstamp(si, 1);
+    // ---- FFN second layer: accumulate over hidden chunks (modes 1, 2: no epilogue yet) ---------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (st.acc_mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accF[j][r] = acc[j][r];
+      } else if (st.acc_mode >= 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accF[j][r] += acc[j][r];
+      }
+    }
+    if (st.acc_mode == 1 || st.acc_mode == 2) { if (st.sync_after) lds_barrier4(); stamp(3 + 2 * si); continue; }
+    // ---- fast path: a full-width hidden stage h = relu(x.W + b) -> other panel (FFN dense1 chunks, utils.py:49) ---------------
+    if (st.acc_mode == 0 && st.act == ACT_RELU && st.n == 256 && !st.pe && st.res < 0 && !st.gamma && !st.out && st.dst >= 0 &&
+        st.dst != st.a0 && !(st.asw < st.nk && st.dst == st.a1)) {
+      const float* sp = prm + si * 256;
+      char* Dp = panel_ptr(st.dst);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kt = 2 * wave + j;                                    // this column block = k-tile kt of the destination
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bi = *reinterpret_cast<const float4*>(sp + 32 * kt + 8 * q + 4 * half);
+          const float x[4] = {fmaxf(acc[j][4 * q] * st.scale + bi.x, 0.f), fmaxf(acc[j][4 * q + 1] * st.scale + bi.y, 0.f),
+                              fmaxf(acc[j][4 * q + 2] * st.scale + bi.z, 0.f), fmaxf(acc[j][4 * q + 3] * st.scale + bi.w, 0.f)};
+          panel_put4(Dp, l31, kt, 8 * q + 4 * half, x);
+        }
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
+    if (vstage) {
+      if (wave_on) {
+        const int Hh = st.aoi_D >> 6, TT = (st.aoi_T + 31) >> 5;
+        float* tb = reinterpret_cast<float*>(smem + g.vt_lds) + wave * (32 * 33);      // wave-private [32 channels][33]
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int cb = 32 * (2 * wave + j);
+          if (cb >= st.n) continue;                                     // (wave-uniform)
+          const float* bp = prm + si * 256 + cb;                        // (zero padded when the stage has no bias)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 bi = *reinterpret_cast<const float4*>(bp + 8 * q + 4 * half);
+            const float bq[4] = {bi.x, bi.y, bi.z, bi.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tb[(8 * q + 4 * half + e) * 33 + l31] = acc[j][4 * q + e] * st.scale + bq[e];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int cv = st.aoi_c0 - 2 * st.aoi_D + cb + l31;           // V column of this lane: head cv >> 6, channel cv & 63
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = tb[l31 * 33 + 16 * tp + (e & 3) + 4 * half + 8 * (e >> 2)];   // k-slot (tp, g = half, e) -> row of the panel
+            const int R = m0 + 16 * tp;
+            if (R >= g.M) continue;
+            const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
+            h16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)x[e]; hi[e] = hh; lo[e] = (_Float16)(x[e] - (float)hh); }
+            char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
+                         ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
+            *reinterpret_cast<h16x8*>(pdst) = hi;
+            *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the block is read before the next one overwrites it
+        }
+      }
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
+    if (st.acc_mode == 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = accF[j][r];
+    }
+
+    // ---- epilogue: v = act(acc*scale + bias) (+ residual panel) ; optional LayerNorm over the row ------------------------
+    // lane (row l31, half) holds columns n = 32 (2 wave + j) + 8q + 4 half + e  (register 4q + e of block j)
+    float v[2][16];
+    const float* sp = prm + si * 256;
+    bool cok[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = 32 * (2 * wave + j) + 8 * q + 4 * half;
+        cok[j][q] = col < st.n;                                         // (n is a multiple of 4)
+        const float4 bi = *reinterpret_cast<const float4*>(sp + col);
+        v[j][4 * q + 0] = acc[j][4 * q + 0] * st.scale + bi.x;
+        v[j][4 * q + 1] = acc[j][4 * q + 1] * st.scale + bi.y;
+        v[j][4 * q + 2] = acc[j][4 * q + 2] * st.scale + bi.z;
+        v[j][4 * q + 3] = acc[j][4 * q + 3] * st.scale + bi.w;
+      }
+    if (st.act == ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[j][r] = fmaxf(v[j][r], 0.f);
+    } else if (st.act == ACT_TANH) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[j][r] = fast_tanhf(v[j][r]);
+    }
+    wstamp(si, 4);
+    if (g.cpl_stage > 0 && si == g.cpl_stage) {
+      // ================= fused affine coupling (ChainArgs::cpl_stage; arithmetic of misc.hip: coupling_fwd_kernel) ==============
+      // v = [log_scale (hc columns) | shift (hc columns)], hc = 64: waves 0 and 1 park it in LDS ([32][2 hc + 4] floats); behind the
+      // barrier all 256 threads share the elementwise work (thread -> row tid >> 4 of a 16-row half, 4-column piece tid & 15).
+      const int cst = st.n + 4;
+      float* cx = reinterpret_cast<float*>(smem + g.cpl_lds);
+      if (wave_on) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cok[j][q])
+              *reinterpret_cast<float4*>(cx + l31 * cst + 32 * (2 * wave + j) + 8 * q + 4 * half) =
+                  make_float4(v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]);
+      }
+      lds_barrier4();
+      {
+        char* Dp = panel_ptr(st.dst);
+        const int c = (tid_s & 15) * 4;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int prow = 16 * rr + (tid_s >> 4), row = m0 + prow;
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            const int zoff = which ? g.cpl_cond_off : g.cpl_zp_off;
+            float* zp = g.cpl_z + (size_t)row * g.cpl_ld + zoff + c;
+            const float4 zo = row < g.M ? *reinterpret_cast<const float4*>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float o[4] = {zo.x, zo.y, zo.z, zo.w};
+            if (which == 0) {
+              const float4 ls = *reinterpret_cast<const float4*>(cx + prow * cst + c), sh = *reinterpret_cast<const float4*>(cx + prow * cst + 64 + c);
+              const float lv[4] = {ls.x, ls.y, ls.z, ls.w}, sv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float scale = 1.0f / (1.0f + expf(-(lv[e] + 2.0f)));                    // tf.math.sigmoid(log_scale + 2), flow.py:231
+                o[e] = scale * o[e] + sv[e];                                                  // _affine, flow.py:216
+              }
+              if (row < g.M) out_store4(zp, o[0], o[1], o[2], o[3]);
+            }
+            panel_put4(Dp, prow, (zoff + c) >> 5, (zoff + c) & 31, o);
+          }
+        }
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
+    {
+      const int row = m0 + l31;
+      if (st.pe) {                                                      // + pos_weight * PE[t] (encoder.py:85, transform.py:51)
+        const float* pr = st.pe + (size_t)(row % st.pe_T) * st.n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = 32 * (2 * wave + j) + 8 * q + 4 * half;
+            if (cok[j][q] && row < g.M) {
+              const float4 p4 = *reinterpret_cast<const float4*>(pr + col);
+              v[j][4 * q] += st.pe_w * p4.x; v[j][4 * q + 1] += st.pe_w * p4.y; v[j][4 * q + 2] += st.pe_w * p4.z; v[j][4 * q + 3] += st.pe_w * p4.w;
+            }
+          }
+      }
+      if (st.res >= 0) {                                                // residual = hi + lo of the panel entry (22 bits)
+        const char* Rp = panel_ptr(st.res);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kt = 2 * wave + j, p = 8 * q + 4 * half;
+            const h16x4 rh = *reinterpret_cast<const h16x4*>(Rp + panel_off4(l31, kt, p >> 3) + (p & 4) * 2);
+            const h16x4 rl = *reinterpret_cast<const h16x4*>(Rp + panel_off4(l31, kt, 4 + (p >> 3)) + (p & 4) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][4 * q + e] += (float)rh[e] + (float)rl[e];
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (!cok[j][q]) v[j][4 * q] = v[j][4 * q + 1] = v[j][4 * q + 2] = v[j][4 * q + 3] = 0.f;
+    }
+    if (st.gamma && st.out_pre) {                                       // training: x + Dense(.) before the normalisation
+      const int row = m0 + l31;
+      if (row < g.M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (cok[j][q]) out_store4(st.out_pre + (size_t)row * st.ldo + 32 * (2 * wave + j) + 8 * q + 4 * half, v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]);
+      }
+    }
+    if (st.gamma) {
+      // LayerNormalization (eps 1e-3), ONE exchange: every wave reduces its own <= 64 columns of a row to (sum, M2 about its own
+      // mean) and the four partials are merged exactly (Chan et al.): var.n = sum_w [M2_w + c_w (mean_w - mean)^2]
+      int cw = st.n - 64 * wave; cw = cw < 0 ? 0 : (cw > 64 ? 64 : cw);          // valid columns of this wave
+      const float rcw = cw > 0 ? 1.f / (float)cw : 0.f;
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += v[j][r];
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mw = s1 * rcw;
+      float m2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = cok[j][q] ? v[j][4 * q + e] - mw : 0.f;
+            m2 += d * d;
+          }
+      m2 += __shfl_xor(m2, 32, 64);
+      if (half == 0) { scratch[l31 * 4 + wave] = s1; scratch[kRows * 4 + l31 * 4 + wave] = m2; }
+      lds_barrier4();
+      const float* lnp = prm + st.lds_ln;                               // gamma [256] | beta [256]
+      const float rn = 1.f / (float)st.n;
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(scratch + l31 * 4);
+      const f32x4 ma = *reinterpret_cast<const f32x4*>(scratch + kRows * 4 + l31 * 4);
+      const float tot = sa[0] + sa[1] + sa[2] + sa[3];
+      const float mu = tot * rn;
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < kNW; ++w) {
+        int c = st.n - 64 * w; c = c < 0 ? 0 : (c > 64 ? 64 : c);
+        const float dm = c > 0 ? sa[w] / (float)c - mu : 0.f;
+        var += ma[w] + (float)c * dm * dm;
+      }
+      const float rstd = 1.0f / sqrtf(var * rn + kLnEps);
+      if (st.out_stats && wave == 0 && half == 0 && m0 + l31 < g.M)
+        *reinterpret_cast<float2*>(st.out_stats + 2 * (size_t)(m0 + l31)) = make_float2(mu, rstd);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * (2 * wave + j) + 8 * q + 4 * half;
+          const float4 ga = *reinterpret_cast<const float4*>(lnp + col), be = *reinterpret_cast<const float4*>(lnp + 256 + col);
+          v[j][4 * q + 0] = (v[j][4 * q + 0] - mu) * rstd * ga.x + be.x;
+          v[j][4 * q + 1] = (v[j][4 * q + 1] - mu) * rstd * ga.y + be.y;
+          v[j][4 * q + 2] = (v[j][4 * q + 2] - mu) * rstd * ga.z + be.z;
+          v[j][4 * q + 3] = (v[j][4 * q + 3] - mu) * rstd * ga.w + be.w;
+        }
+    } else if (st.dst >= 0 && (st.dst == st.a0 || (st.asw < st.nk && st.dst == st.a1))) {
+      lds_barrier4();                                                 // in-place stage: every wave is done reading the source panel
+    }
+    wstamp(si, 2);
+    // ---- outputs: HBM (fp32, 16-byte row pieces) and/or destination panel (split fp16) -----------------------------------
+    {
+      const int row = m0 + l31;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb = 32 * (2 * wave + j);                             // first column of this block
+        if (cb >= st.n) continue;                                       // (wave-uniform)
+        char* img_row = nullptr;                         // Q/K-type: address of this lane's 16-byte unit for t = 0, g = 0
+        bool img_generic = false;
+        if (st.out && st.out_fmt != 0 && row < g.M) {
+          const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + cb;
+          const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
+          if (which == 2) img_generic = true;
+          else {
+            const int TT = (st.aoi_T + 31) >> 5, bb = row / st.aoi_T, tt = row - bb * st.aoi_T;
+            img_row = reinterpret_cast<char*>(st.out) + (size_t)which * st.aoi_img_bytes +
+                      ((size_t)(bb * (Dd >> 6) + (cw >> 6)) * TT + (tt >> 5)) * kAoiTile + ((cw & 63) >> 4) * 1024 + ((tt & 31) << 4) + half * 8;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = cb + 8 * q + 4 * half;
+          if (!cok[j][q]) continue;
+          if (st.out && row < g.M) {
+            if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
+              h16x4 hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[j][4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[j][4 * q + e] - (float)hh); }
+              char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
+              *reinterpret_cast<h16x4*>(pd) = hi;
+              *reinterpret_cast<h16x4*>(pd + 4096) = lo;
+            } else if (img_generic) {
+              AoiDesc ad; ad.mode = 4; ad.D = st.aoi_D; ad.T = st.aoi_T; ad.TT = (st.aoi_T + 31) >> 5; ad.blk_bytes = st.aoi_img_bytes;
+              ad.qk = reinterpret_cast<char*>(st.out); ad.vt = ad.qk + 2 * st.aoi_img_bytes;
+              aoi_store4(ad, row, st.aoi_c0 + col, &v[j][4 * q]);
+            }
+            else out_store4(st.out + (size_t)row * st.ldo + col, v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]);
+          }
+          if (st.dst >= 0) panel_put4(panel_ptr(st.dst), l31, col >> 5, col & 31, &v[j][4 * q]);
+        }
+      }
+    }
+    wstamp(si, 5);
+    if (st.sync_after) lds_barrier4();                                // panels are complete / free before the next stage
+    stamp(3 + 2 * si);
+    wstamp(si, 3);
+  }
+}
+
+hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
+  static int attr_set[kMaxDevices] = {0};
+  opt_in_dynamic_lds((const void*)panel_chain4_kernel, lds, attr_set);
+  const int wgs = (g.M + kRows - 1) / kRows;
+  static const char* ts_path = getenv("VNR_CHAIN_TS");
+  if (ts_path) {
+    ChainArgs gg = g;
+    static const char* ts_stage = getenv("VNR_CHAIN_TS_STAGE");       // stage whose per-wave stamps are taken (default 1)
+    gg.dbg_stage = ts_stage ? atoi(ts_stage) : 1;
+    const size_t n = (size_t)wgs * 128;
+    unsigned long long* d = nullptr;
+    if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemset(d, 0, n * 8);
+    gg.dbg_ts = d;
+    vnr_launch(panel_chain4_kernel, dim3(wgs), dim3(256), lds, s, gg);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hbuf(n);
+    (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    FILE* f = fopen(ts_path, "ab");
+    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 128)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    return hipGetLastError();
+  }
+  vnr_launch(panel_chain4_kernel, dim3(wgs), dim3(256), lds, s, g);
+  return hipGetLastError();
+}
+
+}  // namespace vnr

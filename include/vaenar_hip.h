@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VNR_ABI_VERSION 4
+#define VNR_ABI_VERSION 5
 
 typedef struct vnr_context *vnr_handle;
 
@@ -297,8 +297,41 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * as two backward-chain launches per block (0 = one launch per operation).
  * "n_sample" (default 1): hps.Train.num_samples for vnr_elbo_fwd / vnr_train_step (models.py:13,141-178), see vnr_elbo_fwd.
  * "deterministic" (default 0): the reference pins TF_DETERMINISTIC_OPS=1 and every seed (train.py:17-32); with 1 vnr_train_step
- * accumulates every gradient in a fixed order (no float atomics): two identical steps give bit-identical gradients and variables. */
+ * accumulates every gradient in a fixed order (no float atomics): two identical steps give bit-identical gradients and variables.
+ * "chain_waves4" (default 0): 32-row chain launches on the one-wave-per-SIMD kernel (csrc/gemm3c.hip: 4 waves x 64 columns, 8 k-tiles
+ * of weight operands in flight per wave) instead of the 8-wave kernel of csrc/gemm3.hip; same programs, same arithmetic.
+ * "range_guard" (default 1): see "Arithmetic contract of the split path" below; setting it (to either value) forgets the surveys. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
+
+/* Arithmetic contract of the split path (ABI version 5).
+ *
+ * TensorFlow evaluates every Dense / Conv1D / matmul of the path in fp32 (/root/reference/modules/attention.py:217-246,
+ * modules/utils.py:44-53,76-85).  With "split_fp16" = 1 a product a*w is evaluated here as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo with
+ * a = a_hi + a_lo in fp16 and fp32 accumulation.  Weight panels are split once, pre-scaled by a per-panel power of two, so ANY fp32
+ * kernel magnitude keeps 22 bits.  Activations are split UNSCALED: the representation a_hi + a_lo carries 22 significant bits while
+ * |a| >= 2^-3, an absolute resolution of 2^-25 below that (fp16 subnormals), and becomes inf above 65504.  Stated per tensor: if the
+ * largest magnitude of a GEMM input tensor is m, the error of every product row is bounded by 2^-22 (m >= 2^-3) resp.
+ * 2^-25 / m (m < 2^-3) RELATIVE TO m times the kernel column's 1-norm -- fp32 round-off class while m lies in [2^-6, 2^15).
+ *
+ * "range_guard" = 1 enforces that window instead of assuming it.  Activation magnitudes are a property of the WEIGHTS (the inputs of
+ * the path are token ids, lengths and unit-variance noise), so the first call of vnr_text_encoder_fwd / vnr_prior_sample /
+ * vnr_prior_log_probability / vnr_decoder_fwd / vnr_posterior_fwd / vnr_inference / vnr_elbo_fwd (outside training mode) after
+ * the weights of a module changed runs that call on exact fp32 MFMA with an abs-max survey of the input tensor of every Dense /
+ * Conv1D and of every attention operand (Q, K, V):
+ *   - all maxima in [2^-6, 2^15): the module is marked "in window"; the call is repeated on the split path (so it returns what
+ *     every later call returns) and later calls cost nothing extra;
+ *   - a Dense / Conv1D input outside: the modules of that call run on exact fp32 MFMA from then on (fp32 dynamic range, about half
+ *     the speed) until their weights change;
+ *   - an attention operand outside: the call fails with VNR_ERR_STATE and a message naming the range -- the attention cores split
+ *     Q, K and V in every mode and have no exact-fp32 form.
+ * All-zero tensors (the noise at temperature 0) are ignored.  vnr_op_dense with "op_dense_split" applies the same window per ROW of
+ * its inputs and falls back to the exact kernel.  vnr_train_step is not covered: it pre-scales gradients by their abs-max (csrc/
+ * gemm2.hip) and runs its forward unscaled.  Noise of a far larger standard deviation than the surveyed call's needs a fresh
+ * survey (set "range_guard" again).
+ *
+ * vnr_range_info: states4[0..3] = encoder, prior, decoder, posterior: 0 not surveyed, 1 in window (split path), 2 exact fp32 forced;
+ * lo / hi = smallest / largest non-zero tensor maximum of the last survey; surveys = number of surveys run.  Any pointer may be NULL. */
+int vnr_range_info(vnr_handle h, int *states4, float *lo, float *hi, int64_t *surveys);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,
  * utils.py:15,17,84, posterior.py:122) draw counter-based masks; BatchNormalization (utils.py:79-83) normalises with the

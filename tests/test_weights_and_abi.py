@@ -137,3 +137,5 @@ def test_build_record_shows_spill_free_chain_kernels():
     for k in ("panel_chain_kernel<1>", "panel_chain_kernel<2>", "bwd_chain_kernel<1>", "bwd_chain_kernel<2>"):
         assert res[k]["vgpr_spill"] == 0 and res[k]["scratch_bytes_per_lane"] == 0, (k, res[k])
         assert res[k]["waves_per_simd"] >= 2, (k, res[k])
+    k = "panel_chain4_kernel"                            # the one-wave-per-SIMD generation (gemm3c.hip): the whole register file, still no spill
+    assert res[k]["vgpr_spill"] == 0 and res[k]["scratch_bytes_per_lane"] == 0 and res[k]["waves_per_simd"] == 1, (k, res[k])

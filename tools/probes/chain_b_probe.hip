@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(NW * 64) kS(const char* w, unsigned long long*
 // slots of a stage are not issued in the k-loop -- where every load instruction blocks its wave at the address unit's queue -- but
 // in the epilogue, where the vector-memory path is otherwise idle: SPREAD = 0 all at once behind the k-loop, SPREAD = 1 one piece
 // per dependent LDS round trip of the epilogue.
-template <int EPI, int DEFER, int SPREAD, int ORDER = 0>
+template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0>
 __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out, float* sink) {
   constexpr int NW = 4, CT = 2, DEPTH = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out
   float keep = 0.f;
   unsigned long long t_loop = 0, t_epi = 0;
   auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+  int nkc = 8, aswc = 8;
+  asm volatile("" : "+s"(nkc), "+s"(aswc));
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
   for (int stage = 0; stage < NSTAGE; ++stage) {
@@ -153,9 +155,22 @@ __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out
     for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const h8*>(pin + lane * 16 + 1024 * i);
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) {
+      if (SWZ) {
+        // the real kernel's panel addressing: row l31 * 1024 + (((kt * 8 + c) ^ (l31 & 15)) << 4), tile clamped / panel selected by scalars
+        const int l31 = lane & 31, half = lane >> 5;
+        int kt = u + 1 + (stage & 1); kt = kt < nkc ? kt : nkc - 1;
+        const char* Ap = (kt < aswc) ? pin : pout;
+        const int akt = (kt < aswc) ? kt + (stage & 2) : kt - aswc;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[(u + 1) & 1][2 * t] = *reinterpret_cast<const h8*>(Ap + (l31 * 1024 + (((((akt << 3) + 2 * t + half) ^ (l31 & 15)) << 4)) & 32767));
+          a[(u + 1) & 1][2 * t + 1] = *reinterpret_cast<const h8*>(Ap + (l31 * 1024 + (((((akt << 3) + 4 + 2 * t + half) ^ (l31 & 15)) << 4)) & 32767));
+        }
+      } else {
       const char* ap = pin + ((u + 1) & 7) * 4096 + lane * 16;
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[(u + 1) & 1][i] = *reinterpret_cast<const h8*>(ap + 1024 * i);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (ORDER == 0) {
 #pragma unroll
@@ -242,12 +257,12 @@ __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out
   if (keep == 1234.5f) sink[0] = keep;
 }
 
-template <int EPI, int DEFER, int SPREAD, int ORDER = 0>
+template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0>
 static void runP(const char* name, const char* w, unsigned long long* out, float* sink) {
   const int lds = 2 * 8 * 4096 + 4096;
-  hipFuncSetAttribute((const void*)kP<EPI, DEFER, SPREAD, ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute((const void*)kP<EPI, DEFER, SPREAD, ORDER, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   for (int wgs : {200}) {
-    for (int rep = 0; rep < 3; ++rep) { kP<EPI, DEFER, SPREAD, ORDER><<<wgs, 256, lds>>>(w, out, sink); hipDeviceSynchronize(); }
+    for (int rep = 0; rep < 3; ++rep) { kP<EPI, DEFER, SPREAD, ORDER, SWZ><<<wgs, 256, lds>>>(w, out, sink); hipDeviceSynchronize(); }
     std::vector<unsigned long long> h(wgs * 8 * 3); hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> tot, lp, ep;
     for (int b = 0; b < wgs; ++b) {
@@ -279,10 +294,17 @@ static void run(const char* name, const char* w, unsigned long long* out, float*
   }
 }
 
-int main() {
+int g_rand = 0;
+int main(int argc, char** argv) {
   char* w; unsigned long long* out; float* sink;
   const size_t wbytes = (size_t)IMG_TILES * 32768;
-  hipMalloc(&w, wbytes); hipMemset(w, 0, wbytes); hipMalloc(&out, 256 * 8 * 3 * 8); hipMalloc(&sink, 16);
+  hipMalloc(&w, wbytes); hipMemset(w, 0, wbytes);
+  if (argc > 1) {                                       // random fp16 weights in [-1, 1): the data the matrix pipe toggles on
+    std::vector<_Float16> hw(wbytes / 2); unsigned x = 12345u;
+    for (auto& v : hw) { x = x * 1664525u + 1013904223u; v = (_Float16)(((int)(x >> 8) % 2001 - 1000) * 0.001f); }
+    hipMemcpy(w, hw.data(), wbytes, hipMemcpyHostToDevice); g_rand = 1;
+    printf("== random weights and activations\n");
+  } hipMalloc(&out, 256 * 8 * 3 * 8); hipMalloc(&sink, 16);
   printf("-- free-running (no epilogue, no barrier)\n");
   run<8, 4, 0, 0>("8 waves x 32 cols, 4 tiles in flight (as built)", w, out, sink);
   run<4, 4, 0, 0>("4 waves x 64 cols, 4 tiles in flight", w, out, sink);
@@ -321,5 +343,8 @@ int main() {
   runP<32, 0, 0, 1>("EPI 32, ORDER 1", w, out, sink);
   runP<32, 0, 0, 2>("EPI 32, ORDER 2", w, out, sink);
   runP<0, 4, 0, 1>("EPI  0, ORDER 1, 4 slots deferred (burst): loop floor", w, out, sink);
+  printf("-- ORDER 2 with the real kernel's per-tile A addressing (swizzle arithmetic on the VALU, clamps / panel select on the SALU)\n");
+  runP<0, 0, 0, 2, 1>("EPI  0, ORDER 2, swizzled A addresses", w, out, sink);
+  runP<12, 0, 0, 2, 1>("EPI 12, ORDER 2, swizzled A addresses", w, out, sink);
   return 0;
 }

@@ -4,7 +4,7 @@
 st=${1:-5}
 for w4 in 1 0; do
 rm -f /tmp/cts.bin
-VNR_CHAIN_TS=/tmp/cts.bin VNR_CHAIN_TS_STAGE=$st VNR_CHAIN_WAVES4=$w4 python -c "
+VNR_CHAIN_TS=/tmp/cts.bin VNR_CHAIN_TS_STAGE=$st VNR_CHAIN_WAVES4=$w4 VNR_CHAIN_PRIO=${PRIO:-1} python -c "
 import sys; sys.path.insert(0,'.')
 import numpy as np
 from vaenar_tts_amd.configs import LJHPS

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
 
@@ -109,6 +109,7 @@ PROTOTYPES = {
     "vnr_comm_init": [_vp, _i, _i, C.c_char_p],
     "vnr_comm_broadcast_weights": [_vp],
     "vnr_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "vnr_range_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)],
     "vnr_comm_destroy": [_vp],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
@@ -354,6 +355,15 @@ class Engine:
 
     def comm_destroy(self):
         check(self.lib.vnr_comm_destroy(self.handle), self.handle)
+
+    def range_info(self):
+        """The range guard of the split-fp16 path (include/vaenar_hip.h, "Arithmetic contract"): per-module states
+        (0 not surveyed, 1 in window = split path, 2 exact fp32 forced), the smallest / largest tensor maximum of the last survey and
+        the number of surveys run."""
+        st = (C.c_int * 4)()
+        lo, hi, n = C.c_float(0), C.c_float(0), C.c_int64(0)
+        check(self.lib.vnr_range_info(self.handle, st, C.byref(lo), C.byref(hi), C.byref(n)), self.handle)
+        return {"encoder": st[0], "prior": st[1], "decoder": st[2], "posterior": st[3], "lo": lo.value, "hi": hi.value, "surveys": n.value}
 
     def get_gradient(self, path, shape):
         out = np.empty(shape, np.float32)

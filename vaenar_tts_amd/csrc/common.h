@@ -400,6 +400,8 @@ hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const 
 // training step: backward / optimizer kernels (train_kernels.hip)
 hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift, hipStream_t s);
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
+// out[0] = max over rows of the row maximum of |x|, out[1] = min over rows with a non-zero maximum (float bits; misc.hip)
+hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s);
 #if defined(__HIPCC__)
 // Publish a candidate maximum (bits of a non-negative float; the word is zero on entry and only grows).  Same-address atomics serialise at
 // ~15-20 ns each: one per wave was 1024-4096 per attention-backward launch, 6-25 us of a 40-90 us kernel (profiles/r03_experiments.txt).

@@ -57,6 +57,8 @@ struct FlowStep {
   const float *inv_wt, *inv_b;           // (InvertibleLinear o ActNorm)^-1 : eps = (z.inv(W) - b) / (exp(ls) + 1e-8)
   double inv_logdet_per_frame;           // -sum(log_scale) + log|det inv(W)|  (flow.py:181,141-145)
   const float *pre_wt, *pre_b;           // transform pre_projection
+  const float* pre_wt_x = nullptr;       // the same kernel as a [Dp][C] panel over the WHOLE latent row (zero columns for the half that is not the conditioning
+                                         // one): a K = C stage that reads tiles 0 .. C/32 - 1 of the z panel -- what gemm3c.hip's regular k-loop takes
   float pos_weight;
   const float *heads_wt, *heads_b;       // log_scale_proj | shift_proj
   std::vector<XBlk> blks;
@@ -151,6 +153,20 @@ struct vnr_context {
   DetState det;                  // its scratch: per-stream partial buffers (common.h)
   unsigned drop_seed = 0;        // engine option "dropout_seed"
   bool split_scope = false;      // set by the module bodies: never inside the encoder -> length predictor chain
+  // ---- range guard of the split-fp16 path (include/vaenar_hip.h, "Arithmetic contract") ------------------------------------------
+  // The fp16 hi/lo split of an ACTIVATION is unscaled: a tensor whose magnitudes leave [2^-6, 2^15) loses the 22-bit contract
+  // (|a| > 65504 would even become inf).  Activation ranges are a property of the weights (the path's inputs are token ids and
+  // unit noise), so the FIRST inference-type call of a module after the weights changed runs on exact fp32 MFMA with an abs-max
+  // survey of every GEMM input / output; in-window modules then run split (the call is repeated on the split path so that it
+  // returns what later calls return), out-of-window modules stay on exact fp32 until the weights change again.
+  bool range_guard = true;       // engine option "range_guard"
+  int range_state[4] = {0, 0, 0, 0};   // per module (encoder, prior, decoder, posterior): 0 unknown, 1 in window, 2 exact fp32 forced
+  bool split_suspended = false;  // exact fp32 for the duration of a guarded call (survey, or a module in state 2)
+  bool surveying = false;
+  unsigned* survey_words = nullptr; int survey_n = 0;        // device [kSurveyMax][2]: (max, min non-zero) row maximum of each surveyed matrix
+  std::vector<int> survey_kind;                              // 0: input of a Dense / Conv1D product, 1: operand of an attention core
+  float range_lo = 0.f, range_hi = 0.f;                      // last survey: smallest / largest tensor maximum
+  int64_t range_surveys = 0;                                 // surveys run so far (tests)
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
 
   // workspace arena (chunks; bump allocation, reset at every top-level call)
@@ -225,9 +241,26 @@ struct ProfScope {
   }
 };
 
+constexpr int kSurveyMax = 2048;
+constexpr float kRangeLo = 0.015625f, kRangeHi = 32768.f;      // [2^-6, 2^15)
+inline bool split_active(vnr_handle h) { return h->split_enabled && !h->split_suspended; }
+// survey: one (max, min non-zero row max) record per matrix
+int survey_matrix(vnr_handle h, const float* x, long long ld, int rows, int cols, int kind) {
+  if (!x || rows <= 0 || cols <= 0 || h->survey_n >= kSurveyMax) return VNR_OK;
+  const hipError_t e = launch_row_range(x, ld, rows, cols, h->survey_words + 2 * h->survey_n, h->stream);
+  if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("range survey: ") + hipGetErrorString(e));
+  h->survey_n++;
+  h->survey_kind.push_back(kind);
+  return VNR_OK;
+}
+
 int run_gemm(vnr_handle h, const GemmArgs& g_in) {
   GemmArgs g = g_in;
-  if (h->split_enabled && h->split_scope && g.M >= 64) {
+  if (h->surveying) {
+    TRY(survey_matrix(h, g.A1, g.lda1, g.M, g.taps > 0 ? g.conv_C : (g.A2 ? g.K1 : g.K), 0));
+    if (g.A2) TRY(survey_matrix(h, g.A2, g.lda2, g.M, g.K - g.K1, 0));
+  }
+  if (split_active(h) && h->split_scope && g.M >= 64) {
     // the fp32 panel that contains g.Wt (sub-panels start on a row boundary and keep the row length K)
     auto it = h->split_panels.upper_bound(g.Wt);
     if (it != h->split_panels.begin()) {
@@ -319,6 +352,13 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
 
 int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
   AttnArgs a = a_in;
+  if (h->surveying) {                                     // the attention cores split Q, K and V in every mode: their ranges have no exact fallback
+    for (int b = 0; b < a.B; ++b) {
+      TRY(survey_matrix(h, a.Q + (size_t)b * a.q_bs, a.ldq, a.Tq, a.H * 64, 1));
+      TRY(survey_matrix(h, a.K + (size_t)b * a.k_bs, a.ldk, a.Tk, a.H * 64, 1));
+      TRY(survey_matrix(h, a.V + (size_t)b * a.v_bs, a.ldv, a.Tk, a.H * 64, 1));
+    }
+  }
   if (a.ali && a.Tk > 512 && !a.row_max) {             // two-pass alignment form (attention2.hip): scratch for the row statistics
     const size_t n = (size_t)a.B * a.H * a.Tq;
     a.row_max = ws_alloc(h, n); a.row_linv = ws_alloc(h, n);
@@ -503,7 +543,7 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
 
 // self-attention Q|K|V as attention operand images (three images of img_bytes each instead of the fp32 [M, 3D] panel)
 bool self_aoi_on(vnr_handle h, int D, int heads) {
-  return h->aoi_enabled && h->aoi_self && D > 0 && D == heads * 64;
+  return h->aoi_enabled && h->aoi_self && !h->split_suspended && D > 0 && D == heads * 64;
 }
 long long aoi_img_bytes(int B, int T, int D) { return (long long)B * (D / 64) * ((T + 31) / 32) * kAoiTile; }
 size_t qkv_floats(bool aoi, int B, int T, int D) { return aoi ? (size_t)(3 * aoi_img_bytes(B, T, D) / 4) : (size_t)B * T * 3 * D; }
@@ -563,7 +603,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
 
   // ---- fused row-panel chains (gemm3.hip) when the split images exist and the widths fit one 256-column panel --------
   SplitRef r_p1, r_q, r_p2, r_f1, r_f2;
-  bool chain = h->split_enabled && h->split_scope && h->chain_enabled && D <= 256 && !(D & 31) && !(F & 31) &&
+  bool chain = split_active(h) && h->split_scope && h->chain_enabled && D <= 256 && !(D & 31) && !(F & 31) &&
                split_lookup(h, k.proj1_wt, 2 * D, D, r_p1) && split_lookup(h, k.q_wt, D, D, r_q) &&
                split_lookup(h, k.proj2_wt, 2 * D, D, r_p2) && split_lookup(h, k.ffn1_wt, D, F, r_f1) &&
                split_lookup(h, k.ffn2_wt, F, D, r_f2) && r_p1.opm && r_q.opm && r_p2.opm && r_f1.opm && r_f2.opm;
@@ -738,7 +778,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
 int run_prechain(vnr_handle h, const float* in, int ld_in, int Cin, int M, const std::vector<PreStage>& stages, bool* done) {
   *done = false;
   static const bool off = getenv("VNR_NO_PRECHAIN") != nullptr;       // A/B switch
-  if (off || !(h->split_enabled && h->split_scope && h->chain_enabled) || Cin > 256 || (Cin & 31)) return VNR_OK;
+  if (off || !(split_active(h) && h->split_scope && h->chain_enabled) || Cin > 256 || (Cin & 31)) return VNR_OK;
   ChainArgs c; memset(&c, 0, sizeof(c));
   c.in0 = in; c.ld0 = ld_in; c.in1 = nullptr; c.M = M; c.D = Cin;
   int n = 0;
@@ -828,7 +868,7 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
 // A conv stack can hand its activations from layer to layer as split rows when the split-fp16 path is on for this scope, every
 // layer has its weight image and the channel counts are whole 32-channel tiles (option "split_rows", default 1)
 bool split_rows_ok(vnr_handle h, const std::vector<ConvL>& convs, int M) {
-  if (!h->split_rows || h->training || !h->split_enabled || !h->split_scope || convs.empty() || M < 64) return false;      // (run_gemm takes the split path from 64 rows)
+  if (!h->split_rows || h->training || !split_active(h) || !h->split_scope || convs.empty() || M < 64) return false;      // (run_gemm takes the split path from 64 rows)
   for (const ConvL& c : convs) {
     SplitRef r;
     if ((c.cout & 31) || !split_lookup(h, c.wt, c.k * c.cin, c.cout, r)) return false;
@@ -851,7 +891,7 @@ int refresh_bn_affine(vnr_handle h) {
 int run_kv(vnr_handle h, const float* text_embd, int B, int Tt, int mem, const float* panel, int n, float* out, int D) {
   GemmArgs g;
   g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = B * Tt; g.N = n;
-  if (h->aoi_enabled && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g)) {
+  if (h->aoi_enabled && !h->split_suspended && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g)) {
     const int nblk = n / (2 * D), TT = (Tt + 31) / 32;
     const size_t blk_bytes = (size_t)B * (D / 64) * TT * kAoiTile;
     WS(img, 2 * nblk * blk_bytes / 4);
@@ -1080,7 +1120,8 @@ int prior_body(vnr_handle h, const int32_t* z_len, const int32_t* t_len, const f
     const int cond_off = (s % 2) == 0 ? 0 : half;
     return std::vector<PreStage>{
         PreStage{f.fold_wt, C, C, p_in, 0, f.fold_b, nullptr, 1, 0.f, dst, C, p_mid},
-        PreStage{f.pre_wt, half, D, p_mid, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, p_out},
+        (h->chain_waves4 && f.pre_wt_x && C == 128) ? PreStage{f.pre_wt_x, C, D, p_mid, 0, f.pre_b, pe, Tz, f.pos_weight, xa, D, p_out}
+                                                    : PreStage{f.pre_wt, half, D, p_mid, cond_off / 32, f.pre_b, pe, Tz, f.pos_weight, xa, D, p_out},
         PreStage{f.blks[0].qkv_wt, D, 3 * D, p_out, 0, nullptr, nullptr, 1, 0.f, qkv_pre, 3 * D, -1, saoi ? Tz : 0, B}};
   };
   auto step_dst = [&](int s, float* cur) { return (s == nsteps - 1) ? z_out : (cur == za ? zb : za); };
@@ -1366,6 +1407,65 @@ int check_ready(vnr_handle h) {
   return VNR_OK;
 }
 
+// ---- range guard (see vnr_context::range_guard) ------------------------------------------------------------------------------------
+enum { MOD_ENC = 1, MOD_PRIOR = 2, MOD_DEC = 4, MOD_POST = 8 };
+int survey_begin(vnr_handle h) {
+  if (!h->survey_words) HIP_TRY(h, hipMalloc((void**)&h->survey_words, (size_t)kSurveyMax * 2 * sizeof(unsigned)));
+  std::vector<unsigned> init((size_t)kSurveyMax * 2);
+  for (int i = 0; i < kSurveyMax; ++i) { init[2 * i] = 0u; init[2 * i + 1] = 0x7f800000u; }
+  HIP_TRY(h, hipMemcpyAsync(h->survey_words, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));            // (the host vector goes out of scope)
+  h->survey_n = 0; h->survey_kind.clear();
+  h->surveying = true;
+  return VNR_OK;
+}
+// verdict: 1 every surveyed tensor maximum inside [kRangeLo, kRangeHi), 2 a Dense / Conv1D input outside (exact fp32 from now on),
+// 3 an attention operand outside (no exact form of the attention core exists: the call fails)
+int survey_end(vnr_handle h, int* verdict) {
+  h->surveying = false;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<unsigned> w((size_t)h->survey_n * 2);
+  if (h->survey_n) HIP_TRY(h, hipMemcpy(w.data(), h->survey_words, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+  float lo = INFINITY, hi = 0.f; int v = 1;
+  for (int i = 0; i < h->survey_n; ++i) {
+    float mx; memcpy(&mx, &w[2 * i], 4);
+    if (mx == 0.f) continue;                               // an all-zero matrix (temperature 0: the noise) splits exactly
+    lo = fminf(lo, mx); hi = fmaxf(hi, mx);
+    if (!(mx >= kRangeLo && mx < kRangeHi)) v = (h->survey_kind[i] == 1) ? 3 : (v == 3 ? 3 : 2);
+  }
+  h->range_lo = (lo == INFINITY) ? 0.f : lo; h->range_hi = hi;
+  h->range_surveys++;
+  *verdict = v;
+  return VNR_OK;
+}
+template <class F> int range_guarded(vnr_handle h, unsigned mods, F body) {
+  if (!h) return body();
+  TRY(check_ready(h));                                     // (a stale pack is rebuilt here: that resets the states before they are read)
+  h->split_suspended = false;
+  if (!h->range_guard || !h->split_enabled || h->training || h->in_train_step) return body();
+  bool any_exact = false, any_unknown = false;
+  for (int m = 0; m < 4; ++m) if (mods & (1u << m)) { any_exact |= h->range_state[m] == 2; any_unknown |= h->range_state[m] == 0; }
+  if (!any_exact && !any_unknown) return body();
+  if (!any_unknown) { h->split_suspended = true; const int rc = body(); h->split_suspended = false; return rc; }
+  TRY(survey_begin(h));
+  h->split_suspended = true;
+  const int rc = body();
+  h->split_suspended = false;
+  int verdict = 1;
+  const int rc2 = survey_end(h, &verdict);
+  if (rc != VNR_OK) return rc;
+  if (rc2 != VNR_OK) return rc2;
+  if (verdict == 3) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "an attention operand (query / key / value projection output) has magnitude %.3g .. %.3g, outside the split-fp16 "
+             "window [2^-6, 2^15): rescale those kernels (the attention cores have no exact-fp32 form)", (double)h->range_lo, (double)h->range_hi);
+    return fail(h, VNR_ERR_STATE, msg);
+  }
+  for (int m = 0; m < 4; ++m) if (mods & (1u << m)) h->range_state[m] = (any_exact || verdict == 2) ? 2 : 1;
+  if (verdict == 1 && !any_exact) return body();           // in window: the call returns what every later call returns (split path)
+  return VNR_OK;                                           // exact fp32 results stand
+}
+
 #include "train.inc"
 
 }  // namespace
@@ -1461,6 +1561,7 @@ int vnr_destroy(vnr_handle h) {
   for (auto& c : h->chunks) hipFree(c.p);
   for (auto& kv : h->pe_cache) hipFree(kv.second);
   for (auto& kv : h->voc_tables) hipFree(kv.second);
+  if (h->survey_words) hipFree(h->survey_words);
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
@@ -1565,6 +1666,7 @@ int vnr_finalize_weights(vnr_handle h) {
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->packed_stale = false;
+  for (int m = 0; m < 4; ++m) h->range_state[m] = 0;      // activation ranges are a property of the weights: surveyed again on the next call
   for (auto& kv : h->w) if (kv.second.n == 1 && kv.second.d) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
   for (auto p : h->packed_allocs) hipFree(p);
   h->packed_allocs.clear();
@@ -1655,6 +1757,16 @@ int vnr_finalize_weights(vnr_handle h) {
     f.pos_weight = P.scalar(p + "/2/net/pos_weight");
     f.pre_wt = P.wt(p + "/2/net/pre_projection/kernel", half, Dp);
     f.pre_b = P.raw(p + "/2/net/pre_projection/bias", {Dp});
+    {
+      float* px = P.alloc((size_t)Dp * C);
+      const int cond_off = (s % 2) == 0 ? 0 : half;         // prior.py:85-87, flow.py:227-228
+      if (px && f.pre_wt && P.rc == VNR_OK &&
+          (hipMemsetAsync(px, 0, (size_t)Dp * C * sizeof(float), h->stream) != hipSuccess ||
+           hipMemcpy2DAsync(px + cond_off, (size_t)C * sizeof(float), f.pre_wt, (size_t)half * sizeof(float), (size_t)half * sizeof(float), Dp,
+                            hipMemcpyDeviceToDevice, h->stream) != hipSuccess)) { P.rc = VNR_ERR_HIP; P.missing = "expanded pre_projection panel"; }
+      f.pre_wt_x = px;
+      P.reg(px, Dp, C);
+    }
     float* hw = P.alloc((size_t)C * Dp); float* hb = P.alloc(C);
     P.transpose_into(P.raw(p + "/2/net/log_scale_proj/kernel", {Dp, half}), Dp, half, hw, 0);
     P.transpose_into(P.raw(p + "/2/net/shift_proj/kernel", {Dp, half}), Dp, half, hw, half);
@@ -1745,12 +1857,15 @@ int vnr_finalize_weights(vnr_handle h) {
 }
 
 // ---- modules ------------------------------------------------------------------------------------------
-int vnr_text_encoder_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_lengths, int B, int T, float pos_step, float* d_out) {
+static int vnr_text_encoder_fwd_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_lengths, int B, int T, float pos_step, float* d_out) {
   TRY(check_ready(h));
   if (!d_ids || !d_out || B <= 0 || T <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
   ws_reset(h);
   TRY(encoder_body(h, d_ids, d_lengths, B, T, pos_step, d_out));
   return h->training ? refresh_bn_affine(h) : VNR_OK;
+}
+int vnr_text_encoder_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_lengths, int B, int T, float pos_step, float* d_out) {
+  return range_guarded(h, MOD_ENC, [&] { return vnr_text_encoder_fwd_impl(h, d_ids, d_lengths, B, T, pos_step, d_out); });
 }
 
 int vnr_length_predictor_fwd(vnr_handle h, const float* d_text_embd, const int32_t* d_lengths, int B, int T, float* d_out) {
@@ -1761,7 +1876,7 @@ int vnr_length_predictor_fwd(vnr_handle h, const float* d_text_embd, const int32
   return VNR_OK;
 }
 
-int vnr_prior_sample(vnr_handle h, const int32_t* d_z_lengths, const float* d_text_embd, const int32_t* d_text_lengths,
+static int vnr_prior_sample_impl(vnr_handle h, const int32_t* d_z_lengths, const float* d_text_embd, const int32_t* d_text_lengths,
                      int B, int Tz, int Tt, const float* d_eps, float* d_z, float* d_logprobs) {
   TRY(check_ready(h));
   if (!d_z_lengths || !d_text_embd || !d_z || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
@@ -1770,8 +1885,12 @@ int vnr_prior_sample(vnr_handle h, const int32_t* d_z_lengths, const float* d_te
   TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
   return prior_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs);
 }
+int vnr_prior_sample(vnr_handle h, const int32_t* d_z_lengths, const float* d_text_embd, const int32_t* d_text_lengths,
+                     int B, int Tz, int Tt, const float* d_eps, float* d_z, float* d_logprobs) {
+  return range_guarded(h, MOD_PRIOR, [&] { return vnr_prior_sample_impl(h, d_z_lengths, d_text_embd, d_text_lengths, B, Tz, Tt, d_eps, d_z, d_logprobs); });
+}
 
-int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+static int vnr_decoder_fwd_impl(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
                     const int32_t* d_text_lengths, int B, int Tz, int Tt, int reduction_factor, float* d_initial,
                     float* d_outputs, float* d_alignments) {
   TRY(check_ready(h));
@@ -1783,8 +1902,13 @@ int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, co
                    d_outputs, d_alignments));
   return h->training ? refresh_bn_affine(h) : VNR_OK;
 }
+int vnr_decoder_fwd(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+                    const int32_t* d_text_lengths, int B, int Tz, int Tt, int reduction_factor, float* d_initial,
+                    float* d_outputs, float* d_alignments) {
+  return range_guarded(h, MOD_DEC, [&] { return vnr_decoder_fwd_impl(h, d_z, d_text_embd, d_z_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, d_initial, d_outputs, d_alignments); });
+}
 
-int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_embd, const int32_t* d_text_lengths,
+static int vnr_posterior_fwd_impl(vnr_handle h, const float* d_mels, const float* d_text_embd, const int32_t* d_text_lengths,
                       const int32_t* d_target_lengths, int B, int Tz, int Tt, float* d_mu, float* d_logvar) {
   TRY(check_ready(h));
   if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
@@ -1794,8 +1918,12 @@ int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_emb
   TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->post_kv_wt, h->post_kv_n, kv, h->cfg.post_attention_dim));
   return posterior_body(h, d_mels, kv, h->post_kv_n, d_text_lengths, d_target_lengths, B, Tz, Tt, d_mu, d_logvar);
 }
+int vnr_posterior_fwd(vnr_handle h, const float* d_mels, const float* d_text_embd, const int32_t* d_text_lengths,
+                      const int32_t* d_target_lengths, int B, int Tz, int Tt, float* d_mu, float* d_logvar) {
+  return range_guarded(h, MOD_POST, [&] { return vnr_posterior_fwd_impl(h, d_mels, d_text_embd, d_text_lengths, d_target_lengths, B, Tz, Tt, d_mu, d_logvar); });
+}
 
-int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths,
+static int vnr_inference_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths,
                   int B, int Tt, int Tz, int reduction_factor, float pos_step, const float* d_eps, float* d_mel,
                   float* d_alignments, float* d_text_embd_out) {
   TRY(check_ready(h));
@@ -1836,8 +1964,13 @@ int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_leng
   return decoder_body(h, z, kv + h->prior_kv_n, kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor,
                       nullptr, d_mel, d_alignments);
 }
+int vnr_inference(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const int32_t* d_reduced_lengths,
+                  int B, int Tt, int Tz, int reduction_factor, float pos_step, const float* d_eps, float* d_mel,
+                  float* d_alignments, float* d_text_embd_out) {
+  return range_guarded(h, MOD_ENC | MOD_PRIOR | MOD_DEC, [&] { return vnr_inference_impl(h, d_ids, d_text_lengths, d_reduced_lengths, B, Tt, Tz, reduction_factor, pos_step, d_eps, d_mel, d_alignments, d_text_embd_out); });
+}
 
-int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+static int vnr_prior_log_probability_impl(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
                               const int32_t* d_text_lengths, int B, int Tz, int Tt, float* d_logprobs) {
   TRY(check_ready(h));
   if (!d_z || !d_text_embd || !d_z_lengths || !d_logprobs || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
@@ -1847,6 +1980,10 @@ int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_tex
   WS(zc, (size_t)B * Tz * h->cfg.latent_dim);
   HIP_TRY(h, hipMemcpyAsync(zc, d_z, (size_t)B * Tz * h->cfg.latent_dim * 4, hipMemcpyDeviceToDevice, h->stream));
   return prior_logprob_body(h, zc, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_logprobs);
+}
+int vnr_prior_log_probability(vnr_handle h, const float* d_z, const float* d_text_embd, const int32_t* d_z_lengths,
+                              const int32_t* d_text_lengths, int B, int Tz, int Tt, float* d_logprobs) {
+  return range_guarded(h, MOD_PRIOR, [&] { return vnr_prior_log_probability_impl(h, d_z, d_text_embd, d_z_lengths, d_text_lengths, B, Tz, Tt, d_logprobs); });
 }
 
 // BasePosterior.reparameterize (posterior.py:21-39): samples [B, ns, T, C] = eps * exp(0.5 logvar) + mu; d_eps [B, ns, T, C] is the
@@ -1891,7 +2028,7 @@ int vnr_prior_init(vnr_handle h, const int32_t* d_z_lengths, const float* d_text
   return vnr_finalize_weights(h);
 }
 
-int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
+static int vnr_elbo_fwd_impl(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
                  const int32_t* d_mel_lengths, const int32_t* d_reduced_lengths, int B, int Tt, int Tm, int rf,
                  float pos_step, const float* d_eps, float* d_outs, float* d_l2, float* d_kl, float* d_length_l2,
                  float* d_alignments, float* d_aux) {
@@ -1970,6 +2107,15 @@ int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengt
   }
   if (h->training) TRY(refresh_bn_affine(h));     // the moving statistics moved
   return VNR_OK;
+}
+int vnr_elbo_fwd(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, const float* d_mel_targets,
+                 const int32_t* d_mel_lengths, const int32_t* d_reduced_lengths, int B, int Tt, int Tm, int rf,
+                 float pos_step, const float* d_eps, float* d_outs, float* d_l2, float* d_kl, float* d_length_l2,
+                 float* d_alignments, float* d_aux) {
+  return range_guarded(h, MOD_ENC | MOD_PRIOR | MOD_DEC | MOD_POST, [&] {
+    return vnr_elbo_fwd_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps, d_outs, d_l2, d_kl,
+                             d_length_l2, d_alignments, d_aux);
+  });
 }
 
 // train_step (train.py:127-138): training-mode forward, gradients of mel_l2 + kl_weight * max(kl, 0) + length_weight *
@@ -2152,7 +2298,21 @@ int vnr_op_dense(vnr_handle h, const vnr_dense_desc* d) {
   g.Wt = wt; g.ldw = K; g.bias = d->d_bias; g.act = d->activation; g.residual = d->d_residual; g.ldr = d->ldr;
   g.pe = d->d_pe; g.pe_T = d->pe_T > 0 ? d->pe_T : 1; g.pe_w = d->pe_weight; g.C = d->d_c; g.ldc = d->ldc; g.M = d->m; g.N = d->n;
   h->split_scope = false;                  // the operator entry point picks the path explicitly:
-  if (h->op_dense_split) {                  // option "op_dense_split": exercise the split-fp16 kernel on a temporary image
+  bool split_ok = h->op_dense_split;
+  if (split_ok && h->range_guard) {          // the split path's range contract, per ROW at the operator level: a row maximum outside the window -> exact fp32
+    TRY(survey_begin(h));
+    h->surveying = false;
+    TRY(survey_matrix(h, g.A1, g.lda1, g.M, g.A2 ? g.K1 : g.K, 0));
+    if (g.A2) TRY(survey_matrix(h, g.A2, g.lda2, g.M, g.K - g.K1, 0));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    unsigned w[4] = {0u, 0x7f800000u, 0u, 0x7f800000u};
+    HIP_TRY(h, hipMemcpy(w, h->survey_words, (size_t)h->survey_n * 2 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->survey_n; ++i) {
+      float mx, mn; memcpy(&mx, &w[2 * i], 4); memcpy(&mn, &w[2 * i + 1], 4);
+      if (mx != 0.f && !(mx < kRangeHi && mn >= kRangeLo)) split_ok = false;
+    }
+  }
+  if (split_ok) {                           // option "op_dense_split": exercise the split-fp16 kernel on a temporary image
     WS(img, (size_t)d->n * ((K + 31) / 32) * 32);
     RUN_MISC(h, launch_split_weights(wt, d->n, K, 256.f, img, h->stream));
     g.Wsplit = img; g.acc_scale = 1.f / 256.f;
@@ -2322,7 +2482,17 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "dropout_seed")) { h->drop_seed = (unsigned)value; return VNR_OK; }
   if (!strcmp(name, "n_sample")) { if (value < 1 || value > 64) return fail(h, VNR_ERR_ARG, "n_sample: 1..64"); h->n_sample = value; return VNR_OK; }
   if (!strcmp(name, "deterministic")) { h->deterministic = value != 0; return VNR_OK; }
+  if (!strcmp(name, "range_guard")) { h->range_guard = value != 0; for (int m = 0; m < 4; ++m) h->range_state[m] = 0; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
+}
+
+int vnr_range_info(vnr_handle h, int* states4, float* lo, float* hi, int64_t* surveys) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  if (states4) for (int m = 0; m < 4; ++m) states4[m] = h->range_state[m];
+  if (lo) *lo = h->range_lo;
+  if (hi) *hi = h->range_hi;
+  if (surveys) *surveys = h->range_surveys;
+  return VNR_OK;
 }
 
 // ---- instrumentation -------------------------------------------------------------------------------------------

@@ -95,16 +95,17 @@ panel_chain_kernel(const ChainArgs g) {
   __amdgpu_buffer_rsrc_t frs;
   auto open_stage = [&](int s_) {
     const ChainStage& st = g.st[s_];
-    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(st.w), 0, 0x40000000, 0x00020000);
+    // (measurement only, VNR_CHAIN_PRIO=8: every stage reads the first 8 k-tiles of stage 0's image -- L2-resident, wrong results)
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.prio_mode == 8 ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
     fnk = st.nk;
     fpad = (st.nk + PF - 1) / PF * PF;
-    fvoff = (32 * wave < st.n) ? (unsigned)((wave * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
+    fvoff = (32 * wave < st.n) ? (unsigned)((wave * (g.prio_mode == 8 ? 8 : st.kt_total) + (g.prio_mode == 8 ? 0 : st.kt0)) * 4096 + lane * 16) : kOob3;
   };
   auto fetch = [&](int u) {
     const unsigned vo = (fk < fnk) ? fvoff : kOob3;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      wreg[u][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, fk * 4096 + i * 1024, 0));
+      wreg[u][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, (g.prio_mode == 8 ? (fk & 7) : fk) * 4096 + i * 1024, 0));
     if (++fk == fpad) {
       fk = 0;
       if (fs + 1 < g.nstages) { ++fs; open_stage(fs); } else { fnk = 0; }      // past the end: dummy (out-of-range) refills
@@ -867,6 +868,14 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     const int need = 32 * (g.st[g.cpl_stage].n + 4) * 4;
     if (g.att_stage > 0 && g.cpl_stage > g.att_stage && need <= (g.D >> 6) * 32 * 66 * 4) g.cpl_lds = g.att_lds;
     else { g.cpl_lds = (lds + 15) & ~15; lds = g.cpl_lds + need; }
+  }
+  if (g.waves4) {                                       // gemm3c.hip takes REGULAR programs only (its single k-loop instance): see there
+    for (int i = 0; i < g.nstages && g.waves4; ++i) {
+      const ChainStage& st = g.st[i];
+      const bool ok = (st.nk == 4 && st.akt0 == 0 && st.asw >= st.nk) || (!(st.nk & 7) && !(st.akt0 & 1) && (st.asw >= st.nk || !(st.asw & 7)));
+      if (!ok) g.waves4 = 0;
+    }
+    if (g.D != 256 && g.D != 128) g.waves4 = 0;
   }
   if (g.waves4) {                                       // gemm3c.hip turns the V-type stages of a Q|K|V tail through LDS: wave-private 32 x 33 floats
     bool anyv = false;

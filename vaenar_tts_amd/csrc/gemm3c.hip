@@ -78,17 +78,35 @@ panel_chain4_kernel(const ChainArgs g) {
   __amdgpu_buffer_rsrc_t frs;
   auto open_stage = [&](int s_) {
     const ChainStage& st = g.st[s_];
-    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(st.w), 0, 0x40000000, 0x00020000);
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.prio_mode == 8 ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
     fnk = st.nk;
     fpad = (st.nk + kDepth - 1) / kDepth * kDepth;
-    fvoff0 = (64 * wave < st.n) ? (unsigned)(((2 * wave) * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
-    fvoff1 = (64 * wave + 32 < st.n) ? (unsigned)(((2 * wave + 1) * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
+    // (measurement only, VNR_CHAIN_PRIO=8: every stage reads the first 256 KiB of stage 0's image -- L2-resident, not L1-resident, wrong results)
+    const int ktt = g.prio_mode == 8 ? 8 : st.kt_total, k0 = g.prio_mode == 8 ? 0 : st.kt0;
+    fvoff0 = (64 * wave < st.n) ? (unsigned)(((2 * wave) * ktt + k0) * 4096 + lane * 16) : kOob3;
+    fvoff1 = (64 * wave + 32 < st.n) ? (unsigned)(((2 * wave + 1) * ktt + k0) * 4096 + lane * 16) : kOob3;
+  };
+  // Validity of a fetched k-tile (kt < nk of the fetched stage) is decided once per TRIP for three slot groups -- a stage has at least
+  // two k-tiles: slots 0-1 always carry one, slots 2-3 iff more than 2 remain, slots 4-7 iff more than 4 -- so the loop body holds no
+  // select; the piece index rides in the instruction's immediate offset, the k-tile in the scalar offset.
+  unsigned vo[3][2];
+  int fsoff = 0;                                         // fk * 4096 (or the measurement overrides below)
+  auto trip_offsets = [&]() {
+    const int left = fnk - fk;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned v = j ? fvoff1 : fvoff0;
+      vo[0][j] = left > 0 ? v : kOob3;
+      vo[1][j] = left > 2 ? v : kOob3;
+      vo[2][j] = left > 4 ? v : kOob3;
+    }
+    // (measurement only, VNR_CHAIN_PRIO=9: every weight read goes to the stage's first k-tile -- L1-resident, wrong results;
+    //  VNR_CHAIN_PRIO=8: the first 8 k-tiles of stage 0's image -- L2-resident, wrong results)
+    fsoff = g.prio_mode == 9 ? 0 : (g.prio_mode == 8 ? 0 : fk * 4096);
   };
   auto piece = [&](int u, int j, int i) {
-    const int kt = fk + u;
-    const unsigned vo = (kt < fnk) ? (j ? fvoff1 : fvoff0) : kOob3;
-    // (measurement only, VNR_CHAIN_PRIO=9: every weight read goes to the stage's first k-tile -- L1-resident, wrong results)
-    wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, (g.prio_mode == 9 ? 0 : kt * 4096) + i * 1024, 0));
+    const unsigned v = vo[u < 2 ? 0 : (u < 4 ? 1 : 2)][j];
+    wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, v + i * 1024, fsoff + (g.prio_mode == 9 ? 0 : u * 4096), 0));
   };
   auto advance = [&]() {
     fk += kDepth;
@@ -96,8 +114,10 @@ panel_chain4_kernel(const ChainArgs g) {
       fk = 0;
       if (fs + 1 < g.nstages) { ++fs; open_stage(fs); } else { fnk = 0; }
     }
+    trip_offsets();
   };
   open_stage(0);
+  trip_offsets();
 #pragma unroll
   for (int u = 0; u < kDepth; ++u)
 #pragma unroll
@@ -148,6 +168,10 @@ panel_chain4_kernel(const ChainArgs g) {
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    // the three panels start as zeros (while the rows above are in flight): a short stage (nk = 4) multiplies tiles 4-7 of its source
+    // rows with zero weights, and 0 x NaN from whatever the LDS held would poison the accumulators
+    for (int o = tid * 16; o < 3 * kPanelBytes; o += 256 * 16) *reinterpret_cast<float4*>(smem + kPOff + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    lds_barrier4();
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       if (!(pi == 0 ? g.in0 : g.in1)) continue;
@@ -346,43 +370,65 @@ panel_chain4_kernel(const ChainArgs g) {
     wstamp(si, 0);
     const int npad = (st.nk + kDepth - 1) / kDepth * kDepth;
     h16x8 afr[2][4];                                     // activation operands, ONE k-tile ahead: [set][2 t + (hi | lo)]
-    auto read_a = [&](int kt, int set) {
-      const int kc = kt < st.nk ? kt : st.nk - 1;
-      const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
-      const int akt = (kc < st.asw) ? kc + st.akt0 : kc - st.asw;
+    // One trip = 8 slots.  Waves without columns and padding k-tiles multiply the zeros their out-of-range refills returned.
+    // Consecutive MFMAs alternate between the two accumulators; the refill of a piece follows the last MFMA that read it.
+    // With one wave per SIMD nothing hides the loop's scalar / vector bookkeeping (about five issue slots fit beside an MFMA), so the
+    // A operands are addressed through eight per-trip row pointers (even / odd tile x four 16-byte chunks, the XOR swizzle folded in)
+    // plus immediate offsets: no per-tile arithmetic at all.  ONE instance of the loop: a second one (a general form for irregular
+    // stages was tried) makes every wreg element a phi of the two and the kernel spills ~500 registers.
+    auto mfma_slot = [&](int u) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        afr[set][2 * t] = *reinterpret_cast<const h16x8*>(Ap + panel_off4(l31, akt, 2 * t + half));
-        afr[set][2 * t + 1] = *reinterpret_cast<const h16x8*>(Ap + panel_off4(l31, akt, 4 + 2 * t + half));
+        const h16x8 ah = afr[u & 1][2 * t], al = afr[u & 1][2 * t + 1];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], ah, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], ah, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], al, acc[0], 0, 0, 0);
+        piece(u, 0, 2 * t);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], al, acc[1], 0, 0, 0);
+        piece(u, 1, 2 * t);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t + 1], ah, acc[0], 0, 0, 0);
+        piece(u, 0, 2 * t + 1);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t + 1], ah, acc[1], 0, 0, 0);
+        piece(u, 1, 2 * t + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    // One trip = 8 slots, ONE instance of the loop (a second instantiation -- an idle-wave form, the operand-swapped form of the
-    // 8-wave kernel's V stages, a short form for K <= 128 -- makes every wreg element a phi of the variants and the kernel spills
-    // ~150 registers): waves without columns and padding k-tiles multiply the zeros their out-of-range refills returned.
-    // Consecutive MFMAs alternate between the two accumulators; the refill of a piece follows the last MFMA that read it.
-    read_a(0, 0);
+    // launch_panel_chain admits only REGULAR programs to this kernel: nk = 4 (then the stage reads tiles 0-3 of its panel: K = 128, first
+    // tile 0) or a multiple of 8 with an even first tile and the panel switch (asw) on a trip boundary.  Slot u of a trip then reads
+    // tile t0 + u of ONE panel; for nk = 4 the slots 4-7 read tiles 4-7 of the same rows -- finite stale data (the panels are
+    // zero-filled at kernel start) against the zeros of their out-of-range weight refills.
+    {
+      const int x15 = l31 & 15;
+      int arow[2][4];                                    // LDS byte addresses of this lane's chunks in tile pair 0 of the trip's source
+      auto trip_rows = [&](int kb) {
+        const int kc = kb < st.nk ? kb : 0;
+        const char* Ap = (kc < st.asw) ? Ap0 : Ap1;
+        const int t0 = (kc < st.asw) ? kc + st.akt0 : kc - st.asw;
+        const int base = (int)(size_t)(Ap - smem) + (t0 >> 1) * 256 + l31 * 1024;
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+          for (int idx = 0; idx < 4; ++idx) {
+            const int c = ((idx & 1) ? 4 : 0) + 2 * (idx >> 1) + half;
+            arow[par][idx] = base + ((((par << 3) | c) ^ x15) << 4);
+          }
+      };
+      auto read_r = [&](int u, int set) {                // k-tile u of the current trip rows
+#pragma unroll
+        for (int idx = 0; idx < 4; ++idx) afr[set][idx] = *reinterpret_cast<const h16x8*>(smem + arow[u & 1][idx] + (u >> 1) * 256);
+      };
+      trip_rows(0);
+      read_r(0, 0);
 #pragma unroll 1
-    for (int kb = 0; kb < npad; kb += kDepth) {
+      for (int kb = 0; kb < npad; kb += kDepth) {
 #pragma unroll
-      for (int u = 0; u < kDepth; ++u) {
-        read_a(kb + u + 1, (u + 1) & 1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const h16x8 ah = afr[u & 1][2 * t], al = afr[u & 1][2 * t + 1];
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], ah, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], ah, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t], al, acc[0], 0, 0, 0);
-          piece(u, 0, 2 * t);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t], al, acc[1], 0, 0, 0);
-          piece(u, 1, 2 * t);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][0][2 * t + 1], ah, acc[0], 0, 0, 0);
-          piece(u, 0, 2 * t + 1);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[u][1][2 * t + 1], ah, acc[1], 0, 0, 0);
-          piece(u, 1, 2 * t + 1);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < kDepth; ++u) {
+          if (u + 1 < kDepth) read_r(u + 1, (u + 1) & 1);
+          else { trip_rows(kb + kDepth); read_r(0, 0); }   // the next trip's first tile (after the last trip: a harmless re-read)
+          mfma_slot(u);
         }
+        advance();
       }
-      advance();
     }
     stamp(2 + 2 * si);
     wstamp(si, 1);

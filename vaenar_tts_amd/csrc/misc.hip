@@ -907,4 +907,30 @@ hipError_t launch_philox_normal(float* out, size_t n, unsigned long long seed, u
   return hipGetLastError();
 }
 
+
+// ---- range survey of an activation matrix (engine.hip: range guard of the split-fp16 path) ------------------------------------------
+// out[0] = bits of the largest row maximum max_r max_c |x[r][c]| (atomicMax), out[1] = bits of the smallest NON-ZERO row maximum
+// (atomicMin; the caller initialises it to 0x7f800000).  Non-negative floats order like their bit patterns; a NaN counts as +inf.
+namespace {
+__global__ void __launch_bounds__(256) row_range_kernel(const float* x, long long ld, int rows, int cols, unsigned* out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + (size_t)row * ld;
+  float m = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float v = p[c]; m = fmaxf(m, (v != v) ? INFINITY : fabsf(v)); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) {
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, b);
+    if (b != 0u && b < __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out + 1, b);
+  }
+}
+}  // namespace
+hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, rows, cols, out);
+  return hipGetLastError();
+}
+
 }  // namespace vnr

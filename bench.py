@@ -53,7 +53,11 @@ def parse_args(argv=None):
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--exact-fp32", action="store_true", help="disable the split-fp16 GEMM path (exact fp32 MFMA everywhere)")
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra exact-fp32 pass (`exact_fp32` block)")
+    ap.add_argument("--no-attn-phase", action="store_true", help="skip the child process that stamps the in-chain cross-attention phase")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (A/B switches), repeatable")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="training block: GLOBAL batch of the data-parallel step, split evenly over the ranks (strong-scaled reading of BASELINE "
+                         "config 5: 32 -> 4 utterances per rank at 8 GPUs); 0 = 32 utterances per rank (weak scaling)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engine handles (= HIP streams) the K timed steps of `value` are dealt to.  1 (default) = the strictly "
                          "sequential schedule the roofline blocks are measured on; >1 is an experiment switch")
@@ -336,7 +340,47 @@ def run_rank(args):
                                  "note": "attention_core_bytes = Q + K,V + context + alignments as SURVEY D3 counts a stand-alone core (30.41 MB); "
                                          "inside the launch Q and the context stay in LDS: only K,V images (4.2 MB) are read and the alignments "
                                          "(13.1 MB) written for the attention phase"},
-                "bound": "mfma (the launch is a row-panel chain of 12+ dense stages)", "frac": None}
+                "bound": "hbm (the attention + alignment PHASE of the launch, priced below; the launch as a whole is a row-panel chain of 12+ dense stages)",
+                "frac": None}
+            # (round 5) the number stays observable: (a) the in-chain attention + alignment phase from the kernel's own s_memtime stamps
+            # (a child process: the stamp mode synchronises after every chain launch), priced as the bytes the phase moves -- the K, V
+            # images read (4.19 MB) + the alignments written (13.11 MB) -- against 8 TB/s; (b) one profiled pass with fuse_xattn = 0, where the
+            # stand-alone attn3_kernel<true> runs, priced with SURVEY D3's 30.41 MB
+            rca = out["roofline_cross_attention"]
+            kv_bytes, ali_bytes = 4.0 * 2 * B * Tt * 256, 4.0 * B * 4 * (Tm // rf) * Tt
+            if not args.no_attn_phase:
+                try:
+                    import subprocess
+                    cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "attn_phase.py")],
+                                        capture_output=True, text=True, timeout=300)
+                    ph = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+                    if ph.get("launches"):
+                        us = ph["share"] * rca["fused_launch"]["avg_launch_us"]
+                        gb = (kv_bytes + ali_bytes) / (us * 1e-6) / 1e9
+                        rca["in_chain_phase"] = {"phase_us": us, "share_of_the_launch": ph["share"], "phase_kcyc": ph["phase_kcyc"],
+                                                 "workgroup_lifetime_kcyc": ph["lifetime_kcyc"], "bytes": kv_bytes + ali_bytes,
+                                                 "achieved": gb, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gb / PEAK_HBM_GBPS,
+                                                 "definition": "median over workgroups of (stamp after the alignment stores - stamp at the start of the attention phase) / "
+                                                               "workgroup lifetime x the launch's measured duration; bytes = K, V images read + fp32 alignments written"}
+                        rca["frac"] = gb / PEAK_HBM_GBPS
+                except Exception as e:
+                    rca["in_chain_phase"] = {"error": repr(e)}
+            try:
+                eng.set_option("fuse_xattn", 0)
+                run_on(lanes[0]); eng.synchronize()
+                eng.profile(True); eng.profile_reset()
+                for _ in range(ps):
+                    run_on(lanes[0])
+                eng.synchronize()
+                sa = _get("attn_cross_ali")
+                eng.profile(False); eng.profile_reset()
+                if sa["launches"]:
+                    gbps = sa["bytes"] / (sa["ms"] * 1e-3) / 1e9
+                    rca["standalone_kernel_fuse_xattn_0"] = {"kernel": "attn3_kernel<true>", "avg_launch_us": 1e3 * sa["ms"] / sa["launches"],
+                                                             "algorithmic_bytes_per_launch": sa["bytes"] / sa["launches"], "achieved": gbps,
+                                                             "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}
+            finally:
+                eng.set_option("fuse_xattn", 1)
         if a["launches"]:
             gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             out["roofline_cross_attention"] = {
@@ -406,13 +450,8 @@ def run_rank(args):
         for ln in extra:
             ln["model"].engine.close()
 
-    mel_exact = out.pop("_mel_exact", None)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out.update(cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact))
-        if mel_exact is not None and "exact_fp32" in out and "_exact_err" in out:
-            out["exact_fp32"]["max_abs_mel_err"] = out.pop("_exact_err")
-    out.pop("_exact_err", None)
-
+    # (the training blocks run BEFORE the CPU baseline: that leg imports torch, whose bundled RCCL then answers the engine's dlopen of
+    #  librccl.so and fails to initialise a communicator -- seen on the first round-5 run of the one-rank data-parallel block)
     if not args.no_train:
         for ln in lanes:
             ln["model"].engine.close()
@@ -434,6 +473,15 @@ def run_rank(args):
             wd.cancel()
         if rank == 0:
             out["training"] = tr
+        if world == 1 and "error" not in tr:
+            out["training"]["data_parallel_rank_shape"] = rank_shape_block(args, device, tr)
+
+    mel_exact = out.pop("_mel_exact", None)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact))
+        if mel_exact is not None and "exact_fp32" in out and "_exact_err" in out:
+            out["exact_fp32"]["max_abs_mel_err"] = out.pop("_exact_err")
+    out.pop("_exact_err", None)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -504,6 +552,93 @@ def cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact=None):
     return res
 
 
+def _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, world, rank, deterministic, nst, seed):
+    """2 warm-up + nst timed training steps in the given accumulation mode -> (seconds per step, max over ranks; last result; launches per
+    step; next dropout seed).  `deterministic` = 1 is what train.py runs by default (like the reference's TF_DETERMINISTIC_OPS=1,
+    /root/reference/train.py:17-32): gradients accumulated in a fixed order; 0 = float atomics."""
+    tm.engine.set_option("deterministic", int(deterministic))
+    res = None
+    for _ in range(2):
+        res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=seed * world + rank); seed += 1
+    tm.engine.synchronize()        # (a step returns when its results are on the host; the derived kernel copies for the next step follow it)
+    n0 = tm.engine.launch_count()
+    if world > 1:
+        vdist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(nst):
+        res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=seed * world + rank); seed += 1
+    tm.engine.synchronize()        # the timed region ends with an idle stream
+    if world > 1:
+        vdist.barrier()
+    tdt = vdist.max_over_ranks((time.perf_counter() - t1) / nst)
+    return tdt, res, (tm.engine.launch_count() - n0) // nst, seed
+
+
+def rank_shape_block(args, device, t1):
+    """What ONE of 8 ranks runs in BASELINE config 5 read as a strong-scaled job (DataBaker train.py, GLOBAL B = 32, data-parallel with an
+    RCCL gradient all-reduce): DataBakerHPS, 4 utterances, the communicator bound (one rank here: the call sequence is the N-rank one),
+    deterministic accumulation -- measured on this GPU -- plus a STATED model of the 8-GPU step from it.  No multi-GPU number is claimed:
+    the driver's SCALE run is the measurement, this block is what a single GPU can show beforehand."""
+    import numpy as np
+    from vaenar_tts_amd import dist as vdist
+    from vaenar_tts_amd.configs import DataBakerHPS
+    from vaenar_tts_amd.models import VAENAR
+    from vaenar_tts_amd.synthetic import make_batch
+    from vaenar_tts_amd.weights import init_weights
+    Tt, Tm, trf, TB = S1["T_text"], S1["T_mel"], 2, 4
+    try:
+        hps = DataBakerHPS
+        tm = VAENAR(hps, device=device, weights=init_weights(hps, seed=1234, mode="synthetic", include_posterior=True))
+        tb = make_batch(TB, Tt, Tm, vocab_size=hps.Encoder.Transformer.vocab_size, ragged=False, seed=99)
+        r = np.random.Generator(np.random.PCG64(7))
+        t_mels = tm.engine.to_device(r.standard_normal((TB, Tm, hps.Audio.num_mels)).astype(np.float32), np.float32)
+        t_eps = tm.engine.to_device(r.standard_normal((TB, (Tm + trf - 1) // trf, hps.Common.latent_dim)).astype(np.float32), np.float32)
+        t_ids = tm.engine.to_device(tb["ids"], np.int32)
+        # the rank's own work (no communicator), then the same steps with the communicator bound: the call sequence of an N-rank job.  RCCL's
+        # ONE-rank all-reduce is a self-copy on a single channel (139 MB in ~9 ms): it says nothing about the xGMI exchange and is reported apart
+        dt4, res, launches, seed = _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, 1, 0, 1, 6, 0)
+        tm.engine.comm_init(1, 0, tm.engine.comm_unique_id())
+        dt4c, _, launches_c, _ = _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, 1, 0, 1, 4, seed)
+        nr, rk = tm.engine.comm_info()
+        tm.engine.comm_destroy(); tm.engine.close()
+        # the stated model.  Payload: the flat fp32 gradient (SURVEY 8e / BASELINE.md: 138.9 MB for LJHPS; DataBaker differs by 4 embedding
+        # rows).  xGMI: 7 links per GPU at ~153 GB/s each (the figure this project was given; taken as bidirectional: 76.5 GB/s per
+        # direction).  RCCL ring all-reduce moves 2 (N-1)/N of the payload through ONE link direction per GPU; a direct reduce-scatter +
+        # all-gather over all 7 links moves 2 x payload / N per peer.  vnr_train_step exchanges 4 buckets in reverse layer order on
+        # its own stream while the backward pass continues (DESIGN.md section 5), so only the LAST bucket (encoder + length predictor,
+        # 46 of 139 MB) is exposed in front of Adam.
+        N, payload, last_bucket, link = 8, 138.9e6, 46.0e6, 76.5e9
+        ring = 2.0 * (N - 1) / N * payload / link
+        direct = 2.0 * payload / N / link
+        exposed_ring, exposed_direct = ring * last_bucket / payload, direct * last_bucket / payload
+        t32 = t1["ms_per_step"] * 1e-3                                  # this GPU's step at B = 32 (deterministic)
+        strong = {"step_ms_per_rank_measured_B4": 1e3 * dt4,
+                  "predicted_step_ms_at_8": {"ring_overlapped": 1e3 * (dt4 + exposed_ring), "ring_not_overlapped": 1e3 * (dt4 + ring),
+                                             "direct_overlapped": 1e3 * (dt4 + exposed_direct)},
+                  "predicted_speedup_over_1_gpu_B32": {"ring_overlapped": t32 / (dt4 + exposed_ring), "ring_not_overlapped": t32 / (dt4 + ring)},
+                  "predicted_efficiency": {"ring_overlapped": t32 / (dt4 + exposed_ring) / N, "ring_not_overlapped": t32 / (dt4 + ring) / N}}
+        weak = {"step_ms_per_rank_measured_B32": 1e3 * t32,
+                "predicted_step_ms_at_8": {"ring_overlapped": 1e3 * (t32 + exposed_ring), "ring_not_overlapped": 1e3 * (t32 + ring)},
+                "predicted_efficiency": {"ring_overlapped": t32 / (t32 + exposed_ring), "ring_not_overlapped": t32 / (t32 + ring)}}
+        return {"workload": "one rank of BASELINE config 5 as a strong-scaled job: DataBakerHPS train_step, 4 utterances (global B = 32 over 8 ranks), "
+                            "T_text=128, T_mel=800, rf=2, deterministic accumulation",
+                "ms_per_step": 1e3 * dt4, "kernel_launches_per_step": launches, "loss": res[0],
+                "with_one_rank_communicator": {"ms_per_step": 1e3 * dt4c, "rccl_ranks": nr, "rccl_rank": rk, "kernel_launches_per_step": launches_c,
+                                               "note": "the N-rank call sequence (4 bucketed ncclAllReduce + scaling on the exchange stream); a one-rank "
+                                                       "all-reduce is RCCL copying 138.9 MB onto itself on one channel -- not the xGMI exchange, not used by the model"},
+                "inference_shard": "S3 (B = 128 over 8 GPUs) gives every rank exactly the S1 batch of the headline line: `ms_per_step` above, no collective",
+                "model": {"assumptions": {"ranks": N, "gradient_bytes": payload, "xgmi_GBps_per_link_direction": link / 1e9, "links_per_gpu": 7,
+                                          "ring_allreduce_ms": 1e3 * ring, "direct_rs_ag_ms": 1e3 * direct, "exposed_last_bucket_bytes": last_bucket,
+                                          "note": "a step of 923 launches has a floor of ~9.6 ms whatever the batch (B = 1: 9.6, 4: 9.9, 16: 13.5, 32: 19 ms on one box, "
+                                                  "profiles/r05_experiments.txt) and a chain launch lasts as long as one workgroup's walk whatever its grid (DESIGN.md "
+                                                  "4.3c): a 4-utterance step is half, not an eighth, of a 32-utterance one -- that bounds the strong-scaled reading"},
+                          "strong_scaling_global_B32": strong, "weak_scaling_B32_per_rank": weak,
+                          "recommended_reading": "weak (B = 32 per rank, global 256): per-rank work keeps the GPU full and the exchange hides behind the backward pass; "
+                                                 "`bench.py --gpus N --global-batch 32` times the strong-scaled reading when a multi-GPU box is available"}}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def training_block(args, hps, device, rank, world):
     """The training step beside the headline metric (never part of `value`): world == 1 -> BASELINE config 3 (T1: train.py
     step, ELBO fwd + bwd + Adam, B=32, no all-reduce); world > 1 -> config 5's exchange (T2: the same step per rank, B=32 per
@@ -522,31 +657,23 @@ def training_block(args, hps, device, rank, world):
             tm.engine.comm_init(world, rank, uid)
             tm.engine.comm_broadcast_weights()
         TB, trf = 32, 2
+        if getattr(args, "global_batch", 0) and world > 1:
+            if args.global_batch % world:
+                return {"error": "--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world)}
+            TB = args.global_batch // world
         tb = make_batch(TB, Tt, Tm, ragged=False, seed=99 + rank)
         r = np.random.Generator(np.random.PCG64(7 + rank))
         t_mels = tm.engine.to_device(r.standard_normal((TB, Tm, hps.Audio.num_mels)).astype(np.float32), np.float32)
         t_eps = tm.engine.to_device(r.standard_normal((TB, (Tm + trf - 1) // trf, hps.Common.latent_dim)).astype(np.float32), np.float32)
         t_ids = tm.engine.to_device(tb["ids"], np.int32)
-        res = None
-        for i in range(2):
-            res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=i * world + rank)
-        tm.engine.synchronize()        # (a step returns when its results are on the host; the derived kernel copies for the next step follow it)
-        n0 = tm.engine.launch_count()
-        if world > 1:
-            vdist.barrier()
-        t1 = time.perf_counter()
         nst = 4
-        for i in range(nst):
-            res = tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=(2 + i) * world + rank)
-        tm.engine.synchronize()        # the timed region ends with an idle stream
-        if world > 1:
-            vdist.barrier()
-        tdt = vdist.max_over_ranks((time.perf_counter() - t1) / nst)
-        launches_per_step = (tm.engine.launch_count() - n0) // nst
+        tdt, res, launches_per_step, seed = _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, world, rank, 1, nst, 0)
+        tdt_atomic, _, _, seed = _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, world, rank, 0, nst, seed)
+        tm.engine.set_option("deterministic", 1)
         rccl_ranks, rccl_rank = (tm.engine.comm_info() if world > 1 else (1, 0))        # what RCCL says (ncclCommCount / ncclCommUserRank)
         # one more step with dispatch events on every heavy launch: executed matrix-pipe FLOPs and the dominant kernel class
         tm.engine.profile(True); tm.engine.profile_reset()
-        tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=(2 + nst) * world + rank)
+        tm.train_step(t_ids, t_mels, tb["text_lengths"], tb["mel_lengths"], 1e-5, trf, eps=t_eps, dropout_seed=seed * world + rank)
         tm.engine.synchronize()
         tcls = ("gemm", "gemm_fp32", "chain", "gemm_tn", "bwd_chain", "attn_bwd", "attn_self", "attn_cross")
         tprof = {c: tm.engine.profile_get(c) for c in tcls}
@@ -564,7 +691,7 @@ def training_block(args, hps, device, rank, world):
                 "achieved": f16_flops / tdt / 1e12, "frac": f16_flops / tdt / 1e12 / PEAK_F16_MFMA_TFLOPS,
                 "definition": "EXECUTED f16 MFMA FLOPs of one step (3 x the algorithmic 2*M*N*K of every split-fp16 launch: forward / "
                               "data-gradient GEMMs, forward and backward chains, kernel-gradient GEMMs, attention forward and backward) / "
-                              "step time / 2.5 PF; the exact-fp32 convolution forwards are listed apart",
+                              "step time / 2.5 PF; launches on the fp32 matrix pipe (none in the default configuration) are listed apart",
                 "executed_f16_gflop_per_step": f16_flops / 1e9, "fp32_mfma_gflop_per_step": fp32_flops / 1e9,
                 "dominant_kernel": {"class": tdom, "launches_per_step": d["launches"], "ms_per_step_beside_the_other_stream": d["ms"],
                                     "executed_tflops": exec_mult[tdom] * d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else None,
@@ -575,11 +702,14 @@ def training_block(args, hps, device, rank, world):
             }
         blk = {
             "workload": ("T1" if world == 1 else "T2") + " train_step (train.py:127-138): training-mode ELBO forward + backward of all 501 "
-                        "variables + Adam, B=32 per GPU, T_text=128, T_mel=800, rf=2, LJHPS; forward / data-gradient GEMMs on the 3-term "
-                        "split-fp16 path (convolution forward exact fp32), kernel gradients split-fp16; "
+                        "variables + Adam, B=%d per GPU, T_text=128, T_mel=800, rf=2, LJHPS; forward (convolutions included) / data-gradient GEMMs and the "
+                        "kernel gradients on the 3-term split-fp16 path; " % TB
                         + ("1 GPU, no gradient all-reduce" if world == 1 else
                            "%d ranks, flat 138.9 MB fp32 gradient all-reduced with RCCL inside every step" % world),
             "ms_per_step": 1e3 * tdt, "mel_frames_per_s": TB * Tm * world / tdt, "steps": nst, "rccl_ranks": rccl_ranks, "rccl_rank": rccl_rank,
+            "accumulation": "deterministic = 1 (train.py's default, the reference's TF_DETERMINISTIC_OPS=1, /root/reference/train.py:17-32): every "
+                            "gradient accumulated in a fixed order; `atomic_mode_ms_per_step` is the same step with float atomics (deterministic = 0)",
+            "atomic_mode_ms_per_step": 1e3 * tdt_atomic, "batch_per_rank": TB, "global_batch": TB * world,
             "world_size_env": world, "roofline": troof,
             "kernel_launches_per_step": launches_per_step,
             "approx_tflops": 3.0 * ALG_GFLOP_S1 * (TB / S1["B"]) * world * 1e9 / tdt / 1e12,

@@ -1,7 +1,11 @@
 """Training step on the GPU (vnr_train_step) against the autograd restatement (oracle/vaenar_torch.py, float64):
 losses, the gradient of EVERY trainable variable, and the Adam update (train.py:127-138)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import kinks
 from oracle.vaenar_torch import TorchOracle, adam_step
@@ -193,3 +197,53 @@ def test_deterministic_training_mode():
             assert np.array_equal(ws[k], runs[0][1][k]), "variable %s differs after two deterministic optimizer steps" % k
         for k in sorted(gs[1]):
             assert np.array_equal(gs[1][k], runs[0][0][1][k]), k
+
+
+_FORK_CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from vaenar_tts_amd.configs import tiny_hps
+from vaenar_tts_amd.models import VAENAR
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights
+hps = tiny_hps()
+w = init_weights(hps, seed=31, mode="synthetic")
+b = make_batch(3, 13, 44, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, seed=3, text_step=3, mel_step=7)
+r = np.random.Generator(np.random.PCG64(4))
+mels = r.standard_normal((3, 44, hps.Audio.num_mels)).astype(np.float32)
+eps = r.standard_normal((3, 22, hps.Common.latent_dim)).astype(np.float32)
+m = VAENAR(hps, weights=w)
+m.engine.set_option("deterministic", 1)
+out = []
+for rep in range(3):
+    m.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, eps=eps, dropout_seed=5, apply_update=False)
+    g = m.gradients()
+    out.append({k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] for k, v in g.items()})
+enc = {k: float(np.abs(v).max()) for k, v in g.items() if k.startswith("text_encoder/")}
+print(json.dumps({"digests": out, "enc_max": enc}))
+m.engine.close()
+"""
+
+
+def _fork_child(env_extra):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ); env.update(env_extra)
+    cp = subprocess.run([sys.executable, "-c", _FORK_CHILD % ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    return json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_decoder_branch_stays_on_the_main_stream_without_the_stacked_projection():
+    """the decoder branch may leave the main stream only while the stacked cross K | V projection is active.
+    Without it (VNR_TRAIN_NO_KV_STACK=1) every decoder block adds its own data gradient into the text encoding's gradient; forked, that
+    raced with the prior's blocks and with the arena clear -- text-encoder gradients wrong and irreproducible, silently.  Child
+    processes (the switches are read once per process): deterministic mode, three identical steps each -- the un-stacked run must be
+    reproducible and agree bit for bit with the one-stream schedule."""
+    a = _fork_child({"VNR_TRAIN_NO_KV_STACK": "1"})
+    b = _fork_child({"VNR_TRAIN_NO_KV_STACK": "1", "VNR_TRAIN_ONE_STREAM": "1"})
+    assert a["digests"][0] == a["digests"][1] == a["digests"][2]
+    assert a["digests"][0] == b["digests"][0]
+    assert all(v > 0 for v in a["enc_max"].values())

@@ -4,11 +4,15 @@ import struct, sys
 import numpy as np
 data = open(sys.argv[1], "rb").read(); off = 0; seen = {}
 while off < len(data):
-    M, D, ns, nw = struct.unpack_from("4i", data, off); off += 16
+    M, Dw, ns, nw = struct.unpack_from("4i", data, off); off += 16
     ts = np.frombuffer(data, dtype=np.uint64, count=nw * 128, offset=off).reshape(nw, 128).astype(np.int64); off += nw * 1024
-    seen[(M, D, ns)] = ts
-for (M, D, ns), ts in seen.items():
-    print("M=%d D=%d stages=%d wgs=%d   lifetime median %.1f kcyc" % (M, D, ns, len(ts), np.median(ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3))
+    seen[(M, Dw, ns)] = ts
+for (M, Dw, ns), ts in seen.items():
+    D, ali, att = Dw & 0xffff, (Dw >> 16) & 1, Dw >> 20        # (round 5: the header's D word carries the fused-attention flags)
+    print("M=%d D=%d stages=%d wgs=%d%s   lifetime median %.1f kcyc" % (M, D, ns, len(ts), (" attention in front of stage %d%s" % (att, " + alignments" if ali else "")) if att else "",
+                                                                       np.median(ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3))
+    if att and ts[:, 61].any():
+        print("  attention phase: %.2f kcyc (inside stage %d's \"loop\" figure below)" % (np.median(ts[:, 61] - ts[:, 60]) / 1e3, att))
     print("  panel load: %.2f kcyc" % (np.median(ts[:, 1] - ts[:, 0]) / 1e3))
     tl = te = 0.0
     for s in range(ns):

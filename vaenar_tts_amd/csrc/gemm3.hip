@@ -200,6 +200,7 @@ panel_chain_kernel(const ChainArgs g) {
     int tid_s = tid;
     asm volatile("" : "+v"(tid_s));
     if (RT == 1 && g.att_stage > 0 && si == g.att_stage) {
+      stamp(60);                                                       // attention phase begins (the previous stage's barrier is behind)
       // ================= fused cross-attention of this panel (see ChainArgs::att_stage) ===================================
       // wave w: head = w >> 1, key blocks 2 (w & 1) and 2 (w & 1) + 1 (32 keys each, Tk <= 128).  Per block, as attn3_kernel:
       // S^T = K.Q^T (lane = query row: softmax statistics in-lane + one half swap), logits in the log2 domain, online softmax
@@ -386,6 +387,7 @@ panel_chain_kernel(const ChainArgs g) {
           lds_barrier();                                               // the scratch is the next pass's merge area again
         }
       }
+      stamp(61);                                                       // attention (and alignment) phase ends
     }
     const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
     const bool wave_on = 32 * wave < st.n;               // this wave owns output columns 32w .. 32w+31
@@ -801,7 +803,7 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     FILE* f = fopen(ts_path, "ab");
-    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 128)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    if (f) { int hdr[4] = {g.M, g.D | (g.att_stage > 0 ? (g.att_stage << 20) : 0) | (g.att_ali ? (1 << 16) : 0), g.nstages, (int)(n / 128)}; /* D <= 256: flags above bit 15 */ fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
   vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, g);

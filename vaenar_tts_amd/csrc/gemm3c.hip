@@ -204,6 +204,7 @@ panel_chain4_kernel(const ChainArgs g) {
     int tid_s = tid;
     asm volatile("" : "+v"(tid_s));
     if (g.att_stage > 0 && si == g.att_stage) {
+      stamp(60);                                                       // attention phase begins
       // ================= fused cross-attention of this panel (ChainArgs::att_stage) ========================================
       // wave = head (D = 256: four heads).  Per 32-key block, as attn3_kernel: S^T = K.Q^T (lane = query row: softmax statistics
       // in-lane + one half swap), logits in the log2 domain, online softmax over the blocks, O^T += V^T.P^T.  The context replaces
@@ -352,6 +353,7 @@ panel_chain4_kernel(const ChainArgs g) {
         }
       }
       lds_barrier4();                                                  // the context panel is complete for every wave
+      stamp(61);                                                       // attention (and alignment) phase ends
     }
     const ChainStage st = g.st[si];                      // by value: one scalar burst from the kernarg segment per stage
     const bool wave_on = 64 * wave < st.n;               // this wave owns output columns 64w .. 64w+63 (column blocks 2w, 2w+1)
@@ -758,7 +760,7 @@ hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     FILE* f = fopen(ts_path, "ab");
-    if (f) { int hdr[4] = {g.M, g.D, g.nstages, (int)(n / 128)}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
+    if (f) { int hdr[4] = {g.M, g.D | (g.att_stage > 0 ? (g.att_stage << 20) : 0) | (g.att_ali ? (1 << 16) : 0), g.nstages, (int)(n / 128)}; /* D <= 256: flags above bit 15 */ fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
   vnr_launch(panel_chain4_kernel, dim3(wgs), dim3(256), lds, s, g);

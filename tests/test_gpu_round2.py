@@ -446,3 +446,40 @@ def test_blocks_without_alignments_fused_and_unfused(B, Tt, Tm, text_step):
         assert launches[0] - launches[1] >= 2 * 12, launches        # 12 prior blocks + 2 decoder blocks, two launches saved each
     finally:
         model.engine.close()
+
+
+def test_train_harness_on_tfrecords_with_test_synthesis(tmp_path):
+    """F3 on the GPU: `{train,dev,test}-*.tfrecords` whose Examples were encoded by the protobuf LIBRARY
+    (tests/tf_protos.py -- not this repository's codec) feed `train.py --data_dir` (/root/reference/train.py:81-110,
+    datasets/tf_record_utils.py:108-142): one epoch with the init step, the dev pass and a checkpoint, then the periodic test
+    synthesis of the reference's main loop (train.py:308-325: test_step -> TestUtils.synthesize_and_save_wavs): predicted mels and
+    Griffin-Lim wavs of one test batch on disk."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_tf_formats import write_tfrecords_with_protobuf_library
+    hps = tiny_hps()
+    r = np.random.Generator(np.random.PCG64(12))
+    items = []
+    for i in range(14):
+        n = 6 + i % 5
+        text = np.concatenate([[1], r.integers(3, hps.Encoder.Transformer.vocab_size, n), [2]]).astype(np.int64)      # int64 text, float64 mels
+        items.append(("utt%02d" % i, text, 0.5 * r.standard_normal((int(4.2 * len(text)) + i % 3, hps.Audio.num_mels))))
+    rec_dir = tmp_path / "records"
+    write_tfrecords_with_protobuf_library(str(rec_dir), {"train": items[:8], "dev": items[8:12], "test": items[12:]})
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--dataset", "tiny", "--data_dir", str(rec_dir), "--model_dir", str(tmp_path / "model"),
+           "--log_dir", str(tmp_path / "log"), "--test_dir", str(tmp_path / "test"), "--test_interval", "1", "--epochs", "1", "--batch_size", "4",
+           "--seed", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2000:])
+    so = out.stdout
+    assert "Initial step" in so and "Training Epoch 1," in so and "dev-total" in so and "Saved checkpoint for epoch" in so
+    steps = [ln for ln in so.splitlines() if ln.startswith("Step ")]
+    assert len(steps) == 2                                       # 8 training utterances in global batches of 4
+    vals = [float(x) for ln in steps for x in __import__("re").findall(r"-?\d+\.\d+", ln.rsplit(", time", 1)[0])]
+    assert np.isfinite(vals).all()
+    assert "Testing ..." in so and "All wavs for test are synthesized!" in so and "test finished" in so
+    made = sorted(os.listdir(tmp_path / "test"))
+    assert [f for f in made if f.endswith(".wav")] == ["test-utt12-1.wav", "test-utt13-1.wav"], made
+    assert [f for f in made if f.endswith(".npy")] == ["test-utt12-1.npy", "test-utt13-1.npy"], made
+    mel = np.load(tmp_path / "test" / "test-utt12-1.npy")
+    assert mel.shape == (items[12][2].shape[0], hps.Audio.num_mels) and np.isfinite(mel).all()
+    assert os.path.getsize(tmp_path / "test" / "test-utt12-1.wav") > 1000

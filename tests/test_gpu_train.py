@@ -247,3 +247,21 @@ def test_decoder_branch_stays_on_the_main_stream_without_the_stacked_projection(
     assert a["digests"][0] == a["digests"][1] == a["digests"][2]
     assert a["digests"][0] == b["digests"][0]
     assert all(v > 0 for v in a["enc_max"].values())
+
+
+def test_train_step_refuses_inverse_flows_by_name():
+    """Prior.Transformer.inverse = True (/root/reference/modules/flow.py:36-47,76-113, prior.py:88-99; no shipped configuration sets it) is
+    honoured by every inference / evaluation / init entry point (tests/test_b2_surface.py) but not by the training step: the refusal must
+    say so -- an explicit error naming the option, never a silently different gradient."""
+    from vaenar_tts_amd import _lib
+    hps = tiny_hps()
+    m = VAENAR(hps, weights=init_weights(hps, seed=3, mode="synthetic"))
+    try:
+        m.engine.set_option("prior_inverse", 1)
+        b = make_batch(2, 9, 24, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, seed=2, text_step=2, mel_step=5)
+        mels = np.zeros((2, 24, hps.Audio.num_mels), np.float32)
+        with pytest.raises(_lib.VnrError) as ei:
+            m.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, dropout_seed=1)
+        assert "inverse" in str(ei.value).lower()
+    finally:
+        m.engine.close()

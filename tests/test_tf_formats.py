@@ -368,3 +368,134 @@ def test_multi_shard_bundles_and_stale_state_entries(tmp_path):
     # re-saving an existing prefix: whole again afterwards, and the index is replaced only behind the data
     tc.write_checkpoint(os.path.join(mdir, "ckpt-1"), {"x": b})
     assert tc.bundle_is_complete(os.path.join(mdir, "ckpt-1")) and np.array_equal(tc.read_checkpoint(os.path.join(mdir, "ckpt-1"))["x"], b)
+
+
+# ---- cross-check against a third-party protobuf implementation (google.protobuf; tests/tf_protos.py builds TensorFlow's messages from
+#      the published field numbers) -- VERDICT round 4 #6: the hand-rolled codecs were pinned by their own round trips and a few KATs only --------
+def _rand_items(n=4, seed=3):
+    r = np.random.Generator(np.random.PCG64(seed))
+    return [("LJ%03d-%04d" % (i, 7 * i), r.integers(1, 43, 3 + 2 * i).astype(np.int64), r.standard_normal((5 + 3 * i, 80))) for i in range(n)]
+
+
+def test_example_codec_against_the_protobuf_library():
+    """tf.train.Example / tf.io.serialize_tensor both ways: the library's bytes parse with tf_record_utils, tf_record_utils' bytes
+    parse with the library; the serialized tensors inside agree byte for byte."""
+    from tf_protos import P, example, tensor_proto
+    w = tfr.TFRecordWriter()
+    for fid, text, mel in _rand_items():
+        lib_bytes = example(fid, text, mel).SerializeToString(deterministic=True)
+        got = w.parse_example(lib_bytes)                                   # library -> ours
+        assert got[0] == fid.encode() and got[3] == len(text) and got[4] == mel.shape[0]
+        assert np.array_equal(got[1], text.astype(np.int32)) and np.array_equal(got[2], mel.astype(np.float32))
+        ours = tfr.TFRecordWriter.serialize_example(fid, text, mel, len(text), mel.shape[0])
+        ex = P["Example"].FromString(ours)                                 # ours -> library
+        f = ex.features.feature
+        assert sorted(f) == ["fid", "mel", "mel_len", "text", "text_len"]
+        assert f["fid"].bytes_list.value[0] == fid.encode() and f["text_len"].int64_list.value[0] == len(text)
+        assert f["mel_len"].int64_list.value[0] == mel.shape[0]
+        t = P["TensorProto"].FromString(f["mel"].bytes_list.value[0])
+        assert t.dtype == 2 and [d.size for d in t.tensor_shape.dim] == list(mel.shape)
+        assert np.array_equal(np.frombuffer(t.tensor_content, "<f8").reshape(mel.shape), mel)
+        t = P["TensorProto"].FromString(f["text"].bytes_list.value[0])
+        assert t.dtype == 9 and np.array_equal(np.frombuffer(t.tensor_content, "<i8"), text)
+        # (no byte equality for the Example itself: protobuf does not define the order of map entries -- TensorFlow's C++ writer emits
+        #  them in hash order -- which is why both directions are PARSED; the map-free TensorProto below is compared byte for byte)
+        assert tfr.serialize_tensor(mel) == tensor_proto(mel).SerializeToString()
+    # value-list forms a TensorFlow writer may also produce: int64_val / float_val / double_val instead of tensor_content
+    t = P["TensorProto"](); t.dtype = 9; t.tensor_shape.dim.add().size = 3; t.int64_val.extend([5, -2, 1 << 40])
+    assert np.array_equal(tfr.parse_tensor(t.SerializeToString()), np.array([5, -2, 1 << 40], np.int64))
+    t = P["TensorProto"](); t.dtype = 2; t.tensor_shape.dim.add().size = 2; t.double_val.extend([0.5, -1.25])
+    assert np.array_equal(tfr.parse_tensor(t.SerializeToString()), np.array([0.5, -1.25]))
+
+
+def test_bundle_entry_and_header_against_the_protobuf_library(tmp_path):
+    """tensor_bundle.proto: every BundleEntryProto / the BundleHeaderProto our writer puts into the index parse with the library to the
+    values written, and entries the library encodes parse with our reader."""
+    from tf_protos import P
+    from vaenar_tts_amd import tf_checkpoint as ck
+    r = np.random.Generator(np.random.PCG64(1))
+    tensors = {"model/a/.ATTRIBUTES/VARIABLE_VALUE": r.standard_normal((3, 5)).astype(np.float32),
+               "model/b/c/.ATTRIBUTES/VARIABLE_VALUE": r.standard_normal((7,)).astype(np.float32),
+               "step/.ATTRIBUTES/VARIABLE_VALUE": np.int64(12)}
+    prefix = str(tmp_path / "ckpt-1")
+    ck.write_checkpoint(prefix, tensors)
+    index = dict(ck.read_index(prefix + ".index"))
+    hdr = P["BundleHeaderProto"].FromString(index[b""])
+    assert hdr.num_shards == 1 and hdr.endianness == 0 and hdr.version.producer == 1
+    data = open(prefix + ".data-00000-of-00001", "rb").read()
+    for key, arr in tensors.items():
+        e = P["BundleEntryProto"].FromString(index[key.encode()])
+        assert e.dtype == {np.dtype("float32"): 1, np.dtype("int64"): 9}[np.asarray(arr).dtype]
+        assert [d.size for d in e.shape.dim] == list(np.shape(arr)) and e.shard_id == 0 and e.size == np.asarray(arr).nbytes
+        raw = data[e.offset:e.offset + e.size]
+        assert np.array_equal(np.frombuffer(raw, np.asarray(arr).dtype).reshape(np.shape(arr)), arr)
+        assert e.crc32c == ck._mask(crc32c(raw))
+        # library -> ours
+        mine = ck._parse_entry(e.SerializeToString())
+        assert (mine["dtype"], mine["shape"], mine["shard_id"], mine["offset"], mine["size"], mine["crc32c"]) == \
+               (e.dtype, list(np.shape(arr)), 0, e.offset, e.size, e.crc32c)
+    # and the whole bundle still reads back through the reader
+    back = ck.read_checkpoint(prefix)
+    assert all(np.array_equal(back[k], v) for k, v in tensors.items())
+
+
+def test_object_graph_against_the_protobuf_library():
+    """trackable_object_graph.proto: the graph our writer emits parses with the library into the node / child / attribute / slot
+    structure tf.train.Checkpoint(step, optimizer, model) expects, and a graph the library encodes parses with our reader."""
+    from tf_protos import P
+    from vaenar_tts_amd import tf_checkpoint as ck
+    paths = ["decoder/pre_projection/kernel", "decoder/pre_projection/bias", "prior/glow/0/1/weight"]
+    buf = ck.object_graph_proto(paths, extra=("step", "optimizer/iter"), slots=[(paths[0], "m"), (paths[0], "v")])
+    g = P["TrackableObjectGraph"].FromString(buf)
+    names = {}
+
+    def walk(nid, prefix):
+        for ch in g.nodes[nid].children:
+            names[ch.node_id] = prefix + [ch.local_name]
+            walk(ch.node_id, prefix + [ch.local_name])
+    walk(0, [])
+    keys = {a.checkpoint_key for n in g.nodes for a in n.attributes}
+    for p in paths:
+        assert "model/%s/.ATTRIBUTES/VARIABLE_VALUE" % p in keys
+        assert any("/".join(v) == "model/" + p for v in names.values())
+    assert "step/.ATTRIBUTES/VARIABLE_VALUE" in keys and "optimizer/iter/.ATTRIBUTES/VARIABLE_VALUE" in keys
+    opt = next(i for i, v in names.items() if v == ["optimizer"])
+    slots = [(s.original_variable_node_id, s.slot_name, s.slot_variable_node_id) for s in g.nodes[opt].slot_variables]
+    assert sorted(s[1] for s in slots) == ["m", "v"]
+    for orig, slot, nid in slots:
+        assert "/".join(names[orig]) == "model/" + paths[0]
+        assert g.nodes[nid].attributes[0].checkpoint_key == "model/%s/.OPTIMIZER_SLOT/optimizer/%s/.ATTRIBUTES/VARIABLE_VALUE" % (paths[0], slot)
+    assert all(a.name == "VARIABLE_VALUE" for n in g.nodes for a in n.attributes)
+    # library -> ours: re-encode with the library (its own field order / lengths) and read with parse_object_graph
+    mine = ck.parse_object_graph(g.SerializeToString(), with_slots=True)
+    assert len(mine) == len(g.nodes)
+    for (children, attrs, sl), n in zip(mine, g.nodes):
+        assert children == [(c.node_id, c.local_name) for c in n.children]
+        assert attrs == [(a.name, a.full_name, a.checkpoint_key) for a in n.attributes]
+        assert sl == [(s.original_variable_node_id, s.slot_name, s.slot_variable_node_id) for s in n.slot_variables]
+
+
+def write_tfrecords_with_protobuf_library(save_dir, items_by_mode, train_split=2):
+    """{train,dev}-*.tfrecords as the reference's writer lays them out (datasets/tf_record_utils.py:84-94), every Example encoded by the
+    protobuf LIBRARY (tests/tf_protos.py); only the record framing (length, masked CRC-32C) is this repository's."""
+    from tf_protos import example
+    os.makedirs(save_dir, exist_ok=True)
+    for mode, items in items_by_mode.items():
+        parts = [items[i::train_split] for i in range(train_split)] if mode == "train" else [items]
+        for i, part in enumerate(parts):
+            tfr.TFRecordWriter.write_records(os.path.join(save_dir, "%s-%d.tfrecords" % (mode, i)),
+                                             (example(fid, text, mel).SerializeToString() for fid, text, mel in part))
+
+
+def test_tfrecords_written_by_the_protobuf_library_feed_create_dataset(tmp_path):
+    items = _rand_items(6, seed=9)
+    write_tfrecords_with_protobuf_library(str(tmp_path), {"train": items[:4], "dev": items[4:]})
+    rec = tfr.TFRecordWriter(save_dir=str(tmp_path))
+    got = list(rec.create_dataset(16, 2, 2, 2, 80, 8, False, rec.get_tfrecords_list("train"), seed=1))
+    assert sum(len(b[3]) for b in got) == 4
+    by_fid = {fid.encode(): (text, mel) for fid, text, mel in items}
+    for fids, texts, mels, tl, ml in got:
+        for j, fid in enumerate(fids):
+            text, mel = by_fid[bytes(fid)]
+            assert tl[j] == len(text) and ml[j] == mel.shape[0]
+            assert np.array_equal(texts[j, :tl[j]], text.astype(np.int32)) and np.array_equal(mels[j, :ml[j]], mel.astype(np.float32))

@@ -66,6 +66,8 @@ def main():
     ap.add_argument('--data_dir', type=str, default='synthetic')
     ap.add_argument('--model_dir', type=str, default='gpurun_out/model_dir')
     ap.add_argument('--log_dir', type=str, default='gpurun_out/log_dir')
+    ap.add_argument('--test_dir', type=str, default=None, help='directory to save test results (default <log_dir>/test)')
+    ap.add_argument('--test_interval', type=int, default=None, help='epochs between test syntheses (default hps.Train.test_interval = 50)')
     ap.add_argument('--epochs', type=int, default=2, help='the reference trains hps.Train.epochs = 2000')
     ap.add_argument('--steps_per_epoch', type=int, default=4, help='synthetic data only')
     ap.add_argument('--batch_size', type=int, default=None, help='GLOBAL batch (default hps.Train.train_batch_size)')
@@ -80,6 +82,8 @@ def main():
     rank, local_rank, world = vdist.init()
     seed = hps.Train.random_seed if args.seed is None else args.seed
     os.makedirs(args.model_dir, exist_ok=True)
+    test_dir = args.test_dir or os.path.join(args.log_dir, 'test')
+    test_interval = args.test_interval or hps.Train.test_interval
     gb = args.batch_size or hps.Train.train_batch_size
     assert gb % world == 0, "global batch must divide over the ranks"
 
@@ -87,19 +91,23 @@ def main():
     if args.data_dir == 'synthetic':
         train = synthetic_batches(hps, args.steps_per_epoch, gb, args.t_text, args.t_mel, seed)
         dev = synthetic_batches(hps, 1, gb, args.t_text, args.t_mel, seed + 1000)
+        test = synthetic_batches(hps, 1, hps.Train.test_batch_size, args.t_text, args.t_mel, seed + 2000)
+        for b in test:
+            b["fids"] = ["synthetic%02d" % i for i in range(len(b["text_lengths"]))]
     else:                                                     # the reference's TFRecord files (tf_record_utils.py)
         from vaenar_tts_amd.tf_record_utils import TFRecordWriter
         rec = TFRecordWriter(save_dir=args.data_dir)
 
         def load(mode, bs, shuffle):
             out = []
-            for _, texts, mels, tl, ml in rec.create_dataset(
+            for _f, texts, mels, tl, ml in rec.create_dataset(
                     hps.Dataset.buffer_size, hps.Dataset.num_parallel_reads, hps.Dataset.pad_factor, bs, hps.Audio.num_mels,
                     hps.Train.shuffle_buffer, shuffle, rec.get_tfrecords_list(mode), seed=seed):
-                if len(tl) == bs:                             # the data-parallel shards need full batches
-                    out.append({"ids": texts, "mels": mels, "text_lengths": tl, "mel_lengths": ml})
+                if len(tl) == bs or mode == 'test':           # the data-parallel shards need full batches
+                    out.append({"fids": _f, "ids": texts, "mels": mels, "text_lengths": tl, "mel_lengths": ml})
             return out
         train, dev = load('train', gb, hps.Train.shuffle), load('dev', gb, False)
+        test = load('test', hps.Train.test_batch_size, False) if rec.get_tfrecords_list('test') else []      # train.py:102-110
     train = [vdist.shard_batch(b, rank, world) for b in train]
     dev = [vdist.shard_batch(b, rank, world) for b in dev]
 
@@ -182,6 +190,22 @@ def main():
         if rank == 0:
             print("Saved checkpoint for epoch {}: {}".format(step, path))
         step += 1
+        if epoch % test_interval == 0 and rank == 0 and test:     # train.py:308-325: test_step -> wavs (+ the predicted mels) of ONE test batch
+            print('Testing ...')
+            from vaenar_tts_amd.audio.utils import TestUtils
+            os.makedirs(test_dir, exist_ok=True)
+            tester = TestUtils(hps, test_dir, engine=model.engine)
+            tb = test[0]
+            mel, _ali = model.inference(tb["ids"], tb["mel_lengths"], tb["text_lengths"], reduction_factor=rf)      # test_step, train.py:163-171
+            mel = mel.numpy()
+            ml = np.minimum(np.asarray(tb["mel_lengths"]), mel.shape[1])
+            try:
+                tester.synthesize_and_save_wavs(epoch, mel, ml, tb["fids"], 'test')
+            except Exception as e:                             # (the reference swallows everything here, train.py:317-318)
+                print('Something wrong with the generated waveform! ({})'.format(e))
+            tester.write_mels(epoch, mel, ml, tb["fids"], 'test')  # (the reference draws spectrograms / alignments with matplotlib: out of scope)
+            print('test finished, check {} for the results'.format(test_dir))
+        vdist.barrier()
     vdist.barrier()
     model.engine.close()
 

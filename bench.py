@@ -402,6 +402,8 @@ def run_rank(args):
             "profiled_pass_ms_per_step": profiled_ms_per_step,      # wall time of the pass the per-kernel numbers were taken on (>= kernel_ms_sum)
         }
         out["device"] = eng.device_info()
+        from vaenar_tts_amd import _lib as _vl
+        out["device"]["gpu_max_hw_queues"] = _vl.HW_QUEUES          # (the effective stream -> hardware-queue setting is part of the record)
         out["kernel_source_digest"] = kernel_source_digest()
         # ---- host-to-host latency of ONE call (ids on the host -> mel on the host), one batch in flight ----
         lat = []

@@ -361,10 +361,15 @@ def test_multi_shard_bundles_and_stale_state_entries(tmp_path):
     tc.write_checkpoint(os.path.join(mdir, "ckpt-2"), {"x": b})
     with open(os.path.join(mdir, "ckpt-2.data-00000-of-00001"), "wb") as f:
         f.write(b"\0")                                                # a save that died inside the data file
-    open(os.path.join(mdir, "ckpt-3.tmp123.index"), "wb").write(b"junk")
+    import subprocess, sys
+    dead = subprocess.Popen([sys.executable, "-c", "pass"]); dead.wait()             # a pid that no longer exists: its temporaries are leftovers
+    open(os.path.join(mdir, "ckpt-3.tmp%d.index" % dead.pid), "wb").write(b"junk")
+    live = os.path.join(mdir, "ckpt-4.tmp%d.index" % os.getpid())                     # a LIVE writer's file (another rank saving right now) stays
+    open(live, "wb").write(b"in flight")
     open(os.path.join(mdir, "checkpoint"), "w").write('model_checkpoint_path: "ckpt-2"\nall_model_checkpoint_paths: "ckpt-1"\nall_model_checkpoint_paths: "ckpt-2"\n')
     m = tc.CheckpointManager(mdir)
-    assert m.latest_checkpoint.endswith("ckpt-1") and not glob.glob(os.path.join(mdir, "*.tmp*"))
+    assert m.latest_checkpoint.endswith("ckpt-1") and glob.glob(os.path.join(mdir, "*.tmp*")) == [live]
+    os.remove(live)
     # re-saving an existing prefix: whole again afterwards, and the index is replaced only behind the data
     tc.write_checkpoint(os.path.join(mdir, "ckpt-1"), {"x": b})
     assert tc.bundle_is_complete(os.path.join(mdir, "ckpt-1")) and np.array_equal(tc.read_checkpoint(os.path.join(mdir, "ckpt-1"))["x"], b)

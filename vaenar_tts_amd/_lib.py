@@ -5,6 +5,7 @@ visible when an engine is created, an exception is raised.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -118,6 +119,7 @@ PROTOTYPES = {
 }
 
 _lib = None
+HW_QUEUES = None        # {value, set_by, hip_possibly_initialised_before} once load() has run
 
 
 def load():
@@ -130,7 +132,22 @@ def load():
     # RCCL): with the default, a fourth handle already lands on the queue of another one -- three batches in flight took 2.2 ms per
     # S1 batch instead of 1.6 as soon as a fourth engine existed in the process (profiles/r04_experiments.txt).  Read by the HIP runtime
     # when it initialises, i.e. at the first engine; a value the caller has set wins.
+    global HW_QUEUES
+    preset = os.environ.get("GPU_MAX_HW_QUEUES")
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # The setting only counts if the HIP runtime has not initialised yet.  A profiler's preloaded library (rocprofv3 --pmc ...) or another
+    # HIP user in the process initialises it BEFORE this line runs: the collection scripts therefore export the variable themselves
+    # (tools/collect_profiles_r05.sh), and this is said out loud instead of letting a profiled run use another queue mapping silently.
+    early = [m for m in ("torch",) if m in sys.modules and getattr(sys.modules[m], "cuda", None) is not None
+             and sys.modules[m].cuda.is_initialized()]
+    if os.environ.get("LD_PRELOAD", "").find("rocprof") >= 0 or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"):
+        early.append("a profiler's preloaded library")
+    HW_QUEUES = {"value": os.environ["GPU_MAX_HW_QUEUES"], "set_by": "caller" if preset is not None else "vaenar_tts_amd._lib.load()",
+                 "hip_possibly_initialised_before": early}
+    if preset is None and early:
+        import warnings
+        warnings.warn("GPU_MAX_HW_QUEUES was not set in the environment and %s may have initialised HIP already: the engine's streams may share "
+                      "hardware queues (export GPU_MAX_HW_QUEUES=8 in front of the command)" % ", ".join(early))
     if not os.path.exists(LIB_PATH):
         raise VnrError(
             "libvaenar_hip.so not found at %s -- build it with `python __graft_entry__.py` or "

@@ -70,8 +70,10 @@ inline void vnr_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned
 // of that stream (the finish kernel of launch i precedes the producer of launch i + 1 in stream order).
 struct DetState {
   std::map<hipStream_t, std::pair<void*, size_t>> bufs;
-  std::vector<void*> retired;                              // outgrown buffers: possibly still read by kernels in flight, freed with the context
-  void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); for (void* p : retired) (void)hipFree(p); bufs.clear(); retired.clear(); }
+  std::vector<void*> retired;                              // outgrown buffers: possibly still read by kernels in flight; freed once the step has synchronised
+  bool alloc_failed = false;                               // a scratch allocation failed: the launcher fell back to float atomics -- the step reports it
+  void release_retired() { for (void* p : retired) (void)hipFree(p); retired.clear(); }
+  void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); release_retired(); bufs.clear(); }
 };
 inline thread_local DetState* g_det = nullptr;
 inline void* det_scratch(hipStream_t s, size_t bytes) {
@@ -80,7 +82,7 @@ inline void* det_scratch(hipStream_t s, size_t bytes) {
   if (b.second < bytes) {
     void* p = nullptr;
     const size_t cap = bytes < ((size_t)16 << 20) ? ((size_t)16 << 20) : bytes + bytes / 2;
-    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { g_det->alloc_failed = true; return nullptr; }      // (vnr_train_step turns this into VNR_ERR_NOMEM)
     if (b.first) g_det->retired.push_back(b.first);
     b = {p, cap};
   }

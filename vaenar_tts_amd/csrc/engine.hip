@@ -2143,6 +2143,11 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
                                  kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
   g_det = nullptr;
   h->split_scope = saved_split; h->training = saved_training; h->in_train_step = false;
+  if (h->det.alloc_failed) {                               // never lose bit-reproducibility silently under memory pressure
+    h->det.alloc_failed = false;
+    return fail(h, VNR_ERR_NOMEM, "deterministic mode: a scratch buffer for ordered partial sums could not be allocated -- that launch fell back to "
+                                  "float atomics, so this step is NOT bit-reproducible (free device memory or set deterministic = 0)");
+  }
   if (rc == VNR_OK && !h->packed_stale) TRY(refresh_bn_affine(h));      // moving statistics moved
   return rc;
 }

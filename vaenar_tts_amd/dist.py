@@ -32,7 +32,10 @@ def env_rank():
 
 
 def _job_key(addr, port, world):
-    return hashlib.sha256(("%s:%d:%d" % (addr, port, world)).encode()).digest()[:16]
+    # (address, port and world size are not secret: the launcher's run id -- torchrun exports TORCHELASTIC_RUN_ID -- or VNR_JOB_SECRET is
+    #  mixed in when present, so that a host that merely knows the rendezvous cannot join as a rank)
+    secret = os.environ.get("VNR_JOB_SECRET") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    return hashlib.sha256(("%s:%d:%d:%s" % (addr, port, world, secret)).encode()).digest()[:16]
 
 
 def _send(sock, payload):
@@ -49,9 +52,22 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
+_MAX_MESSAGE = 1 << 31           # a gathered mel batch is tens of MB; anything beyond 2 GiB is a corrupt or hostile length word
+
+
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_MESSAGE:
+        raise ConnectionError("control plane: message length %d exceeds the %d-byte cap" % (n, _MAX_MESSAGE))
     return _recv_exact(sock, n)
+
+
+def _exchange_timeout():
+    """Seconds an exchange waits for a peer (VNR_CTL_TIMEOUT, default 1800: longer than any step or checkpoint write; 0 = forever)."""
+    try:
+        return float(os.environ.get("VNR_CTL_TIMEOUT", "1800"))
+    except ValueError:
+        return 1800.0
 
 
 def init(backend=None, timeout=300.0):
@@ -71,7 +87,7 @@ def init(backend=None, timeout=300.0):
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost") else "", p))
+                s.bind((addr if addr != "localhost" else "127.0.0.1", p))      # MASTER_ADDR's interface only, never every interface
                 s.listen(world + 8)
                 srv = s
                 break
@@ -150,15 +166,27 @@ def _exchange(payload, combine):
     if not is_initialized():
         out = combine([payload])
         return out[0] if isinstance(out, dict) else out
+    tmo = _exchange_timeout() or None
     if _state["hub"]:
         peers = _state["peers"]
-        parts = [payload] + [_recv(peers[r]) for r in range(1, _state["world"])]
+        parts = [payload]
+        for r in range(1, _state["world"]):
+            peers[r].settimeout(tmo)
+            try:
+                parts.append(_recv(peers[r]))
+            except socket.timeout:
+                raise TimeoutError("control plane: rank %d did not reach the exchange within %.0f s (VNR_CTL_TIMEOUT)" % (r, tmo))
         out = combine(parts)
         for r in range(1, _state["world"]):
             _send(peers[r], out[r] if isinstance(out, dict) else out)
         return out[0] if isinstance(out, dict) else out
+    _state["sock"].settimeout(tmo)
     _send(_state["sock"], payload)
-    return _recv(_state["sock"])
+    try:
+        return _recv(_state["sock"])
+    except socket.timeout:
+        raise TimeoutError("control plane: rank %d got no answer from rank 0 within %.0f s (a rank is missing from the exchange; "
+                           "VNR_CTL_TIMEOUT)" % (_state["rank"], tmo))
 
 
 def shard_bounds(n, rank, world):

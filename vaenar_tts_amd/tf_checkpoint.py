@@ -507,7 +507,22 @@ class CheckpointManager:
         self.directory, self.max_to_keep, self.name = directory, max_to_keep, checkpoint_name
         os.makedirs(directory, exist_ok=True)
         import glob
-        for f in glob.glob(os.path.join(directory, checkpoint_name + "-*.tmp*")):      # leftovers of a save that died before its renames
+        import re
+        # leftovers of a save that died before its renames: `<name>-N.tmp<pid>.*` -- removed only when that process no longer exists (every
+        # rank builds a manager on the same directory: a late starter must not delete rank 0's save in flight)
+        for f in glob.glob(os.path.join(directory, checkpoint_name + "-*.tmp*")):
+            m = re.search(r"\.tmp(\d+)\.", os.path.basename(f))
+            alive = False
+            if m:
+                try:
+                    os.kill(int(m.group(1)), 0)
+                    alive = True
+                except ProcessLookupError:
+                    alive = False
+                except OSError:                       # (exists but is not ours to signal)
+                    alive = True
+            if alive:
+                continue
             try:
                 os.remove(f)
             except OSError:

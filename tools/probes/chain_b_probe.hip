@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(NW * 64) kS(const char* w, unsigned long long*
 // slots of a stage are not issued in the k-loop -- where every load instruction blocks its wave at the address unit's queue -- but
 // in the epilogue, where the vector-memory path is otherwise idle: SPREAD = 0 all at once behind the k-loop, SPREAD = 1 one piece
 // per dependent LDS round trip of the epilogue.
-template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0>
+template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0, int LAYOUT = 0>
 __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out, float* sink) {
   constexpr int NW = 4, CT = 2, DEPTH = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,7 +127,11 @@ __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out
   h8 wr[DEPTH][CT][4];
   int fk = 0;                                            // k-tile index of the NEXT stage's slot 0 (advanced per stage)
   auto piece = [&](int u, int j, int i) {
-    wr[u][j][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(lane * 16), (((fk + u) % IMG_TILES) * 8 + wave * CT + j) * 4096 + i * 1024, 0));
+    // LAYOUT 0: [k-tile][column block] -- the 8 column blocks of a k-tile round are 32 KiB of contiguous memory.
+    // LAYOUT 1: the engine's operand-major image, [stage][column block][k-tile]: a wave's blocks are 32 KiB apart, the waves 64 KiB
+    const int kt = (fk + u) % IMG_TILES;
+    const int tile = LAYOUT == 0 ? kt * 8 + wave * CT + j : (kt >> 3) * 64 + (wave * CT + j) * 8 + (kt & 7);
+    wr[u][j][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(lane * 16), tile * 4096 + i * 1024, 0));
   };
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u)
@@ -257,12 +261,12 @@ __global__ void __launch_bounds__(256) kP(const char* w, unsigned long long* out
   if (keep == 1234.5f) sink[0] = keep;
 }
 
-template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0>
+template <int EPI, int DEFER, int SPREAD, int ORDER = 0, int SWZ = 0, int LAYOUT = 0>
 static void runP(const char* name, const char* w, unsigned long long* out, float* sink) {
   const int lds = 2 * 8 * 4096 + 4096;
-  hipFuncSetAttribute((const void*)kP<EPI, DEFER, SPREAD, ORDER, SWZ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute((const void*)kP<EPI, DEFER, SPREAD, ORDER, SWZ, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   for (int wgs : {200}) {
-    for (int rep = 0; rep < 3; ++rep) { kP<EPI, DEFER, SPREAD, ORDER, SWZ><<<wgs, 256, lds>>>(w, out, sink); hipDeviceSynchronize(); }
+    for (int rep = 0; rep < 3; ++rep) { kP<EPI, DEFER, SPREAD, ORDER, SWZ, LAYOUT><<<wgs, 256, lds>>>(w, out, sink); hipDeviceSynchronize(); }
     std::vector<unsigned long long> h(wgs * 8 * 3); hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
     std::vector<double> tot, lp, ep;
     for (int b = 0; b < wgs; ++b) {
@@ -346,5 +350,9 @@ int main(int argc, char** argv) {
   printf("-- ORDER 2 with the real kernel's per-tile A addressing (swizzle arithmetic on the VALU, clamps / panel select on the SALU)\n");
   runP<0, 0, 0, 2, 1>("EPI  0, ORDER 2, swizzled A addresses", w, out, sink);
   runP<12, 0, 0, 2, 1>("EPI 12, ORDER 2, swizzled A addresses", w, out, sink);
+  printf("-- ORDER 2, weight image in the ENGINE's layout [column block][k-tile] (a k-tile round reads 8 blocks 32 KiB apart) against [k-tile][column block]\n");
+  runP<0, 0, 0, 2, 0, 0>("EPI  0, [k-tile][column block] (contiguous round)", w, out, sink);
+  runP<0, 0, 0, 2, 0, 1>("EPI  0, [column block][k-tile] (engine layout)", w, out, sink);
+  runP<12, 0, 0, 2, 0, 1>("EPI 12, [column block][k-tile] (engine layout)", w, out, sink);
   return 0;
 }

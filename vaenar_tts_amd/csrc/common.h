@@ -296,6 +296,9 @@ struct ChainArgs {
   int cpl_lds;                                 // (set by launch_panel_chain) byte offset of the shift exchange scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
+  unsigned* pf_progress;        // L2 warming (chain_prefetch.h): device words [8 XCDs][16] the workers publish their stage in; null = no prefetch workgroups
+  unsigned pf_epoch;            // this launch's number on that array (monotonic per engine handle)
+  int pf_wgs;                   // (set by launch_panel_chain) prefetch workgroups appended to the grid
   int vt_lds;                   // (set by launch_panel_chain, waves4 only) byte offset of the V-stage transpose scratch [4 waves][32][33] fp32 in LDS
   int waves4;                   // 1: the one-wave-per-SIMD kernel (gemm3c.hip: 4 waves x 64 columns, 8 k-tiles in flight; 32-row panels only), 0: panel_chain_kernel
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage

@@ -2,6 +2,7 @@
 // stream, and the extern "C" ABI declared in include/vaenar_hip.h.
 #include "../../include/vaenar_hip.h"
 #include "common.h"
+#include <chrono>
 
 #include <dlfcn.h>
 #include <math.h>
@@ -137,6 +138,8 @@ struct vnr_context {
   int train_chain_bwd = 1;           // engine option "train_chain_bwd": the backward of the same blocks as two backward-chain launches (gemm3b.hip)
   int train_chain = 1;               // engine option "train_chain" (train.inc: xblk_chain): 0 off, 1 auto, 2 / 3 force 64- / 32-row panels
   bool attn_bwd_recompute = false;   // engine option "attn_bwd_recompute" (train.inc: attn)
+  bool chain_prefetch = true;    // engine option "chain_prefetch": prefetch workgroups on the CUs a chain launch leaves idle warm the XCDs' L2 ahead of the workers (chain_prefetch.h)
+  unsigned* chain_progress = nullptr; unsigned chain_epoch = 0;   // their pacing words [8 XCDs][16] and the launch counter
   bool chain_waves4 = false;     // engine option "chain_waves4": 32-row chain launches on the one-wave-per-SIMD kernel (gemm3c.hip); 0 = the 8-wave kernel of rounds 1-4
   bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
   bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
@@ -340,6 +343,10 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   TRY(chain_params(h, g));
   g.rows64 = h->chain_rows64 ? 1 : 0;
   g.waves4 = (h->chain_waves4 && !h->chain_rows64) ? 1 : 0;
+  // (measured: the 4-wave kernel's k-loops wait on first-touch L2 misses, -13 % with the prefetchers; the 8-wave kernel's do not, +-0 %;
+  //  64-row panels = several batches in flight: the idle CUs belong to them)
+  g.pf_progress = (h->chain_prefetch && g.waves4 && !h->chain_rows64) ? h->chain_progress : nullptr;
+  g.pf_epoch = ++h->chain_epoch;
   // bytes of a launch that also writes alignments: the attention core's own traffic as SURVEY D3 counts it (Q + K, V + context +
   // alignments) -- Q and the context never reach HBM here, the figure is what a stand-alone core would move
   const double ali_bytes = (g.att_stage > 0 && g.att_ali)
@@ -1540,10 +1547,17 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
   h->cfg = *cfg;
   h->device = device;
   if (const char* e = getenv("VNR_CHAIN_ROWS64")) h->chain_rows64 = atoi(e) != 0;
-  if (const char* e = getenv("VNR_CHAIN_WAVES4")) h->chain_waves4 = atoi(e) != 0;      // test / measurement override of the option's default
+  if (const char* e = getenv("VNR_CHAIN_WAVES4")) h->chain_waves4 = atoi(e) != 0;
+  if (const char* e = getenv("VNR_CHAIN_PREFETCH")) h->chain_prefetch = atoi(e) != 0;      // test / measurement override of the option's default
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return fail(nullptr, VNR_ERR_HIP, "hipSetDevice / hipStreamCreate failed");
+  }
+  if (hipMalloc((void**)&h->chain_progress, 1024) != hipSuccess || hipMemset(h->chain_progress, 0, 1024) != hipSuccess) {
+    if (h->chain_progress) hipFree(h->chain_progress);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return fail(nullptr, VNR_ERR_NOMEM, "hipMalloc of the chain kernels' pacing words failed");
   }
   *out = h;
   return VNR_OK;
@@ -1562,6 +1576,7 @@ int vnr_destroy(vnr_handle h) {
   for (auto& kv : h->pe_cache) hipFree(kv.second);
   for (auto& kv : h->voc_tables) hipFree(kv.second);
   if (h->survey_words) hipFree(h->survey_words);
+  if (h->chain_progress) hipFree(h->chain_progress);
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
@@ -2476,6 +2491,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "split_rows")) { h->split_rows = value != 0; return VNR_OK; }
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_waves4")) { h->chain_waves4 = value != 0; return VNR_OK; }
+  if (!strcmp(name, "chain_prefetch")) { h->chain_prefetch = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain_bwd")) { h->train_chain_bwd = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain")) { if (value < 0 || value > 3) return fail(h, VNR_ERR_ARG, "train_chain: 0..3"); h->train_chain = value; return VNR_OK; }

@@ -15,6 +15,7 @@
 //     inside the phase).
 // Selected by ChainArgs::waves4 (engine option "chain_waves4", default on; 32-row panels only).
 #include "common.h"
+#include "chain_prefetch.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -56,6 +57,10 @@ panel_chain4_kernel(const ChainArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    const int nworkers = (g.M + kRows - 1) / kRows;          // L2 warming (chain_prefetch.h)
+    if ((int)blockIdx.x >= nworkers) { chain_prefetch_role(g, ((int)blockIdx.x - nworkers) >> 3, (g.pf_wgs + 7) >> 3); return; }
+  }
   const int m0 = blockIdx.x * kRows;
   auto panel_ptr = [&](int i) -> char* { return smem + kPOff + i * kPanelBytes; };
   float* scratch = reinterpret_cast<float*>(smem);
@@ -78,11 +83,11 @@ panel_chain4_kernel(const ChainArgs g) {
   __amdgpu_buffer_rsrc_t frs;
   auto open_stage = [&](int s_) {
     const ChainStage& st = g.st[s_];
-    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.prio_mode == 8 ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((g.prio_mode == 8 && g.D == 256) ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
     fnk = st.nk;
     fpad = (st.nk + kDepth - 1) / kDepth * kDepth;
     // (measurement only, VNR_CHAIN_PRIO=8: every stage reads the first 256 KiB of stage 0's image -- L2-resident, not L1-resident, wrong results)
-    const int ktt = g.prio_mode == 8 ? 8 : st.kt_total, k0 = g.prio_mode == 8 ? 0 : st.kt0;
+    const int ktt = (g.prio_mode == 8 && g.D == 256) ? 8 : st.kt_total, k0 = (g.prio_mode == 8 && g.D == 256) ? 0 : st.kt0;
     fvoff0 = (64 * wave < st.n) ? (unsigned)(((2 * wave) * ktt + k0) * 4096 + lane * 16) : kOob3;
     fvoff1 = (64 * wave + 32 < st.n) ? (unsigned)(((2 * wave + 1) * ktt + k0) * 4096 + lane * 16) : kOob3;
   };
@@ -102,7 +107,7 @@ panel_chain4_kernel(const ChainArgs g) {
     }
     // (measurement only, VNR_CHAIN_PRIO=9: every weight read goes to the stage's first k-tile -- L1-resident, wrong results;
     //  VNR_CHAIN_PRIO=8: the first 8 k-tiles of stage 0's image -- L2-resident, wrong results)
-    fsoff = g.prio_mode == 9 ? 0 : (g.prio_mode == 8 ? 0 : fk * 4096);
+    fsoff = g.prio_mode == 9 ? 0 : ((g.prio_mode == 8 && g.D == 256) ? 0 : fk * 4096);
   };
   auto piece = [&](int u, int j, int i) {
     const unsigned v = vo[u < 2 ? 0 : (u < 4 ? 1 : 2)][j];
@@ -203,6 +208,7 @@ panel_chain4_kernel(const ChainArgs g) {
     const int half = lane_s >> 5, l31 = lane_s & 31;
     int tid_s = tid;
     asm volatile("" : "+v"(tid_s));
+    if (tid == 0) chain_publish_stage(g, si);               // (chain_prefetch.h)
     if (g.att_stage > 0 && si == g.att_stage) {
       stamp(60);                                                       // attention phase begins
       // ================= fused cross-attention of this panel (ChainArgs::att_stage) ========================================
@@ -754,7 +760,7 @@ hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
-    vnr_launch(panel_chain4_kernel, dim3(wgs), dim3(256), lds, s, gg);
+    vnr_launch(panel_chain4_kernel, dim3(wgs + gg.pf_wgs), dim3(256), lds, s, gg);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hbuf(n);
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -763,7 +769,7 @@ hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
     if (f) { int hdr[4] = {g.M, g.D | (g.att_stage > 0 ? (g.att_stage << 20) : 0) | (g.att_ali ? (1 << 16) : 0), g.nstages, (int)(n / 128)}; /* D <= 256: flags above bit 15 */ fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
-  vnr_launch(panel_chain4_kernel, dim3(wgs), dim3(256), lds, s, g);
+  vnr_launch(panel_chain4_kernel, dim3(wgs + g.pf_wgs), dim3(256), lds, s, g);
   return hipGetLastError();
 }
 

@@ -437,7 +437,7 @@ def run_rank(args):
         out["exact_fp32"] = {"ms_per_step": exact_ms, "max_abs_mel_diff_vs_split": float(_np.abs(mel_e.numpy() - mel.numpy()).max()),
                              "note": "engine option split_fp16=0: every GEMM / attention product on v_mfma_f32_32x32x2_f32; max_abs_mel_err "
                                      "against the fp32 oracle is in `parity` (split path) and below (exact path)"}
-        out["_mel_exact"] = mel_e
+        out["_mel_exact"] = _HostArray(mel_e.numpy())            # (host copy: the engines are closed before the CPU baseline runs)
     # ---- side block: several independent batches in flight on one GPU (every rank; rank 0 reports) --------------------------
     if args.in_flight > 1 and nstreams == 1:
         extra = [make_lane(si, True) for si in range(args.in_flight)]
@@ -452,6 +452,7 @@ def run_rank(args):
         for ln in extra:
             ln["model"].engine.close()
 
+    mel = _HostArray(mel.numpy()) if hasattr(mel, "numpy") and rank == 0 else mel      # host copy for the CPU baseline (the engines close first)
     # (the training blocks run BEFORE the CPU baseline: that leg imports torch, whose bundled RCCL then answers the engine's dlopen of
     #  librccl.so and fails to initialise a communicator -- seen on the first round-5 run of the one-rank data-parallel block)
     if not args.no_train:
@@ -490,6 +491,15 @@ def run_rank(args):
     if world > 1:
         vdist.barrier()
         vdist.shutdown()
+
+
+class _HostArray:
+    """A host ndarray behind the `.numpy()` of a device array (the CPU-baseline leg runs after every engine has been closed)."""
+    def __init__(self, a):
+        self._a = a
+
+    def numpy(self):
+        return self._a
 
 
 def cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact=None):

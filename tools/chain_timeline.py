@@ -23,6 +23,8 @@ for (M, Dw, ns), ts in seen.items():
     print("  sum of loops %.1f, of epilogues %.1f kcyc" % (tl, te))
     w = ts[:, 64:128].reshape(len(ts), 8, 8)
     if w[:, :, 0].any():
+        nzw = w[:, :, 0].any(axis=0)                          # (the 4-wave kernel stamps four waves)
+        w = w[:, nzw, :]
         base = w[:, :, 0].min(axis=1, keepdims=True)
-        for i, name in ((0, "stage start"), (1, "loop end"), (4, "values ready"), (2, "after LN / in-place barrier"), (5, "outputs issued"), (3, "stage end (barrier)")):
+        for i, name in ((0, "stage start"), (1, "loop end"), (4, "values ready"), (6, "residual / PE added"), (7, "row statistics ready"), (2, "after LN / in-place barrier"), (5, "outputs issued"), (3, "stage end (barrier)")):
             print("  per wave %-28s" % name, " ".join("%6.2f" % x for x in np.median(w[:, :, i] - base, axis=0) / 1e3))

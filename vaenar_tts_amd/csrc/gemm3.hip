@@ -10,7 +10,6 @@
 // 3-term hi/lo split with fp32 accumulation (fp32-class accuracy, see gemm2.hip).  FFN hidden activations never
 // touch HBM: the hidden layer is produced and consumed in chunks of <= 256 columns.
 #include "common.h"
-#include "chain_prefetch.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -68,11 +67,8 @@ panel_chain_kernel(const ChainArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  {
-    // L2 warming (chain_prefetch.h): blocks behind the row panels run ahead through the weight images on the CUs this launch leaves idle
-    const int nworkers = (g.M + ROWS - 1) / ROWS;
-    if ((int)blockIdx.x >= nworkers) { chain_prefetch_role(g, ((int)blockIdx.x - nworkers) >> 3, (g.pf_wgs + 7) >> 3); return; }
-  }
+  // (the L2-warming prefetch workgroups of chain_prefetch.h serve the 4-wave kernel only: measured +-0 for this one, and its stage loop is
+  //  better off without the per-stage progress word -- launch_panel_chain gives this kernel no prefetch blocks)
   const int m0 = blockIdx.x * ROWS;
   auto panel_ptr = [&](int i) -> char* { return smem + P_OFF + i * PANEL_BYTES; };
   float* scratch = reinterpret_cast<float*>(smem);
@@ -101,17 +97,16 @@ panel_chain_kernel(const ChainArgs g) {
   __amdgpu_buffer_rsrc_t frs;
   auto open_stage = [&](int s_) {
     const ChainStage& st = g.st[s_];
-    // (measurement only, VNR_CHAIN_PRIO=8: every stage reads the first 8 k-tiles of stage 0's image -- L2-resident, wrong results)
-    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((g.prio_mode == 8 && g.D == 256) ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(st.w), 0, 0x40000000, 0x00020000);
     fnk = st.nk;
     fpad = (st.nk + PF - 1) / PF * PF;
-    fvoff = (32 * wave < st.n) ? (unsigned)((wave * ((g.prio_mode == 8 && g.D == 256) ? 8 : st.kt_total) + ((g.prio_mode == 8 && g.D == 256) ? 0 : st.kt0)) * 4096 + lane * 16) : kOob3;
+    fvoff = (32 * wave < st.n) ? (unsigned)((wave * st.kt_total + st.kt0) * 4096 + lane * 16) : kOob3;
   };
   auto fetch = [&](int u) {
     const unsigned vo = (fk < fnk) ? fvoff : kOob3;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      wreg[u][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, ((g.prio_mode == 8 && g.D == 256) ? (fk & 7) : fk) * 4096 + i * 1024, 0));
+      wreg[u][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, vo, fk * 4096 + i * 1024, 0));
     if (++fk == fpad) {
       fk = 0;
       if (fs + 1 < g.nstages) { ++fs; open_stage(fs); } else { fnk = 0; }      // past the end: dummy (out-of-range) refills
@@ -206,7 +201,6 @@ panel_chain_kernel(const ChainArgs g) {
     const int half = lane_s >> 5, l31 = lane_s & 31;
     int tid_s = tid;
     asm volatile("" : "+v"(tid_s));
-    if (tid == 0) chain_publish_stage(g, si);               // (chain_prefetch.h: the prefetch workgroups of this XCD pace themselves on it)
     if (RT == 1 && g.att_stage > 0 && si == g.att_stage) {
       stamp(60);                                                       // attention phase begins (the previous stage's barrier is behind)
       // ================= fused cross-attention of this panel (see ChainArgs::att_stage) ===================================
@@ -805,7 +799,7 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);
     gg.dbg_ts = d;
-    vnr_launch(panel_chain_kernel<RT>, dim3(wgs + gg.pf_wgs), dim3(512), lds, s, gg);
+    vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, gg);
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hbuf(n);
     (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -814,7 +808,7 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
     if (f) { int hdr[4] = {g.M, g.D | (g.att_stage > 0 ? (g.att_stage << 20) : 0) | (g.att_ali ? (1 << 16) : 0), g.nstages, (int)(n / 128)}; /* D <= 256: flags above bit 15 */ fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
-  vnr_launch(panel_chain_kernel<RT>, dim3(wgs + g.pf_wgs), dim3(512), lds, s, g);
+  vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, g);
   return hipGetLastError();
 }
 
@@ -831,7 +825,7 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
     const int rows = g.rows64 ? 64 : 32, wgs = (g.M + rows - 1) / rows;
     int idle = ncu - wgs;
     idle = idle < 0 ? 0 : (idle > 56 ? 56 : idle);
-    g.pf_wgs = g.pf_progress ? (idle & ~7) : 0;
+    g.pf_wgs = (g.pf_progress && g.waves4 && !g.rows64) ? (idle & ~7) : 0;     // (the 4-wave kernel only)
     if (!g.pf_wgs) g.pf_progress = nullptr;
   }
   if (g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;

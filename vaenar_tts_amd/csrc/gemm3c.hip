@@ -631,6 +631,7 @@ panel_chain4_kernel(const ChainArgs g) {
         for (int q = 0; q < 4; ++q)
           if (!cok[j][q]) v[j][4 * q] = v[j][4 * q + 1] = v[j][4 * q + 2] = v[j][4 * q + 3] = 0.f;
     }
+    wstamp(si, 6);                                       // (finer epilogue stamps, measurement) residual / PE added
     if (st.gamma && st.out_pre) {                                       // training: x + Dense(.) before the normalisation
       const int row = m0 + l31;
       if (row < g.M) {
@@ -664,6 +665,7 @@ panel_chain4_kernel(const ChainArgs g) {
             m2 += d * d;
           }
       m2 += __shfl_xor(m2, 32, 64);
+      wstamp(si, 7);                                     // row statistics of this wave's columns ready
       if (half == 0) { scratch[l31 * 4 + wave] = s1; scratch[kRows * 4 + l31 * 4 + wave] = m2; }
       lds_barrier4();
       const float* lnp = prm + st.lds_ln;                               // gamma [256] | beta [256]

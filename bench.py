@@ -487,6 +487,14 @@ def run_rank(args):
     out.pop("_exact_err", None)
 
     if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio at communicator creation (the one-rank
+        # block above, every N > 1 run), which sits in libc's buffer until exit when stdout is a pipe or a file -- flush it out first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if world > 1:
         vdist.barrier()

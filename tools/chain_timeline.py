@@ -6,14 +6,24 @@ data = open(sys.argv[1], "rb").read(); off = 0; seen = {}
 while off < len(data):
     M, Dw, ns, nw = struct.unpack_from("4i", data, off); off += 16
     ts = np.frombuffer(data, dtype=np.uint64, count=nw * 128, offset=off).reshape(nw, 128).astype(np.int64); off += nw * 1024
-    seen[(M, Dw, ns)] = ts
+    seen[(M, Dw, ns)] = ts[ts[:, 63] < 1000]               # (rows of prefetch workgroups carry 1000 + rank in slot 63: tools/r05_ts_xcd.py reads them)
 for (M, Dw, ns), ts in seen.items():
     D, ali, att = Dw & 0xffff, (Dw >> 16) & 1, Dw >> 20        # (round 5: the header's D word carries the fused-attention flags)
     print("M=%d D=%d stages=%d wgs=%d%s   lifetime median %.1f kcyc" % (M, D, ns, len(ts), (" attention in front of stage %d%s" % (att, " + alignments" if ali else "")) if att else "",
                                                                        np.median(ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3))
+    life = (ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3
+    print("  lifetime p10 %.1f  p90 %.1f  max %.1f kcyc" % (np.percentile(life, 10), np.percentile(life, 90), life.max()))
+    # s_memtime counts per XCD (different bases): spans only within workgroup index mod 8
+    xs = [np.arange(len(ts)) % 8 == x for x in range(8)]
+    print("  by XCD (workgroup mod 8): median lifetime " + " ".join("%6.1f" % np.median(life[m]) for m in xs))
+    print("                            start spread    " + " ".join("%6.1f" % ((ts[m, 0].max() - ts[m, 0].min()) / 1e3) for m in xs))
+    print("                            first start -> last end " + " ".join("%6.1f" % ((ts[m, 1 + 2 * ns].max() - ts[m, 0].min()) / 1e3) for m in xs))
     if att and ts[:, 61].any():
         print("  attention phase: %.2f kcyc (inside stage %d's \"loop\" figure below)" % (np.median(ts[:, 61] - ts[:, 60]) / 1e3, att))
     print("  panel load: %.2f kcyc" % (np.median(ts[:, 1] - ts[:, 0]) / 1e3))
+    if ts[:, 56].any():                                       # (4-wave kernel: sub-phases)
+        print("    row reads issued +%.2f, weight head issued +%.2f, parameter DMA issued + panels zeroed +%.2f, rows converted +%.2f, first weights in +%.2f kcyc" % tuple(
+            np.median(ts[:, b] - ts[:, a]) / 1e3 for a, b in ((0, 56), (56, 59), (59, 57), (57, 58), (58, 1))))
     tl = te = 0.0
     for s in range(ns):
         loop = np.median(ts[:, 2 + 2 * s] - ts[:, 1 + 2 * s]) / 1e3

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f -- python3 bench.py --st
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w -- python3 bench.py --steps 2 --warmup 1 --profile-steps 1 $P > $O/pw.log 2>&1
 python3 tools/pmc_traffic.py $(ls $O/pf/*.db $O/pf/*/*.db 2>/dev/null | head -1) $(ls $O/pw/*.db $O/pw/*/*.db 2>/dev/null | head -1) --json profiles/${R}_hbm_traffic.json > $O/hbm_traffic_pmc.txt
 cp profiles/${R}_hbm_traffic.json $O/hbm_traffic.json
-python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 bench.py > $O/bench.out 2> $O/bench.err; grep "^{" $O/bench.out | tail -1 > $O/bench.json
 rocprofv3 --kernel-trace --stats -d $O/kt -o b -- python3 bench.py --steps 10 --warmup 3 $P > $O/kt.log 2>&1
 python3 tools/rocpd_summary.py $(ls $O/kt/*.db $O/kt/*/*.db 2>/dev/null | head -1) > $O/kernel_stats.txt
 rocprofv3 --kernel-trace --stats -d $O/tr -o t -- python3 tools/bench_train.py 32 3 > $O/train.log 2>&1

@@ -2,7 +2,7 @@
 # round 5: A/B of environment / option settings on ONE box.  usage: r05_ab.sh "<label>|<env assignments>|<bench args>" ...
 # prints ms per S1 step and the kernel-class times (dispatch events) of each setting, alternating twice
 mkdir -p gpurun_out/r05
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for cfg in "$@"; do
   IFS='|' read -r label envs bargs <<< "$cfg"
   line=$(env $envs python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train --no-exact-pass --in-flight 0 --no-attn-phase $bargs 2>&1 | grep '^{' | tail -1)

@@ -296,6 +296,8 @@ struct ChainArgs {
   int cpl_lds;                                 // (set by launch_panel_chain) byte offset of the shift exchange scratch in LDS
   unsigned long long* dbg_ts;   // measurement only: [wgs][128] s_memtime stamps (start, panels, loop/epilogue per stage; [64 + 8 wave + i]: stage dbg_stage per wave)
   int dbg_stage;
+  int seg_T;                    // > 0 (4-wave kernel, M % seg_T == 0): rows per batch element; every element's panels start at its first row
+                                // (ceil(seg_T / 32) workgroups per element, the last one short) instead of M / 32 flat panels
   unsigned* pf_progress;        // L2 warming (chain_prefetch.h): device words [8 XCDs][16] the workers publish their stage in; null = no prefetch workgroups
   unsigned pf_epoch;            // this launch's number on that array (monotonic per engine handle)
   int pf_wgs;                   // (set by launch_panel_chain) prefetch workgroups appended to the grid
@@ -304,6 +306,10 @@ struct ChainArgs {
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage
   ChainStage st[kMaxChainStages];
 };
+// worker workgroups of a chain launch (panels of `rows` rows)
+inline __host__ __device__ int chain_workers(const ChainArgs& g, int rows) {
+  return g.seg_T > 0 ? (g.M / g.seg_T) * ((g.seg_T + rows - 1) / rows) : (g.M + rows - 1) / rows;
+}
 hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);
 hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s);      // gemm3c.hip; called by launch_panel_chain (which validates the program and lays out the LDS)
 

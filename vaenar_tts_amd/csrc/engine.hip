@@ -138,9 +138,10 @@ struct vnr_context {
   int train_chain_bwd = 1;           // engine option "train_chain_bwd": the backward of the same blocks as two backward-chain launches (gemm3b.hip)
   int train_chain = 1;               // engine option "train_chain" (train.inc: xblk_chain): 0 off, 1 auto, 2 / 3 force 64- / 32-row panels
   bool attn_bwd_recompute = false;   // engine option "attn_bwd_recompute" (train.inc: attn)
+  bool chain_segments = true;    // engine option "chain_segments": panels of a fused-attention chain launch start at batch-element boundaries (ChainArgs::seg_T; 4-wave kernel)
   bool chain_prefetch = true;    // engine option "chain_prefetch": prefetch workgroups on the CUs a chain launch leaves idle warm the XCDs' L2 ahead of the workers (chain_prefetch.h)
   unsigned* chain_progress = nullptr; unsigned chain_epoch = 0;   // their pacing words [8 XCDs][16] and the launch counter
-  bool chain_waves4 = false;     // engine option "chain_waves4": 32-row chain launches on the one-wave-per-SIMD kernel (gemm3c.hip); 0 = the 8-wave kernel of rounds 1-4
+  bool chain_waves4 = true;      // engine option "chain_waves4": 32-row chain launches on the one-wave-per-SIMD kernel (gemm3c.hip); 0 = the 8-wave kernel of rounds 1-4
   bool fuse_xattn = true;        // engine option "fuse_xattn": chain B + cross-attention + chain C of a block as ONE launch when no alignments are requested
   bool split_rows = true;        // engine option "split_rows": conv stacks pass their activations as pre-split fp16 hi|lo rows (no conversion in the k-loops)
   bool aoi_self = true;          // engine option "attn_presplit_self": the same for the causal self-attention Q|K|V
@@ -700,6 +701,7 @@ int run_xblk(vnr_handle h, const XBlk& k, const float* x, float* out, const floa
       c.att_K = ka->d.qk + (size_t)kv_blk * ka->d.blk_bytes; c.att_V = ka->d.vt + (size_t)kv_blk * ka->d.blk_bytes;
       c.att_qlen = q_len; c.att_klen = m_len; c.att_Tq = Tq; c.att_Tk = Tt; c.att_B = B; c.att_temp = tau;
       c.att_ali = ali;                                     // (then the context is left in panel 2: the alignment pass needs the queries once more)
+      if (h->chain_segments && (Tq & 31)) c.seg_T = Tq;    // no panel straddles two batch elements: the attention phase runs once in every workgroup
     }
     ChainStage* s = &c.st[n++];
     s->w = r_p2.opm; s->kt_total = r_p2.kt_total; s->kt0 = 0; s->nk = 2 * PT; s->n = D; s->a0 = 0; s->a1 = (fused && ali) ? 2 : 1; s->asw = PT; s->bias = k.proj2_b; s->act = ACT_IDENTITY;
@@ -1548,6 +1550,7 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
   h->device = device;
   if (const char* e = getenv("VNR_CHAIN_ROWS64")) h->chain_rows64 = atoi(e) != 0;
   if (const char* e = getenv("VNR_CHAIN_WAVES4")) h->chain_waves4 = atoi(e) != 0;
+  if (const char* e = getenv("VNR_CHAIN_SEGMENTS")) h->chain_segments = atoi(e) != 0;
   if (const char* e = getenv("VNR_CHAIN_PREFETCH")) h->chain_prefetch = atoi(e) != 0;      // test / measurement override of the option's default
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -2492,6 +2495,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "fuse_xattn")) { h->fuse_xattn = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_waves4")) { h->chain_waves4 = value != 0; return VNR_OK; }
   if (!strcmp(name, "chain_prefetch")) { h->chain_prefetch = value != 0; return VNR_OK; }
+  if (!strcmp(name, "chain_segments")) { h->chain_segments = value != 0; return VNR_OK; }
   if (!strcmp(name, "attn_bwd_recompute")) { h->attn_bwd_recompute = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain_bwd")) { h->train_chain_bwd = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_chain")) { if (value < 0 || value > 3) return fail(h, VNR_ERR_ARG, "train_chain: 0..3"); h->train_chain = value; return VNR_OK; }

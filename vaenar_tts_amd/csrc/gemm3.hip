@@ -816,18 +816,6 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
   ChainArgs g = g_in;
   static const int prio_mode = getenv("VNR_CHAIN_PRIO") ? atoi(getenv("VNR_CHAIN_PRIO")) : 1;
   g.prio_mode = prio_mode;
-  {
-    // prefetch workgroups on the CUs the row panels leave idle: whole groups of 8 (one per XCD), at most 7 per XCD
-    static int cus[kMaxDevices] = {0};
-    int dev = 0; (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < kMaxDevices && !cus[dev]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus[dev] = pr.multiProcessorCount; }
-    const int ncu = (dev >= 0 && dev < kMaxDevices && cus[dev] > 0) ? cus[dev] : 256;
-    const int rows = g.rows64 ? 64 : 32, wgs = (g.M + rows - 1) / rows;
-    int idle = ncu - wgs;
-    idle = idle < 0 ? 0 : (idle > 56 ? 56 : idle);
-    g.pf_wgs = (g.pf_progress && g.waves4 && !g.rows64) ? (idle & ~7) : 0;     // (the 4-wave kernel only)
-    if (!g.pf_wgs) g.pf_progress = nullptr;
-  }
   if (g.M <= 0 || g.D <= 0 || (g.D & 31) || g.D > 256 || g.nstages <= 0 || g.nstages > kMaxChainStages) return hipErrorInvalidValue;
   int nln = 0;
   for (int i = 0; i < g.nstages; ++i) {
@@ -890,23 +878,58 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
       const ChainStage& st = g.st[i];
       const bool ok = (st.nk == 4 && st.akt0 == 0 && st.asw >= st.nk) || (!(st.nk & 7) && !(st.akt0 & 1) && (st.asw >= st.nk || !(st.asw & 7)));
       if (!ok) g.waves4 = 0;
+      // (the 4-wave kernel serves inference programs: no pre-normalisation / statistics outputs of the training chains; its image
+      //  stores address the three Q | K | V images through ONE 2 GiB buffer descriptor)
+      if (st.out_pre || st.out_stats || (st.out && st.out_fmt != 0 && 3 * st.aoi_img_bytes > 0x7f000000ll)) g.waves4 = 0;
     }
     if (g.D != 256 && g.D != 128) g.waves4 = 0;
   }
-  if (g.waves4) {                                       // gemm3c.hip turns the V-type stages of a Q|K|V tail through LDS: wave-private 32 x 33 floats
+  if (g.waves4) {                                       // gemm3c.hip turns the V-type stages of a Q|K|V tail through LDS: wave-private 2 x 32 x 33 floats
     bool anyv = false;
+    int firstv = -1;
     for (int i = 0; i < g.nstages; ++i) {
       const ChainStage& st = g.st[i];
-      anyv = anyv || (st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) && st.acc_mode == 0 &&
-                      st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY);
+      const bool isv = st.out_fmt == 4 && st.out && st.aoi_c0 >= 2 * st.aoi_D && !((st.aoi_c0 - 2 * st.aoi_D) & 31) && !(st.aoi_T & 15) && st.acc_mode == 0 &&
+                       st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY;
+      if (isv && firstv < 0) firstv = i;
+      anyv = anyv || isv;
     }
     g.vt_lds = 0;
     if (anyv) {
-      if (g.att_stage > 0) g.vt_lds = g.att_lds;          // (the attention phase is over by then; its scratch is twice the size)
-      else { g.vt_lds = (lds + 15) & ~15; lds = g.vt_lds + 4 * 32 * 33 * 4; }
+      const int need = 4 * 2 * 32 * 33 * 4;
+      if (g.att_stage > 0 && firstv > g.att_stage) g.vt_lds = g.att_lds;       // (the attention phase is over by then; its scratch is the same size)
+      else if (g.cpl_stage > 0 && firstv > g.cpl_stage && g.cpl_lds != g.att_lds) {   // ... or the coupling's exchange area, grown to fit (a panel barrier lies between)
+        g.vt_lds = g.cpl_lds;
+        if (lds < g.cpl_lds + need) lds = g.cpl_lds + need;
+      }
+      else { g.vt_lds = (lds + 15) & ~15; lds = g.vt_lds + need; }
     }
   }
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  {
+    // prefetch workgroups on the CUs the row panels leave idle: whole groups of 8 (one per XCD), at most 7 per XCD
+    static int cus[kMaxDevices] = {0};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < kMaxDevices && !cus[dev]) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus[dev] = pr.multiProcessorCount; }
+    const int ncu = (dev >= 0 && dev < kMaxDevices && cus[dev] > 0) ? cus[dev] : 256;
+    const int rows = g.rows64 ? 64 : 32;
+    // segmented panels: the 4-wave kernel only, whole batch elements, and not when they would cost another round of workgroups
+    if (!g.waves4 || g.rows64 || g.seg_T <= 0 || g.M % g.seg_T || !(g.seg_T & 31) ||
+        (chain_workers(g, rows) + ncu - 1) / ncu > ((g.M + rows - 1) / rows + ncu - 1) / ncu) g.seg_T = 0;
+    const int wgs = chain_workers(g, rows);
+    int idle = ncu - wgs;
+    idle = idle < 0 ? 0 : (idle > 56 ? 56 : idle);
+    g.pf_wgs = (g.pf_progress && g.waves4 && !g.rows64) ? (idle & ~7) : 0;     // (the 4-wave kernel only)
+    if (!g.pf_wgs) g.pf_progress = nullptr;
+  }
+  if (lds > 160 * 1024 && g.waves4) {                  // the 4-wave kernel's extra scratch does not fit: the 8-wave kernel takes the program
+    ChainArgs g8 = g_in;
+    g8.waves4 = 0;
+    return launch_panel_chain(g8, s);
+  }
+  if (lds > 160 * 1024) {
+    if (getenv("VNR_CHAIN_DEBUG")) fprintf(stderr, "panel chain: %d bytes of LDS (stages %d, D %d, attention %d, coupling %d, waves4 %d)\n", lds, g.nstages, g.D, g.att_stage, g.cpl_stage, g.waves4);
+    return hipErrorInvalidValue;
+  }
   if (g.waves4) return launch_chain4(g, lds, s);
   return launch_chain_rt<1>(g, lds, s);
 }

@@ -24,6 +24,8 @@ namespace vnr {
 
 namespace {
 constexpr unsigned kOob3 = 0x80000000u;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds3_t;
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
@@ -58,17 +60,29 @@ panel_chain4_kernel(const ChainArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {
-    const int nworkers = (g.M + kRows - 1) / kRows;          // L2 warming (chain_prefetch.h)
-    if ((int)blockIdx.x >= nworkers) { chain_prefetch_role(g, ((int)blockIdx.x - nworkers) >> 3, (g.pf_wgs + 7) >> 3); return; }
+    const int nworkers = chain_workers(g, kRows);            // L2 warming (chain_prefetch.h)
+    if ((int)blockIdx.x >= nworkers) { chain_prefetch_role(g, ((int)blockIdx.x - nworkers) >> 3, (g.pf_wgs + 7) >> 3, g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 128 : nullptr); return; }
   }
-  const int m0 = blockIdx.x * kRows;
+  // rows [m0, mend) of this workgroup.  Segmented launches (ChainArgs::seg_T): the panels of a batch element start at its first row,
+  // so no panel straddles two elements (the fused attention would run once per element: 8 of 200 workgroups of an S1 block launch
+  // -- T = 400 = 12.5 panels -- took 14 kcyc longer than the rest, and a launch lasts as long as its slowest workgroup)
+  int m0 = blockIdx.x * kRows, mend = g.M;
+  if (g.seg_T > 0) {
+    const int ppb = (g.seg_T + kRows - 1) / kRows, b = (int)blockIdx.x / ppb;
+    m0 = b * g.seg_T + ((int)blockIdx.x - b * ppb) * kRows;
+    mend = (b + 1) * g.seg_T;
+  }
   auto panel_ptr = [&](int i) -> char* { return smem + kPOff + i * kPanelBytes; };
   float* scratch = reinterpret_cast<float*>(smem);
   float* prm = reinterpret_cast<float*>(smem + kPrmOff);
   unsigned long long* ts = g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 128 : nullptr;
   auto stamp = [&](int i) { if (ts && tid == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   auto wstamp = [&](int si, int i) { if (ts && si == g.dbg_stage && lane == 0) ts[64 + wave * 8 + i] = __builtin_amdgcn_s_memtime(); };
+  // (measurement, VNR_CHAIN_TS_SLOTS=1: dbg_stage carries 0x100 -- the per-wave stamps are then the ends of the 8 k-loop slots of the LAST trip
+  //  of that stage, [32 + wave] the start of its k-loop: tools/r05_slot_ts.py)
+  auto sstamp = [&](int si, int i) { if (ts && (si | 0x100) == g.dbg_stage && lane == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
+  if (ts && tid == 0) ts[62] = chain_xcc_id();            // (measurement: s_memtime counts per XCD)
 
   // ---- the weight stream --------------------------------------------------------------------------------------------
   // Operand-major images as in gemm3.hip: block (32-column block, k-tile) = 4 x 1 KiB pieces (piece 2t + part: k16 step t, hi / lo);
@@ -121,43 +135,6 @@ panel_chain4_kernel(const ChainArgs g) {
     }
     trip_offsets();
   };
-  open_stage(0);
-  trip_offsets();
-#pragma unroll
-  for (int u = 0; u < kDepth; ++u)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) piece(u, j, i);
-  advance();
-
-  // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (stage s by wave s mod 4) ----------------------------------
-  if (g.prm) {
-    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
-    for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(s_ * 3072 + lane * 16), 0, 0, 0);
-      const int lo = g.st[s_].lds_ln;
-      if (lo >= 0) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(s_ * 3072 + 1024 + lane * 16), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(s_ * 3072 + 2048 + lane * 16), 0, 0, 0);
-      }
-    }
-  } else {
-    for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
-      const float* bp = g.st[s_].bias; const float* gp = g.st[s_].gamma; const float* ep = g.st[s_].beta;
-      const unsigned nb = (unsigned)g.st[s_].n * 4u;
-      const bool skip = g.st[s_].acc_mode == 1 || g.st[s_].acc_mode == 2;
-      const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp ? bp : g.in0), 0, (bp && !skip) ? nb : 0u, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
-      const int lo = g.st[s_].lds_ln;
-      if (lo >= 0) {
-        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0, nb, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep ? ep : gp), 0, ep ? nb : 0u, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(lane * 16), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
-      }
-    }
-  }
   // ---- input panels (fp32 rows in HBM -> split fp16 panel): all reads issued first, rows beyond M read as zeros --------
   {
     const int q4 = g.D >> 2;                                       // float4 per row (<= 64)
@@ -166,17 +143,62 @@ panel_chain4_kernel(const ChainArgs g) {
     for (int pi = 0; pi < 2; ++pi) {
       const float* src = pi == 0 ? g.in0 : g.in1;
       const int ld = pi == 0 ? g.ld0 : g.ld1;
+      // buffer reads: a missing source, rows beyond M and slots beyond the panel are out-of-range offsets (zeros, no branch per read)
+      const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src ? src + (size_t)m0 * ld : g.in0), 0,
+                                                                            src ? 0x40000000u : 0u, 0x00020000);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int e = tid + 256 * it, r = e / q4, j = e - r * q4;
-        x[pi][it] = (src && r < kRows && m0 + r < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + r) * ld + 4 * j)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned off = (r < kRows && m0 + r < mend) ? (unsigned)((r * ld + 4 * j) * 4) : kOob3;
+        x[pi][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, 0, 0));
       }
     }
+    stamp(56);
+    // the head of the weight stream goes out BEHIND the rows (memory returns in order: the rows -- which the conversion below waits
+    // for -- are not queued behind 64 KiB of weights per wave)
+    open_stage(0);
+    trip_offsets();
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) piece(u, j, i);
+    advance();
+    stamp(59);
+    // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (stage s by wave s mod 4) ----------------------------------
+    if (g.prm) {
+      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
+      for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(s_ * 3072 + lane * 16), 0, 0, 0);
+        const int lo = g.st[s_].lds_ln;
+        if (lo >= 0) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(s_ * 3072 + 1024 + lane * 16), 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(s_ * 3072 + 2048 + lane * 16), 0, 0, 0);
+        }
+      }
+    } else {
+      for (int s_ = wave; s_ < g.nstages; s_ += kNW) {
+        const float* bp = g.st[s_].bias; const float* gp = g.st[s_].gamma; const float* ep = g.st[s_].beta;
+        const unsigned nb = (unsigned)g.st[s_].n * 4u;
+        const bool skip = g.st[s_].acc_mode == 1 || g.st[s_].acc_mode == 2;
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp ? bp : g.in0), 0, (bp && !skip) ? nb : 0u, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds3_t)(smem + kPrmOff + s_ * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+        const int lo = g.st[s_].lds_ln;
+        if (lo >= 0) {
+          const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp), 0, nb, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep ? ep : gp), 0, ep ? nb : 0u, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds3_t)(smem + kPrmOff + lo * 4), 16, (unsigned)(lane * 16), 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsE, (lds3_t)(smem + kPrmOff + lo * 4 + 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+        }
+      }
+    }
+
     // the three panels start as zeros (while the rows above are in flight): a short stage (nk = 4) multiplies tiles 4-7 of its source
     // rows with zero weights, and 0 x NaN from whatever the LDS held would poison the accumulators
     for (int o = tid * 16; o < 3 * kPanelBytes; o += 256 * 16) *reinterpret_cast<float4*>(smem + kPOff + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier4();
+    stamp(57);
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi) {
       if (!(pi == 0 ? g.in0 : g.in1)) continue;
@@ -189,7 +211,8 @@ panel_chain4_kernel(const ChainArgs g) {
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // parameter DMA landed (the first trip of weights too: issued first)
+  stamp(58);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first trip of weights landed (the parameter DMA too: issued in front of the rows)
   lds_barrier4();
   stamp(1);
 
@@ -209,6 +232,7 @@ panel_chain4_kernel(const ChainArgs g) {
     int tid_s = tid;
     asm volatile("" : "+v"(tid_s));
     if (tid == 0) chain_publish_stage(g, si);               // (chain_prefetch.h)
+    if (ts && tid == 0) ts[96 + si] = __builtin_amdgcn_s_memrealtime();      // (measurement: 100 MHz, the same clock on every CU)
     if (g.att_stage > 0 && si == g.att_stage) {
       stamp(60);                                                       // attention phase begins
       // ================= fused cross-attention of this panel (ChainArgs::att_stage) ========================================
@@ -220,7 +244,7 @@ panel_chain4_kernel(const ChainArgs g) {
       const int head = wave;
       const int H = g.D >> 6, TTk = (g.att_Tk + 31) >> 5;
       const int row = m0 + l31;
-      int b_lo = m0 / g.att_Tq, b_hi = (m0 + 31 < g.M ? m0 + 31 : g.M - 1) / g.att_Tq;
+      int b_lo = m0 / g.att_Tq, b_hi = (m0 + 31 < mend ? m0 + 31 : mend - 1) / g.att_Tq;
       b_lo = __builtin_amdgcn_readfirstlane(b_lo); b_hi = __builtin_amdgcn_readfirstlane(b_hi);
       char* P1 = panel_ptr(1);
       char* Pc = panel_ptr(g.att_ali ? 2 : 1);
@@ -229,7 +253,7 @@ panel_chain4_kernel(const ChainArgs g) {
       for (int bb = b_lo; bb <= b_hi; ++bb) {
         const int qlen = g.att_qlen ? g.att_qlen[bb] : g.att_Tq, klen = g.att_klen ? g.att_klen[bb] : g.att_Tk;
         const int tq = row - bb * g.att_Tq;
-        const bool mine = row < g.M && tq >= 0 && tq < g.att_Tq;
+        const bool mine = row < mend && tq >= 0 && tq < g.att_Tq;
         const bool qvalid = mine && tq < qlen;
         f32x16 O[2];
 #pragma unroll
@@ -351,7 +375,7 @@ panel_chain4_kernel(const ChainArgs g) {
               const int rr = 8 * it + (lane_s >> 3), k4 = (lane_s & 7) * 4;
               const float4 pv = make_float4(tb[rr * 33 + k4], tb[rr * 33 + k4 + 1], tb[rr * 33 + k4 + 2], tb[rr * 33 + k4 + 3]);
               const int rg = m0 + rr, tqr = rg - bb * g.att_Tq, key0 = 32 * kb + k4;
-              if (rg < g.M && tqr >= 0 && tqr < g.att_Tq && key0 < g.att_Tk)
+              if (rg < mend && tqr >= 0 && tqr < g.att_Tq && key0 < g.att_Tk)
                 *reinterpret_cast<float4*>(g.att_ali + (((size_t)(bb * H + head) * g.att_Tq + tqr) * g.att_Tk + key0)) = pv;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -425,6 +449,7 @@ panel_chain4_kernel(const ChainArgs g) {
 #pragma unroll
         for (int idx = 0; idx < 4; ++idx) afr[set][idx] = *reinterpret_cast<const h16x8*>(smem + arow[u & 1][idx] + (u >> 1) * 256);
       };
+      sstamp(si, 32 + wave);
       trip_rows(0);
       read_r(0, 0);
 #pragma unroll 1
@@ -434,6 +459,7 @@ panel_chain4_kernel(const ChainArgs g) {
           if (u + 1 < kDepth) read_r(u + 1, (u + 1) & 1);
           else { trip_rows(kb + kDepth); read_r(0, 0); }   // the next trip's first tile (after the last trip: a harmless re-read)
           mfma_slot(u);
+          sstamp(si, 64 + wave * 8 + u);
         }
         advance();
       }
@@ -452,22 +478,43 @@ panel_chain4_kernel(const ChainArgs g) {
       }
     }
     if (st.acc_mode == 1 || st.acc_mode == 2) { if (st.sync_after) lds_barrier4(); stamp(3 + 2 * si); continue; }
-    // ---- fast path: a full-width hidden stage h = relu(x.W + b) -> other panel (FFN dense1 chunks, utils.py:49) ---------------
-    if (st.acc_mode == 0 && st.act == ACT_RELU && st.n == 256 && !st.pe && st.res < 0 && !st.gamma && !st.out && st.dst >= 0 &&
-        st.dst != st.a0 && !(st.asw < st.nk && st.dst == st.a1)) {
+    // ---- fast path: a full-width stage h = act(x.W + b) -> other panel (FFN dense1 chunks, utils.py:49; the query projection) -----
+    if (st.acc_mode == 0 && (st.act == ACT_RELU || st.act == ACT_IDENTITY) && st.n == 256 && !st.pe && st.res < 0 && !st.gamma && !st.out &&
+        st.dst >= 0 && st.dst != st.a0 && !(st.asw < st.nk && st.dst == st.a1) && !(g.cpl_stage > 0 && si == g.cpl_stage)) {
+      const float floor_v = st.act == ACT_RELU ? 0.f : -__builtin_inff();       // (identity: the query projection in front of the attention)
       const float* sp = prm + si * 256;
       char* Dp = panel_ptr(st.dst);
+      // With ONE wave per SIMD nothing hides an LDS round trip: left to itself the compiler emits read bias -> wait -> 25 dependent VALU
+      // on eight recycled registers -> two stores, eight times over (3.0 kcyc for this epilogue against 1.9 for the 8-wave kernel's).
+      // So: all eight bias reads first, the arithmetic of both column blocks on their own registers, the sixteen stores last.
+      float4 bi[2][4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int kt = 2 * wave + j;                                    // this column block = k-tile kt of the destination
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bi[j][q] = *reinterpret_cast<const float4*>(sp + 32 * (2 * wave + j) + 8 * q + 4 * half);
+      __builtin_amdgcn_sched_barrier(0);
+      h16x4 xh[2][4], xl[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 bi = *reinterpret_cast<const float4*>(sp + 32 * kt + 8 * q + 4 * half);
-          const float x[4] = {fmaxf(acc[j][4 * q] * st.scale + bi.x, 0.f), fmaxf(acc[j][4 * q + 1] * st.scale + bi.y, 0.f),
-                              fmaxf(acc[j][4 * q + 2] * st.scale + bi.z, 0.f), fmaxf(acc[j][4 * q + 3] * st.scale + bi.w, 0.f)};
-          panel_put4(Dp, l31, kt, 8 * q + 4 * half, x);
+          const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = fmaxf(acc[j][4 * q + e] * st.scale + bq[e], floor_v);
+            const _Float16 h = (_Float16)x;
+            xh[j][q][e] = h; xl[j][q][e] = (_Float16)(x - (float)h);
+          }
         }
-      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kt = 2 * wave + j, p = 8 * q + 4 * half;            // this column block = k-tile kt of the destination
+          *reinterpret_cast<h16x4*>(Dp + panel_off4(l31, kt, p >> 3) + (p & 4) * 2) = xh[j][q];
+          *reinterpret_cast<h16x4*>(Dp + panel_off4(l31, kt, 4 + (p >> 3)) + (p & 4) * 2) = xl[j][q];
+        }
       wstamp(si, 5);
       if (st.sync_after) lds_barrier4();
       stamp(3 + 2 * si); wstamp(si, 3);
@@ -475,39 +522,52 @@ panel_chain4_kernel(const ChainArgs g) {
     }
     if (vstage) {
       if (wave_on) {
+        // both 32 x 32 blocks of the wave at once (two wave-private [32 channels][33] float buffers): all writes, ONE wait, all reads
         const int Hh = st.aoi_D >> 6, TT = (st.aoi_T + 31) >> 5;
-        float* tb = reinterpret_cast<float*>(smem + g.vt_lds) + wave * (32 * 33);      // wave-private [32 channels][33]
+        float* tb = reinterpret_cast<float*>(smem + g.vt_lds) + wave * (2 * 32 * 33);
+        const float* bp = prm + si * 256 + 64 * wave;                   // (zero padded when the stage has no bias)
+        const bool j1 = 64 * wave + 32 < st.n;                          // (wave-uniform; block 0 exists: wave_on)
+        float4 bi[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int cb = 32 * (2 * wave + j);
-          if (cb >= st.n) continue;                                     // (wave-uniform)
-          const float* bp = prm + si * 256 + cb;                        // (zero padded when the stage has no bias)
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bi[j][q] = *reinterpret_cast<const float4*>(bp + 32 * j + 8 * q + 4 * half);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 bi = *reinterpret_cast<const float4*>(bp + 8 * q + 4 * half);
-            const float bq[4] = {bi.x, bi.y, bi.z, bi.w};
+            const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tb[(8 * q + 4 * half + e) * 33 + l31] = acc[j][4 * q + e] * st.scale + bq[e];
+            for (int e = 0; e < 4; ++e) tb[j * (32 * 33) + (8 * q + 4 * half + e) * 33 + l31] = acc[j][4 * q + e] * st.scale + bq[e];
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int cv = st.aoi_c0 - 2 * st.aoi_D + cb + l31;           // V column of this lane: head cv >> 6, channel cv & 63
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float x[2][2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[j][tp][e] = tb[j * (32 * 33) + l31 * 33 + 16 * tp + (e & 3) + 4 * half + 8 * (e >> 2)];   // k-slot (tp, g = half, e) -> row of the panel
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j == 1 && !j1) continue;
+          const int cv = st.aoi_c0 - 2 * st.aoi_D + 32 * (2 * wave + j) + l31;   // V column of this lane: head cv >> 6, channel cv & 63
 #pragma unroll
           for (int tp = 0; tp < 2; ++tp) {
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = tb[l31 * 33 + 16 * tp + (e & 3) + 4 * half + 8 * (e >> 2)];   // k-slot (tp, g = half, e) -> row of the panel
             const int R = m0 + 16 * tp;
-            if (R >= g.M) continue;
+            if (R >= mend) continue;
             const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
             h16x8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)x[e]; hi[e] = hh; lo[e] = (_Float16)(x[e] - (float)hh); }
+            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)x[j][tp][e]; hi[e] = hh; lo[e] = (_Float16)(x[j][tp][e] - (float)hh); }
             char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
                          ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
             *reinterpret_cast<h16x8*>(pdst) = hi;
             *reinterpret_cast<h16x8*>(pdst + 4096) = lo;
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the block is read before the next one overwrites it
         }
       }
       if (st.sync_after) lds_barrier4();
@@ -519,6 +579,157 @@ panel_chain4_kernel(const ChainArgs g) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = accF[j][r];
+    }
+
+    // ---- fast path: a full-width stage whose output is a Q or K operand image (the Q | K | V tails of a block: attention.py:436-440) ------
+    if (st.out && st.out_fmt != 0 && st.n == 256 && st.dst < 0 && st.res < 0 && !st.gamma && !st.pe && st.act == ACT_IDENTITY && st.acc_mode == 0 &&
+        ((st.out_fmt == 1 ? 0 : st.aoi_c0) + 255) / (st.out_fmt == 1 ? st.n : st.aoi_D) < 2 && !(g.cpl_stage > 0 && si == g.cpl_stage)) {
+      const float* sp = prm + si * 256;
+      const int row = m0 + l31;
+      const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, TT = (st.aoi_T + 31) >> 5;
+      const int bb = row / st.aoi_T, tt = row - bb * st.aoi_T;
+      const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(st.out, 0, 0x7ffffff0u, 0x00020000);
+      float4 bi[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bi[j][q] = *reinterpret_cast<const float4*>(sp + 32 * (2 * wave + j) + 8 * q + 4 * half);
+      __builtin_amdgcn_sched_barrier(0);
+      h16x4 xh[2][4], xl[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = acc[j][4 * q + e] * st.scale + bq[e];
+            const _Float16 h = (_Float16)x;
+            xh[j][q][e] = h; xl[j][q][e] = (_Float16)(x - (float)h);
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // this lane's 8-byte unit for channel d = (cw & 63) + 8q + 4 half of image `which`: t = d >> 4, g = q & 1 (common.h: AoiDesc)
+        const int wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + 32 * (2 * wave + j);
+        const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
+        const unsigned io = (unsigned)((long long)which * st.aoi_img_bytes + ((long long)(bb * (Dd >> 6) + (cw >> 6)) * TT + (tt >> 5)) * kAoiTile) +
+                            (unsigned)(((cw & 63) >> 4) * 1024 + ((tt & 31) << 4) + half * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned o = row < mend ? io + (unsigned)((q >> 1) * 1024 + (q & 1) * 512) : kOob3;     // (rows beyond the panel: dropped by the hardware)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, xh[j][q]), rsI, o, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, xl[j][q]), rsI, o == kOob3 ? kOob3 : o + 4096u, 0, 0);
+        }
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
+
+    // ---- fast path: the full-width residual + LayerNorm stage (att_proj1 / att_proj2 / FFN dense2 of a block: attention.py:449-452,
+    // utils.py:50-53), straight-line: every LDS read of a phase is issued before the arithmetic that needs it (see the hidden path) ------
+    if (st.gamma && st.n == 256 && !st.pe && st.res >= 0 && !st.out_pre && !st.out_stats && st.out_fmt == 0 && st.act == ACT_IDENTITY &&
+        st.dst >= 0 && !(g.cpl_stage > 0 && si == g.cpl_stage)) {
+      const float* sp = prm + si * 256;
+      const float* lnp = prm + st.lds_ln;                               // gamma [256] | beta [256]
+      const char* Rp = panel_ptr(st.res);
+      char* Dp = panel_ptr(st.dst);
+      int po[2][4];                                                     // this lane's 8-byte piece of (block j, group q): hi chunk; lo = +4 chunks
+      float4 bi[2][4];
+      h16x4 rh[2][4], rl[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          po[j][q] = panel_off4(l31, 2 * wave + j, q) + 8 * half;
+          bi[j][q] = *reinterpret_cast<const float4*>(sp + 32 * (2 * wave + j) + 8 * q + 4 * half);
+          rh[j][q] = *reinterpret_cast<const h16x4*>(Rp + po[j][q]);
+          rl[j][q] = *reinterpret_cast<const h16x4*>(Rp + (po[j][q] ^ 64));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      float v[2][16];
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[j][4 * q + e] * st.scale + bq[e];
+            x += (float)rh[j][q][e] + (float)rl[j][q][e];               // residual = hi + lo of the panel entry (22 bits)
+            v[j][4 * q + e] = x;
+            ps[e] += x;
+          }
+        }
+      wstamp(si, 6);
+      // gamma / beta do not depend on the statistics: their reads travel while the row sums are exchanged
+      float4 ga[2][4], be[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = 32 * (2 * wave + j) + 8 * q + 4 * half;
+          ga[j][q] = *reinterpret_cast<const float4*>(lnp + col);
+          be[j][q] = *reinterpret_cast<const float4*>(lnp + 256 + col);
+        }
+      float s1 = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mw = s1 * (1.f / 64.f);
+      float pm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = v[j][r] - mw; pm[r & 3] += d * d; }
+      float m2 = (pm[0] + pm[1]) + (pm[2] + pm[3]);
+      m2 += __shfl_xor(m2, 32, 64);
+      wstamp(si, 7);
+      if (half == 0) { scratch[l31 * 4 + wave] = s1; scratch[kRows * 4 + l31 * 4 + wave] = m2; }
+      lds_barrier4();                                                   // (also: every wave is done reading the source / residual panels)
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(scratch + l31 * 4);
+      const f32x4 ma = *reinterpret_cast<const f32x4*>(scratch + kRows * 4 + l31 * 4);
+      const float mu = (sa[0] + sa[1] + sa[2] + sa[3]) * (1.f / 256.f);
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < kNW; ++w) { const float dm = sa[w] * (1.f / 64.f) - mu; var += ma[w] + 64.f * dm * dm; }      // Chan et al.: exact merge
+      const float rstd = 1.0f / sqrtf(var * (1.f / 256.f) + kLnEps);
+      h16x4 xh[2][4], xl[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float gq[4] = {ga[j][q].x, ga[j][q].y, ga[j][q].z, ga[j][q].w}, eq[4] = {be[j][q].x, be[j][q].y, be[j][q].z, be[j][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = (v[j][4 * q + e] - mu) * rstd * gq[e] + eq[e];
+            v[j][4 * q + e] = x;
+            const _Float16 hh = (_Float16)x;
+            xh[j][q][e] = hh; xl[j][q][e] = (_Float16)(x - (float)hh);
+          }
+        }
+      wstamp(si, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<h16x4*>(Dp + po[j][q]) = xh[j][q];
+          *reinterpret_cast<h16x4*>(Dp + (po[j][q] ^ 64)) = xl[j][q];
+        }
+      if (st.out && m0 + l31 < mend) {
+        float* orow = st.out + (size_t)(m0 + l31) * st.ldo + 64 * wave + 4 * half;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out_store4(orow + 32 * j + 8 * q, v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]);
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
     }
 
     // ---- epilogue: v = act(acc*scale + bias) (+ residual panel) ; optional LayerNorm over the row ------------------------
@@ -576,7 +787,7 @@ panel_chain4_kernel(const ChainArgs g) {
           for (int which = 0; which < 2; ++which) {
             const int zoff = which ? g.cpl_cond_off : g.cpl_zp_off;
             float* zp = g.cpl_z + (size_t)row * g.cpl_ld + zoff + c;
-            const float4 zo = row < g.M ? *reinterpret_cast<const float4*>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 zo = row < mend ? *reinterpret_cast<const float4*>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
             float o[4] = {zo.x, zo.y, zo.z, zo.w};
             if (which == 0) {
               const float4 ls = *reinterpret_cast<const float4*>(cx + prow * cst + c), sh = *reinterpret_cast<const float4*>(cx + prow * cst + 64 + c);
@@ -586,7 +797,7 @@ panel_chain4_kernel(const ChainArgs g) {
                 const float scale = 1.0f / (1.0f + expf(-(lv[e] + 2.0f)));                    // tf.math.sigmoid(log_scale + 2), flow.py:231
                 o[e] = scale * o[e] + sv[e];                                                  // _affine, flow.py:216
               }
-              if (row < g.M) out_store4(zp, o[0], o[1], o[2], o[3]);
+              if (row < mend) out_store4(zp, o[0], o[1], o[2], o[3]);
             }
             panel_put4(Dp, prow, (zoff + c) >> 5, (zoff + c) & 31, o);
           }
@@ -606,7 +817,7 @@ panel_chain4_kernel(const ChainArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int col = 32 * (2 * wave + j) + 8 * q + 4 * half;
-            if (cok[j][q] && row < g.M) {
+            if (cok[j][q] && row < mend) {
               const float4 p4 = *reinterpret_cast<const float4*>(pr + col);
               v[j][4 * q] += st.pe_w * p4.x; v[j][4 * q + 1] += st.pe_w * p4.y; v[j][4 * q + 2] += st.pe_w * p4.z; v[j][4 * q + 3] += st.pe_w * p4.w;
             }
@@ -634,7 +845,7 @@ panel_chain4_kernel(const ChainArgs g) {
     wstamp(si, 6);                                       // (finer epilogue stamps, measurement) residual / PE added
     if (st.gamma && st.out_pre) {                                       // training: x + Dense(.) before the normalisation
       const int row = m0 + l31;
-      if (row < g.M) {
+      if (row < mend) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -682,7 +893,7 @@ panel_chain4_kernel(const ChainArgs g) {
         var += ma[w] + (float)c * dm * dm;
       }
       const float rstd = 1.0f / sqrtf(var * rn + kLnEps);
-      if (st.out_stats && wave == 0 && half == 0 && m0 + l31 < g.M)
+      if (st.out_stats && wave == 0 && half == 0 && m0 + l31 < mend)
         *reinterpret_cast<float2*>(st.out_stats + 2 * (size_t)(m0 + l31)) = make_float2(mu, rstd);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -708,7 +919,7 @@ panel_chain4_kernel(const ChainArgs g) {
         if (cb >= st.n) continue;                                       // (wave-uniform)
         char* img_row = nullptr;                         // Q/K-type: address of this lane's 16-byte unit for t = 0, g = 0
         bool img_generic = false;
-        if (st.out && st.out_fmt != 0 && row < g.M) {
+        if (st.out && st.out_fmt != 0 && row < mend) {
           const int Dd = st.out_fmt == 1 ? st.n : st.aoi_D, wc0 = (st.out_fmt == 1 ? 0 : st.aoi_c0) + cb;
           const int which = __builtin_amdgcn_readfirstlane(wc0 / Dd), cw = wc0 - which * Dd;
           if (which == 2) img_generic = true;
@@ -722,7 +933,7 @@ panel_chain4_kernel(const ChainArgs g) {
         for (int q = 0; q < 4; ++q) {
           const int col = cb + 8 * q + 4 * half;
           if (!cok[j][q]) continue;
-          if (st.out && row < g.M) {
+          if (st.out && row < mend) {
             if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
               h16x4 hi, lo;
 #pragma unroll
@@ -751,13 +962,14 @@ panel_chain4_kernel(const ChainArgs g) {
 hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
   static int attr_set[kMaxDevices] = {0};
   opt_in_dynamic_lds((const void*)panel_chain4_kernel, lds, attr_set);
-  const int wgs = (g.M + kRows - 1) / kRows;
+  const int wgs = chain_workers(g, kRows);
   static const char* ts_path = getenv("VNR_CHAIN_TS");
   if (ts_path) {
     ChainArgs gg = g;
     static const char* ts_stage = getenv("VNR_CHAIN_TS_STAGE");       // stage whose per-wave stamps are taken (default 1)
     gg.dbg_stage = ts_stage ? atoi(ts_stage) : 1;
-    const size_t n = (size_t)wgs * 128;
+    if (getenv("VNR_CHAIN_TS_SLOTS")) gg.dbg_stage |= 0x100;
+    const size_t n = (size_t)(wgs + gg.pf_wgs) * 128;       // (the prefetch workgroups stamp too)
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
     (void)hipMemset(d, 0, n * 8);

@@ -7,7 +7,7 @@ while off < len(data):
     ts=ts[ts[:,63]<1000]; nw=len(ts)
     nwv=int(sys.argv[2]) if len(sys.argv)>2 else 4
     start=ts[:,32:32+nwv]; slots=ts[:,64:64+8*nwv].reshape(nw,nwv,8)
-    if not slots.any() or not ts[:,32].any(): continue
+    if not slots.all() or not ts[:,32].all(): continue
     d=np.diff(np.concatenate([start[:,:,None],slots],axis=2),axis=2)
     print("stages=%d: per-wave slot durations (clk, median over workgroups), slot 0..7:"%ns)
     for w in range(nwv): print("  wave %d:"%w, " ".join("%5d"%x for x in np.median(d[:,w,:],axis=0)), "  sum %d"%np.median(d[:,w,:].sum(axis=1)))

@@ -307,7 +307,7 @@ struct ChainArgs {
   ChainStage st[kMaxChainStages];
 };
 // worker workgroups of a chain launch (panels of `rows` rows)
-inline __host__ __device__ int chain_workers(const ChainArgs& g, int rows) {
+__attribute__((always_inline)) inline __host__ __device__ int chain_workers(const ChainArgs& g, int rows) {
   return g.seg_T > 0 ? (g.M / g.seg_T) * ((g.seg_T + rows - 1) / rows) : (g.M + rows - 1) / rows;
 }
 hipError_t launch_panel_chain(const ChainArgs& g, hipStream_t s);

@@ -797,7 +797,7 @@ static hipError_t launch_chain_rt(const ChainArgs& g, int lds, hipStream_t s) {
     const size_t n = (size_t)wgs * 128;
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
-    (void)hipMemset(d, 0, n * 8);
+    (void)hipMemsetAsync(d, 0, n * 8, s);
     gg.dbg_ts = d;
     vnr_launch(panel_chain_kernel<RT>, dim3(wgs), dim3(512), lds, s, gg);
     (void)hipStreamSynchronize(s);
@@ -881,6 +881,7 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
       // (the 4-wave kernel serves inference programs: no pre-normalisation / statistics outputs of the training chains; its image
       //  stores address the three Q | K | V images through ONE 2 GiB buffer descriptor)
       if (st.out_pre || st.out_stats || (st.out && st.out_fmt != 0 && 3 * st.aoi_img_bytes > 0x7f000000ll)) g.waves4 = 0;
+      if (st.kt_total >= 1024 || st.kt0 >= 1024 || st.kt_total < 0 || st.kt0 < 0) g.waves4 = 0;      // (its fetch table packs them into 10 bits each)
     }
     if (g.D != 256 && g.D != 128) g.waves4 = 0;
   }

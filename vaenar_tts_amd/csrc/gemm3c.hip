@@ -95,21 +95,48 @@ panel_chain4_kernel(const ChainArgs g) {
   int fs = 0, fk = 0, fnk = 0, fpad = 0;
   unsigned fvoff0 = kOob3, fvoff1 = kOob3;
   __amdgpu_buffer_rsrc_t frs;
-  auto open_stage = [&](int s_) {
+  auto set_stage = [&](const void* w, int nk, int n, int ktt, int k0) {
+    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x40000000, 0x00020000);
+    fnk = nk;
+    fpad = (nk + kDepth - 1) / kDepth * kDepth;
+    fvoff0 = (64 * wave < n) ? (unsigned)(((2 * wave) * ktt + k0) * 4096 + lane * 16) : kOob3;
+    fvoff1 = (64 * wave + 32 < n) ? (unsigned)(((2 * wave + 1) * ktt + k0) * 4096 + lane * 16) : kOob3;
+  };
+  // The fetch cursor opens a stage from a table held in three REGISTERS -- lane s = stage s: the image address as a distance from stage
+  // 0's image (two dwords) and nk | n / 4 | kt_total | kt0 packed into one -- with three v_readlane.  Through the kernel-argument segment
+  // it was two dependent rounds of scalar loads behind the last k-tile of every trip: ~1 kcyc that one wave per SIMD cannot hide
+  // (per-slot stamps, profiles/r05_experiments.txt).  Only the head of the stream (prologue) still opens stages that way.
+  unsigned ft_lo = 0, ft_hi = 0, ft_pk = 0;
+  {
+    // (through the kernel-argument POINTER: g.st[lane] with a lane-varying index makes the compiler copy all of `g` to scratch)
+    typedef const __attribute__((address_space(4))) char* kbytes_t;
+    const int sl = lane < g.nstages ? lane : 0;
+    kbytes_t sp_ = (kbytes_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ChainArgs, st) + (size_t)sl * sizeof(ChainStage);
+    const unsigned long long wd = *reinterpret_cast<const __attribute__((address_space(4))) unsigned long long*>(sp_ + offsetof(ChainStage, w)) -
+                                  reinterpret_cast<unsigned long long>(g.st[0].w);
+    const unsigned nk_ = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(sp_ + offsetof(ChainStage, nk));
+    const unsigned n_ = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(sp_ + offsetof(ChainStage, n));
+    const unsigned ktt_ = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(sp_ + offsetof(ChainStage, kt_total));
+    const unsigned k0_ = *reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(sp_ + offsetof(ChainStage, kt0));
+    ft_lo = (unsigned)wd; ft_hi = (unsigned)(wd >> 32);
+    ft_pk = nk_ | ((n_ >> 2) << 5) | (ktt_ << 12) | (k0_ << 22);          // nk <= 16, n / 4 <= 64, kt_total, kt0 < 1024 (launch_panel_chain checks)
+  }
+  auto open_stage_k = [&](int s_) {
     const ChainStage& st = g.st[s_];
-    frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((g.prio_mode == 8 && g.D == 256) ? g.st[0].w : st.w), 0, 0x40000000, 0x00020000);
-    fnk = st.nk;
-    fpad = (st.nk + kDepth - 1) / kDepth * kDepth;
-    // (measurement only, VNR_CHAIN_PRIO=8: every stage reads the first 256 KiB of stage 0's image -- L2-resident, not L1-resident, wrong results)
-    const int ktt = (g.prio_mode == 8 && g.D == 256) ? 8 : st.kt_total, k0 = (g.prio_mode == 8 && g.D == 256) ? 0 : st.kt0;
-    fvoff0 = (64 * wave < st.n) ? (unsigned)(((2 * wave) * ktt + k0) * 4096 + lane * 16) : kOob3;
-    fvoff1 = (64 * wave + 32 < st.n) ? (unsigned)(((2 * wave + 1) * ktt + k0) * 4096 + lane * 16) : kOob3;
+    set_stage(st.w, st.nk, st.n, st.kt_total, st.kt0);
+  };
+  auto open_stage = [&](int s_) {
+    const long long wd = (long long)((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ft_lo, s_) |
+                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ft_hi, s_) << 32));
+    const unsigned pk = (unsigned)__builtin_amdgcn_readlane((int)ft_pk, s_);
+    set_stage(static_cast<const char*>(g.st[0].w) + wd, (int)(pk & 31u), (int)(((pk >> 5) & 127u) << 2), (int)((pk >> 12) & 1023u), (int)(pk >> 22));
   };
   // Validity of a fetched k-tile (kt < nk of the fetched stage) is decided once per TRIP for three slot groups -- a stage has at least
   // two k-tiles: slots 0-1 always carry one, slots 2-3 iff more than 2 remain, slots 4-7 iff more than 4 -- so the loop body holds no
-  // select; the piece index rides in the instruction's immediate offset, the k-tile in the scalar offset.
+  // select; the piece index rides in the instruction's immediate offset, the k-tile in the scalar offset.  (The validity cannot live in
+  // the descriptor -- zero records for an invalid group: the hardware checks offset >= num_records - scalar offset, which wraps.)
   unsigned vo[3][2];
-  int fsoff = 0;                                         // fk * 4096 (or the measurement overrides below)
+  int fsoff = 0;                                         // fk * 4096
   auto trip_offsets = [&]() {
     const int left = fnk - fk;
 #pragma unroll
@@ -119,13 +146,11 @@ panel_chain4_kernel(const ChainArgs g) {
       vo[1][j] = left > 2 ? v : kOob3;
       vo[2][j] = left > 4 ? v : kOob3;
     }
-    // (measurement only, VNR_CHAIN_PRIO=9: every weight read goes to the stage's first k-tile -- L1-resident, wrong results;
-    //  VNR_CHAIN_PRIO=8: the first 8 k-tiles of stage 0's image -- L2-resident, wrong results)
-    fsoff = g.prio_mode == 9 ? 0 : ((g.prio_mode == 8 && g.D == 256) ? 0 : fk * 4096);
+    fsoff = fk * 4096;
   };
   auto piece = [&](int u, int j, int i) {
     const unsigned v = vo[u < 2 ? 0 : (u < 4 ? 1 : 2)][j];
-    wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, v + i * 1024, fsoff + (g.prio_mode == 9 ? 0 : u * 4096), 0));
+    wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, v + i * 1024, fsoff + u * 4096, 0));
   };
   auto advance = [&]() {
     fk += kDepth;
@@ -156,7 +181,7 @@ panel_chain4_kernel(const ChainArgs g) {
     stamp(56);
     // the head of the weight stream goes out BEHIND the rows (memory returns in order: the rows -- which the conversion below waits
     // for -- are not queued behind 64 KiB of weights per wave)
-    open_stage(0);
+    open_stage_k(0);
     trip_offsets();
 #pragma unroll
     for (int u = 0; u < kDepth; ++u)
@@ -164,7 +189,14 @@ panel_chain4_kernel(const ChainArgs g) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) piece(u, j, i);
-    advance();
+    // (the head of the stream: the table does not exist yet, and stage 1 is opened through the kernel arguments -- written out, not a
+    //  flag of advance(): two paths to &g.st[fs] that meet make the compiler copy all of `g` to scratch)
+    fk += kDepth;
+    if (fk >= fpad) {
+      fk = 0;
+      if (g.nstages > 1) { fs = 1; open_stage_k(1); } else { fnk = 0; }
+    }
+    trip_offsets();
     stamp(59);
     // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (stage s by wave s mod 4) ----------------------------------
     if (g.prm) {
@@ -972,7 +1004,7 @@ hipError_t launch_chain4(const ChainArgs& g, int lds, hipStream_t s) {
     const size_t n = (size_t)(wgs + gg.pf_wgs) * 128;       // (the prefetch workgroups stamp too)
     unsigned long long* d = nullptr;
     if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
-    (void)hipMemset(d, 0, n * 8);
+    (void)hipMemsetAsync(d, 0, n * 8, s);
     gg.dbg_ts = d;
     vnr_launch(panel_chain4_kernel, dim3(wgs + gg.pf_wgs), dim3(256), lds, s, gg);
     (void)hipStreamSynchronize(s);

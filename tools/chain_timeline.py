@@ -22,8 +22,8 @@ for (M, Dw, ns), ts in seen.items():
         print("  attention phase: %.2f kcyc (inside stage %d's \"loop\" figure below)" % (np.median(ts[:, 61] - ts[:, 60]) / 1e3, att))
     print("  panel load: %.2f kcyc" % (np.median(ts[:, 1] - ts[:, 0]) / 1e3))
     if ts[:, 56].any():                                       # (4-wave kernel: sub-phases)
-        print("    row reads issued +%.2f, weight head issued +%.2f, parameter DMA issued + panels zeroed +%.2f, rows converted +%.2f, first weights in +%.2f kcyc" % tuple(
-            np.median(ts[:, b] - ts[:, a]) / 1e3 for a, b in ((0, 56), (56, 59), (59, 57), (57, 58), (58, 1))))
+        print("    row reads issued +%.2f, weight head k-tiles 0-3 issued +%.2f, zero fill + rows converted +%.2f, k-tiles 4-7 + parameter DMA issued and landed +%.2f kcyc" % tuple(
+            np.median(ts[:, b] - ts[:, a]) / 1e3 for a, b in ((0, 56), (56, 59), (59, 58), (58, 1))))
     tl = te = 0.0
     for s in range(ns):
         loop = np.median(ts[:, 2 + 2 * s] - ts[:, 1 + 2 * s]) / 1e3

@@ -132,24 +132,19 @@ panel_chain4_kernel(const ChainArgs g) {
     set_stage(static_cast<const char*>(g.st[0].w) + wd, (int)(pk & 31u), (int)(((pk >> 5) & 127u) << 2), (int)((pk >> 12) & 1023u), (int)(pk >> 22));
   };
   // Validity of a fetched k-tile (kt < nk of the fetched stage) is decided once per TRIP for three slot groups -- a stage has at least
-  // two k-tiles: slots 0-1 always carry one, slots 2-3 iff more than 2 remain, slots 4-7 iff more than 4 -- so the loop body holds no
-  // select; the piece index rides in the instruction's immediate offset, the k-tile in the scalar offset.  (The validity cannot live in
+  // two k-tiles: slots 0-1 always carry one, slots 2-3 iff more than 2 remain, slots 4-7 iff more than 4 -- so the loop body holds one
+  // select per piece (on a scalar condition); the piece index rides in the instruction's immediate offset, the k-tile in the scalar offset.  (The validity cannot live in
   // the descriptor -- zero records for an invalid group: the hardware checks offset >= num_records - scalar offset, which wraps.)
-  unsigned vo[3][2];
+  int fleft = 0;                                         // fnk - fk of the fetched trip (a scalar: the six selected offsets as registers
+                                                         // were the ones the allocator spilled across the stage loop)
   int fsoff = 0;                                         // fk * 4096
   auto trip_offsets = [&]() {
-    const int left = fnk - fk;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned v = j ? fvoff1 : fvoff0;
-      vo[0][j] = left > 0 ? v : kOob3;
-      vo[1][j] = left > 2 ? v : kOob3;
-      vo[2][j] = left > 4 ? v : kOob3;
-    }
+    fleft = fnk - fk;
     fsoff = fk * 4096;
   };
   auto piece = [&](int u, int j, int i) {
-    const unsigned v = vo[u < 2 ? 0 : (u < 4 ? 1 : 2)][j];
+    const bool ok = fleft > (u < 2 ? 0 : (u < 4 ? 2 : 4));
+    const unsigned v = ok ? (j ? fvoff1 : fvoff0) : kOob3;
     wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, v + i * 1024, fsoff + u * 4096, 0));
   };
   auto advance = [&]() {
@@ -179,25 +174,61 @@ panel_chain4_kernel(const ChainArgs g) {
       }
     }
     stamp(56);
-    // the head of the weight stream goes out BEHIND the rows (memory returns in order: the rows -- which the conversion below waits
-    // for -- are not queued behind 64 KiB of weights per wave)
+    // The head of the weight stream goes out BEHIND the rows (memory returns in order), and in two halves around the conversion: k-tiles
+    // 0-3 travel while the rows are split into their panels, k-tiles 4-7 and the parameter DMA follow.  (All 64 loads of a wave first:
+    // the conversion then waited for the whole head -- 8.9 kcyc of issue back-pressure at launch start -- before it touched a row.)
     open_stage_k(0);
     trip_offsets();
 #pragma unroll
-    for (int u = 0; u < kDepth; ++u)
+    for (int u = 0; u < kDepth / 2; ++u)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) piece(u, j, i);
-    // (the head of the stream: the table does not exist yet, and stage 1 is opened through the kernel arguments -- written out, not a
-    //  flag of advance(): two paths to &g.st[fs] that meet make the compiler copy all of `g` to scratch)
+    stamp(59);
+    // What the rows do not overwrite starts as zeros: panel 2, a panel without a source, and the k-tiles beyond D of the others -- a short
+    // stage (nk = 4) multiplies tiles 4-7 of its source rows with zero weights, and 0 x NaN from whatever the LDS held would poison the
+    // accumulators.  (Disjoint from what the conversion writes: no barrier between the two.)
+    {
+      const int dt = g.D >> 5;                                      // k-tiles the rows fill
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {
+        const bool whole = pi == 2 || !(pi == 0 ? g.in0 : g.in1);
+        if (!whole && dt == 8) continue;
+        char* P = panel_ptr(pi);
+        // a row is 8 k-tiles x 8 chunks of 16 bytes (XOR-swizzled within the row): chunk index c of row r holds tile (c ^ (r & 15)) >> 3
+        for (int o = tid; o < kRows * 64; o += 256) {
+          const int r = o >> 6, c = o & 63;
+          if (whole || (((c ^ (r & 15)) >> 3) >= dt)) *reinterpret_cast<float4*>(P + r * 1024 + c * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+      if (!(pi == 0 ? g.in0 : g.in1)) continue;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int e = tid + 256 * it, r = e / q4, j = e - r * q4;
+        if (r >= kRows) continue;
+        const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
+        panel_put4(panel_ptr(pi), r, j >> 3, (j & 7) * 4, xv);
+      }
+    }
+    stamp(58);
+#pragma unroll
+    for (int u = kDepth / 2; u < kDepth; ++u)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) piece(u, j, i);
+    // (the head of the stream: stage 1 is opened through the kernel arguments -- written out, not a flag of advance(): two paths to
+    //  &g.st[fs] that meet make the compiler copy all of `g` to scratch)
     fk += kDepth;
     if (fk >= fpad) {
       fk = 0;
       if (g.nstages > 1) { fs = 1; open_stage_k(1); } else { fnk = 0; }
     }
     trip_offsets();
-    stamp(59);
     // ---- epilogue parameters of the whole program -> LDS by LDS-DMA (stage s by wave s mod 4) ----------------------------------
     if (g.prm) {
       const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.prm), 0, (unsigned)g.nstages * 3072u, 0x00020000);
@@ -226,25 +257,8 @@ panel_chain4_kernel(const ChainArgs g) {
       }
     }
 
-    // the three panels start as zeros (while the rows above are in flight): a short stage (nk = 4) multiplies tiles 4-7 of its source
-    // rows with zero weights, and 0 x NaN from whatever the LDS held would poison the accumulators
-    for (int o = tid * 16; o < 3 * kPanelBytes; o += 256 * 16) *reinterpret_cast<float4*>(smem + kPOff + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-    lds_barrier4();
-    stamp(57);
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      if (!(pi == 0 ? g.in0 : g.in1)) continue;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int e = tid + 256 * it, r = e / q4, j = e - r * q4;
-        if (r >= kRows) continue;
-        const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
-        panel_put4(panel_ptr(pi), r, j >> 3, (j & 7) * 4, xv);
-      }
-    }
   }
-  stamp(58);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first trip of weights landed (the parameter DMA too: issued in front of the rows)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the first trip of weights and the parameter DMA landed
   lds_barrier4();
   stamp(1);
 
@@ -661,6 +675,70 @@ panel_chain4_kernel(const ChainArgs g) {
       continue;
     }
 
+    // ---- fast path: a plain Dense stage of whole 32-column blocks -- y = x.W + b (+ pos_weight * PE[t]) -> HBM rows and / or another panel
+    // (the folded ActNorm o InvertibleLinear and the pre_projection of a flow step: flow.py:149-166, transform.py:45-51) -----------------
+    if (!st.gamma && st.res < 0 && st.act == ACT_IDENTITY && st.acc_mode == 0 && !(st.n & 31) && (st.out ? st.out_fmt == 0 : st.dst >= 0) &&
+        !(st.dst >= 0 && (st.dst == st.a0 || (st.asw < st.nk && st.dst == st.a1))) && !(g.cpl_stage > 0 && si == g.cpl_stage) && wave_on) {
+      const float* sp = prm + si * 256;
+      const int row = m0 + l31;
+      const bool rok = row < mend;
+      const bool j1 = 64 * wave + 32 < st.n;                            // (wave-uniform; block 0 exists: wave_on)
+      const float* prow = st.pe ? st.pe + (size_t)(row % st.pe_T) * st.n + 64 * wave + 4 * half : nullptr;
+      float* orow = st.out ? st.out + (size_t)row * st.ldo + 64 * wave + 4 * half : nullptr;
+      char* Dp = panel_ptr(st.dst >= 0 ? st.dst : 0);
+      // one 32-column block at a time (both at once: 24 spilled registers): PE reads first -- the slowest of the stage --, then bias,
+      // values, split, the eight panel stores, the four row stores
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !j1) continue;
+        float4 p4[4];
+        if (st.pe) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) p4[q] = rok ? *reinterpret_cast<const float4*>(prow + 32 * j + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 bi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bi[q] = *reinterpret_cast<const float4*>(sp + 32 * (2 * wave + j) + 8 * q + 4 * half);
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[4 * q + 0] = acc[j][4 * q + 0] * st.scale + bi[q].x;
+          v[4 * q + 1] = acc[j][4 * q + 1] * st.scale + bi[q].y;
+          v[4 * q + 2] = acc[j][4 * q + 2] * st.scale + bi[q].z;
+          v[4 * q + 3] = acc[j][4 * q + 3] * st.scale + bi[q].w;
+        }
+        if (st.pe) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { v[4 * q] += st.pe_w * p4[q].x; v[4 * q + 1] += st.pe_w * p4[q].y; v[4 * q + 2] += st.pe_w * p4[q].z; v[4 * q + 3] += st.pe_w * p4[q].w; }
+        }
+        if (st.dst >= 0) {
+          h16x4 xh[4], xl[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = v[4 * q + e];
+              const _Float16 hh = (_Float16)x;
+              xh[q][e] = hh; xl[q][e] = (_Float16)(x - (float)hh);
+            }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int po = panel_off4(l31, 2 * wave + j, q) + 8 * half;
+            *reinterpret_cast<h16x4*>(Dp + po) = xh[q];
+            *reinterpret_cast<h16x4*>(Dp + (po ^ 64)) = xl[q];
+          }
+        }
+        if (st.out && rok) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) out_store4(orow + 32 * j + 8 * q, v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+      }
+      wstamp(si, 5);
+      if (st.sync_after) lds_barrier4();
+      stamp(3 + 2 * si); wstamp(si, 3);
+      continue;
+    }
+    // (same, for a wave without columns in this stage: nothing to do but the barrier)
     // ---- fast path: the full-width residual + LayerNorm stage (att_proj1 / att_proj2 / FFN dense2 of a block: attention.py:449-452,
     // utils.py:50-53), straight-line: every LDS read of a phase is issued before the arithmetic that needs it (see the hidden path) ------
     if (st.gamma && st.n == 256 && !st.pe && st.res >= 0 && !st.out_pre && !st.out_stats && st.out_fmt == 0 && st.act == ACT_IDENTITY &&

@@ -287,13 +287,14 @@ def run_rank(args):
         eng.profile_reset()
         traffic, traffic_note = load_traffic_record()
         kernel_ms = {c: p["ms"] / ps for c, p in prof.items()}
-        # the chain class = every panel_chain_kernel launch: the ones that also write the decoder alignments ("chain_ali") included
+        # the chain class = every panel_chain4_kernel / panel_chain_kernel launch: the ones that also write the decoder alignments ("chain_ali") included
         fused_ali = dict(prof["chain_ali"])
         for k in ("ms", "launches", "flops"):
             prof["chain"][k] += prof["chain_ali"][k]
         prof["chain_ali"] = {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0}
-        names = {"chain": "panel_chain_kernel (row-panel chains of the attention blocks: att_proj+LN -> query; att_proj+LN -> FFN -> LN "
-                          "-> next Q|K|V / heads), 3-term split-fp16 MFMA 32x32x16",
+        names = {"chain": "panel_chain4_kernel (row-panel chains of the attention blocks, one wave per SIMD since round 5: att_proj+LN -> query -> "
+                          "cross-attention -> att_proj+LN -> FFN -> LN -> next Q|K|V / heads; csrc/gemm3c.hip; panel_chain_kernel<1> with "
+                          "chain_waves4 = 0 and in the training step), 3-term split-fp16 MFMA 32x32x16",
                  "gemm": "gemm2_kernel family (LDS-DMA ring; Dense / concat / Conv1D / LN epilogues), 3-term split-fp16 MFMA 32x32x16",
                  "gemm_fp32": "gemm2_kernel family on exact fp32 MFMA 32x32x2"}
         mm = {c: prof[c] for c in ("chain", "gemm", "gemm_fp32") if prof[c]["launches"]}
@@ -331,7 +332,7 @@ def run_rank(args):
             # is no stand-alone (HBM-bound) cross-attention kernel left to price against 8 TB/s.  What the fused launch moves and takes:
             n = fused_ali["launches"]
             out["roofline_cross_attention"] = {
-                "kernel": "none: the decoder blocks' cross-attention (alignments included) is a phase of panel_chain_kernel<1> since round 4",
+                "kernel": "none: the decoder blocks' cross-attention (alignments included) is a phase of the chain kernel (panel_chain4_kernel) since round 4",
                 "fused_launch": {"launches_per_step": n // ps, "avg_launch_us": 1e3 * fused_ali["ms"] / n,
                                  "algorithmic_tflops": fused_ali["flops"] / (fused_ali["ms"] * 1e-3) / 1e12,
                                  "frac_f16_peak_executed": SPLIT_TERMS * fused_ali["flops"] / (fused_ali["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
@@ -438,6 +439,24 @@ def run_rank(args):
                              "note": "engine option split_fp16=0: every GEMM / attention product on v_mfma_f32_32x32x2_f32; max_abs_mel_err "
                                      "against the fp32 oracle is in `parity` (split path) and below (exact path)"}
         out["_mel_exact"] = _HostArray(mel_e.numpy())            # (host copy: the engines are closed before the CPU baseline runs)
+    if rank == 0 and not args.exact_fp32 and not args.no_exact_pass and not any(o.startswith("chain_waves4=") for o in (args.opt or [])):
+        # ---- the same step on the 8-wave chain kernel of rounds 1-4 (engine option chain_waves4 = 0), same box, same handle ------------------
+        import numpy as _np
+        eng.set_option("chain_waves4", 0)
+        for _ in range(3):
+            run_on(lanes[0])
+        eng.synchronize()
+        t8 = time.perf_counter()
+        n8 = max(5, args.steps // 2)
+        for _ in range(n8):
+            mel_8, _a8 = run_on(lanes[0])
+        eng.synchronize()
+        ms8 = 1e3 * (time.perf_counter() - t8) / n8
+        eng.set_option("chain_waves4", 1)
+        out["chain_kernel_8wave"] = {"ms_per_step": ms8, "max_abs_mel_diff_vs_default": float(_np.abs(mel_8.numpy() - mel.numpy()).max()),
+                                     "note": "engine option chain_waves4=0: the row-panel chains on panel_chain_kernel<1> (8 waves, rounds 1-4) instead "
+                                             "of panel_chain4_kernel (one wave per SIMD + L2-warming prefetch workgroups); box clocks differ by a few "
+                                             "per cent, this is the same-box comparison"}
     # ---- side block: several independent batches in flight on one GPU (every rank; rank 0 reports) --------------------------
     if args.in_flight > 1 and nstreams == 1:
         extra = [make_lane(si, True) for si in range(args.in_flight)]

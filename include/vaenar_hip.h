@@ -298,8 +298,14 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * "n_sample" (default 1): hps.Train.num_samples for vnr_elbo_fwd / vnr_train_step (models.py:13,141-178), see vnr_elbo_fwd.
  * "deterministic" (default 0): the reference pins TF_DETERMINISTIC_OPS=1 and every seed (train.py:17-32); with 1 vnr_train_step
  * accumulates every gradient in a fixed order (no float atomics): two identical steps give bit-identical gradients and variables.
- * "chain_waves4" (default 0): 32-row chain launches on the one-wave-per-SIMD kernel (csrc/gemm3c.hip: 4 waves x 64 columns, 8 k-tiles
- * of weight operands in flight per wave) instead of the 8-wave kernel of csrc/gemm3.hip; same programs, same arithmetic.
+ * "chain_waves4" (default 1 since round 5): 32-row chain launches of the inference path on the one-wave-per-SIMD kernel
+ * (csrc/gemm3c.hip: 4 waves x 64 columns, 8 k-tiles of weight operands in flight per wave) instead of the 8-wave kernel of
+ * csrc/gemm3.hip (0); same programs, the same split products in another accumulation order.  Programs the 4-wave kernel does not
+ * take (irregular k ranges, scratch beyond 160 KB of LDS, the training chains) run on the 8-wave kernel either way.
+ * "chain_prefetch" (default 1, with chain_waves4): workgroups on the CUs a chain launch leaves idle walk its weight images a few
+ * stages ahead of the workers of their XCD (L2 warming, csrc/chain_prefetch.h).  "chain_segments" (default 1, with chain_waves4):
+ * the 32-row panels of a launch with the fused cross-attention start at utterance boundaries (ceil(T / 32) workgroups per
+ * utterance) so that no workgroup attends for two utterances.
  * "range_guard" (default 1): see "Arithmetic contract of the split path" below; setting it (to either value) forgets the surveys. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 

@@ -32,6 +32,7 @@ for (M, Dw, ns), ts in seen.items():
         print("  stage %2d: loop %.2f  epilogue %.2f kcyc" % (s, loop, epi))
     print("  sum of loops %.1f, of epilogues %.1f kcyc" % (tl, te))
     w = ts[:, 64:128].reshape(len(ts), 8, 8)
+    if ts[:, 56].any(): w = w[:, :4, :]                      # (the 4-wave kernel: slots 96.. carry real-time stamps, not waves 4-7)
     if w[:, :, 0].any():
         nzw = w[:, :, 0].any(axis=0)                          # (the 4-wave kernel stamps four waves)
         w = w[:, nzw, :]

@@ -34,6 +34,9 @@ for PP in "$P1" "$P2" "$P3"; do
 done
 python3 tools/trim_chain_pmc.py $O/chain_pmc.txt $(python3 -c 'import bench; print(bench.kernel_source_digest())') > $O/chain_pmc_trimmed.txt
 rm -f /tmp/cts.bin; VNR_CHAIN_TS=/tmp/cts.bin VNR_CHAIN_TS_STAGE=1 python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/chain_timeline.py /tmp/cts.bin > $O/chain_rows32_timeline.txt 2>&1
+python3 tools/r05_ts_sum.py /tmp/cts.bin > $O/chain_cycle_sums.txt 2>&1
+rm -f /tmp/cts8.bin; VNR_CHAIN_WAVES4=0 VNR_CHAIN_TS=/tmp/cts8.bin VNR_CHAIN_TS_STAGE=1 python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/chain_timeline.py /tmp/cts8.bin > $O/chain_timeline_waves8.txt 2>&1
+echo "--- chain_waves4 = 0 (the 8-wave kernel) on the same box:" >> $O/chain_cycle_sums.txt; python3 tools/r05_ts_sum.py /tmp/cts8.bin >> $O/chain_cycle_sums.txt 2>&1
 rm -f /tmp/g.ts; VNR_GEMM_TS=/tmp/g.ts python3 tools/s1_once.py > /dev/null 2>&1; python3 tools/gemm_timeline.py /tmp/g.ts > $O/gemm_timeline.txt 2>&1
 rocprofv3 --kernel-trace -d $O/sq -o s -- python3 bench.py --steps 6 --warmup 3 --profile-steps 0 $P > $O/sq.log 2>&1; python3 tools/launch_sequence.py $(ls $O/sq/*.db $O/sq/*/*.db 2>/dev/null | head -1) > $O/launch_sequence.txt; rm -rf $O/sq
 tail -c 600 $O/bench.json; echo; head -14 $O/kernel_stats.txt | cut -c1-140; head -8 $O/hbm_traffic_pmc.txt | cut -c1-140; cat $O/hbm_traffic.json | head -14

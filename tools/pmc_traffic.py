@@ -57,7 +57,7 @@ def main():
                       "--profile-steps 1 --in-flight 0 --no-train --no-cpu-baseline`; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                       "(gfx950 wide-read correction), WRITE_SIZE uncalibrated; KiB*1024",
             "kernel_source_digest": kernel_source_digest(),      # bench.py prints these figures only while the kernel sources are the same
-            "chain_bytes_per_launch": total(lambda k: "panel_chain_kernel" in k),
+            "chain_bytes_per_launch": total(lambda k: "panel_chain_kernel" in k or "panel_chain4_kernel" in k),
             "gemm_bytes_per_launch": total(lambda k: gemm2_split(k) is True),
             "gemm_fp32_bytes_per_launch": total(lambda k: gemm2_split(k) is False or "gemm_kernel" in k),
             "cross_attention_ali_bytes_per_launch": total(lambda k: "attn3_kernel<true>" in k or "attn2_kernel<true>" in k),

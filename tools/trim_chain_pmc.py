@@ -9,7 +9,7 @@ src = open(sys.argv[1]).read().split('\n\n')
 digest = sys.argv[2] if len(sys.argv) > 2 else "?"
 out = ["# SQ counters of the S1 inference step per kernel (tools/collect_profiles_r05.sh: three separate `rocprofv3 --kernel-trace --pmc ...`",
        "# passes of tools/s1_once.py, averages per dispatch; weight-preparation kernels of vnr_finalize_weights left out).  Kernel sources %s." % digest,
-       "# panel_chain_kernel<1>: 15 launches per step (13 block launches with everything of a block behind its self-attention, the coupling and",
+       "# panel_chain4_kernel (panel_chain_kernel<1> before the 4-wave kernel became the default): 15 launches per step (13 block launches with everything of a block behind its self-attention, the coupling and",
        "# the next pre-chain, + the first pre-chain): see the ratios at the end."]
 keep = ("kernel ", "vnr::panel_chain", "vnr::attn3", "vnr::gemm2_kernel", "vnr::layer_norm", "vnr::gather_rows", "panel_chain", "attn3", "gemm2_kernel", "layer_norm", "gather_rows")
 vals = {}
@@ -21,11 +21,11 @@ for blk in src:
     out += [l[:260] for l in lines if l.startswith(keep)]
     names = lines[0].split()[3:]
     for l in lines:
-        if "panel_chain_kernel<1>" in l.split("(")[0]:
+        if "panel_chain4_kernel" in l.split("(")[0] or "panel_chain_kernel<1>" in l.split("(")[0]:
             nums = l.split(")")[-1].split()
             for n, v in zip(names, nums[2:]):
                 vals.setdefault(n, []).append(float(v))
-out += ["", "# panel_chain_kernel<1>, mean over its launches of one step (counter names as rocprofv3 prints them, truncated on the left):"]
+out += ["", "# the chain kernel, mean over its launches of one step (counter names as rocprofv3 prints them, truncated on the left):"]
 out += ["#   %-18s %.4g" % (n, statistics.mean(v)) for n, v in vals.items()]
 
 

@@ -13,11 +13,9 @@ for (M, Dw, ns), ts in seen.items():
                                                                        np.median(ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3))
     life = (ts[:, 1 + 2 * ns] - ts[:, 0]) / 1e3
     print("  lifetime p10 %.1f  p90 %.1f  max %.1f kcyc" % (np.percentile(life, 10), np.percentile(life, 90), life.max()))
-    # s_memtime counts per XCD (different bases): spans only within workgroup index mod 8
+    # s_memtime counts per XCD / shader engine (different bases): lifetimes compare, start and end times across workgroups do not
     xs = [np.arange(len(ts)) % 8 == x for x in range(8)]
     print("  by XCD (workgroup mod 8): median lifetime " + " ".join("%6.1f" % np.median(life[m]) for m in xs))
-    print("                            start spread    " + " ".join("%6.1f" % ((ts[m, 0].max() - ts[m, 0].min()) / 1e3) for m in xs))
-    print("                            first start -> last end " + " ".join("%6.1f" % ((ts[m, 1 + 2 * ns].max() - ts[m, 0].min()) / 1e3) for m in xs))
     if att and ts[:, 61].any():
         print("  attention phase: %.2f kcyc (inside stage %d's \"loop\" figure below)" % (np.median(ts[:, 61] - ts[:, 60]) / 1e3, att))
     print("  panel load: %.2f kcyc" % (np.median(ts[:, 1] - ts[:, 0]) / 1e3))
@@ -38,4 +36,5 @@ for (M, Dw, ns), ts in seen.items():
         w = w[:, nzw, :]
         base = w[:, :, 0].min(axis=1, keepdims=True)
         for i, name in ((0, "stage start"), (1, "loop end"), (4, "values ready"), (6, "residual / PE added"), (7, "row statistics ready"), (2, "after LN / in-place barrier"), (5, "outputs issued"), (3, "stage end (barrier)")):
+            if not w[:, :, i].any(): continue                  # (a stamp this stage's path does not take)
             print("  per wave %-28s" % name, " ".join("%6.2f" % x for x in np.median(w[:, :, i] - base, axis=0) / 1e3))

@@ -378,10 +378,10 @@ def test_s1_against_fp32_oracle(rows64):
 
 
 def test_s1_both_chain_kernels_against_float64_oracle():
-    """The two generations of the row-panel chain kernel on the bench workload against the float64 oracle.  The 8-wave kernel
-    (chain_waves4 = 0) sits at fp32 round-off level (3e-6); the 4-wave kernel's launches with the fused cross-attention come out
-    ~3e-5 off -- cause open, DESIGN.md section 8 -- which is why the alignment-writing launches of the decoder stay on the 8-wave
-    kernel.  Both bounds are far inside the 1e-3 contract; this test keeps the gap from growing unnoticed."""
+    """The two generations of the row-panel chain kernel on the bench workload against the float64 oracle: both at fp32 round-off
+    level (3e-6).  The 4-wave kernel once sat at 1.3e-4: its hi / lo splits stored the high halves from v_cvt_pk_f16_f32 and took
+    the low halves from a separate v_cvt_f16_f32, which on gfx950 do not round every input alike (csrc/gemm3c.hip: split_hi_lo;
+    profiles/r05_experiments.txt r05i) -- well inside the 1e-3 contract, invisible to every other test, hence this one."""
     hps = LJHPS
     w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
     b = make_batch(16, 128, 800, ragged=False, seed=1234, temperature=1.0)
@@ -394,7 +394,7 @@ def test_s1_both_chain_kernels_against_float64_oracle():
             mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
             err[w4] = float(np.abs(mel.numpy() - ref).max())
         print("S1 max-abs mel err vs float64 oracle: 4-wave kernel %.3e, 8-wave kernel %.3e" % (err[1], err[0]))
-        assert err[0] < 1e-5 and err[1] < 6e-5, err
+        assert err[0] < 1e-5 and err[1] < 1e-5, err
     finally:
         model.engine.close()
 

@@ -442,10 +442,10 @@ def test_blocks_without_alignments_fused_and_unfused(B, Tt, Tm, text_step):
                 launches[fuse] = model.engine.launch_count() - n0
             assert not ali
             assert np.abs(mels[fuse] - rmel).max() < 2e-4
-        # (both forms are within 2e-4 of the oracle above.  They are not the same arithmetic since round 5: the fused launches run on the
-        #  4-wave chain kernel with panels that start at utterance boundaries, the three-launch form's chain C + coupling tail does not fit
-        #  that kernel's LDS budget and runs on the 8-wave kernel -- another accumulation order of the same split products)
-        assert np.abs(mels[1] - mels[0]).max() < 2e-4
+        # (the fused launches run on the 4-wave chain kernel with panels that start at utterance boundaries, the three-launch form's chain C
+        #  + coupling tail does not fit that kernel's LDS budget and runs on the 8-wave kernel: another accumulation order of the same
+        #  split products)
+        assert np.abs(mels[1] - mels[0]).max() < 2e-5
         assert launches[0] - launches[1] >= 2 * 12, launches        # 12 prior blocks + 2 decoder blocks, two launches saved each
     finally:
         model.engine.close()

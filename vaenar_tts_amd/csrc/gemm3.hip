@@ -890,11 +890,6 @@ hipError_t launch_panel_chain(const ChainArgs& g_in, hipStream_t s) {
       if (st.kt_total >= 1024 || st.kt0 >= 1024 || st.kt_total < 0 || st.kt0 < 0) g.waves4 = 0;      // (its fetch table packs them into 10 bits each)
     }
     if (g.D != 256 && g.D != 128) g.waves4 = 0;
-    // Launches that also write the alignments (the decoder's blocks) stay on the 8-wave kernel: the 4-wave kernel's fused-attention launches
-    // come out ~5e-5 (relative) off the 8-wave kernel's per block -- cause not found, see DESIGN.md section 8 -- and the decoder's two blocks
-    // are the last of the step: nothing behind them attenuates it (S1 mel error against the float64 oracle: 1.3e-4 with them on the 4-wave
-    // kernel, 3.3e-5 without, 3.3e-6 all on the 8-wave kernel; tolerance 1e-3)
-    if (g.att_ali) g.waves4 = 0;
   }
   if (g.waves4) {                                       // gemm3c.hip turns the V-type stages of a Q|K|V tail through LDS: wave-private 2 x 32 x 33 floats
     bool anyv = false;

@@ -44,11 +44,30 @@ __device__ __forceinline__ void lds_barrier4() {
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ int panel_off4(int r, int kt, int c) { return r * 1024 + ((((kt << 3) + c) ^ (r & 15)) << 4); }
+// x = hi + lo in fp16, the low part derived from the STORED high bits.  Written "h = (_Float16)x; hi = h; lo = (_Float16)(x - (float)h)" the
+// compiler is free to convert twice -- it packed the stored halves with v_cvt_pk_f16_f32 and took the low part from a separate
+// v_cvt_f16_f32 -- and on gfx950 the two instructions do not round every input alike: about one element in ten thousand came out one
+// fp16 ulp (2^-9 at |x| in [2, 4)) off, which is how the attention context of this kernel lost 1e-4 at the mel until the last day of
+// round 5 (profiles/r05_experiments.txt r05i).  Vector-typed conversions give the compiler ONE node for the high part: whatever
+// instruction it picks, the stored bits and the subtracted ones are the same.  (An empty asm on the packed register does it too, but pins
+// registers: two spilled.)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_hi_lo(const float (&x)[4], h16x4& hi, h16x4& lo) {
+  const f32x4v xv = {x[0], x[1], x[2], x[3]};
+  hi = __builtin_convertvector(xv, h16x4);               // ONE conversion node: the stored bits and the ones subtracted are the same
+  lo = __builtin_convertvector(xv - __builtin_convertvector(hi, f32x4v), h16x4);
+}
+__device__ __forceinline__ void split_hi_lo(const float (&x)[8], h16x8& hi, h16x8& lo) {
+  const f32x8v xv = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+  hi = __builtin_convertvector(xv, h16x8);
+  lo = __builtin_convertvector(xv - __builtin_convertvector(hi, f32x8v), h16x8);
+}
 // split-fp16 store of 4 consecutive columns [p, p + 4) (p % 4 == 0) of k-tile kt, row r
 __device__ __forceinline__ void panel_put4(char* P, int r, int kt, int p, const float* x) {
   h16x4 hi, lo;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+  const float xx[4] = {x[0], x[1], x[2], x[3]};
+  split_hi_lo(xx, hi, lo);
   *reinterpret_cast<h16x4*>(P + panel_off4(r, kt, p >> 3) + (p & 4) * 2) = hi;
   *reinterpret_cast<h16x4*>(P + panel_off4(r, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
 }
@@ -93,14 +112,17 @@ panel_chain4_kernel(const ChainArgs g) {
   // (fs, fk) therefore runs exactly one trip ahead of the multiplier, across stage boundaries, and every wait is a static vmcnt.
   h16x8 wreg[kDepth][2][4];
   int fs = 0, fk = 0, fnk = 0, fpad = 0;
-  unsigned fvoff0 = kOob3, fvoff1 = kOob3;
+  unsigned fvoff0 = kOob3;                               // offset of this lane in column block 2 wave of the fetched stage (or out of range)
+  int fjd = 0;                                           // + this (a scalar) = column block 2 wave + 1; fj1: that block exists
+  bool fj1 = false;
   __amdgpu_buffer_rsrc_t frs;
   auto set_stage = [&](const void* w, int nk, int n, int ktt, int k0) {
     frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x40000000, 0x00020000);
     fnk = nk;
     fpad = (nk + kDepth - 1) / kDepth * kDepth;
     fvoff0 = (64 * wave < n) ? (unsigned)(((2 * wave) * ktt + k0) * 4096 + lane * 16) : kOob3;
-    fvoff1 = (64 * wave + 32 < n) ? (unsigned)(((2 * wave + 1) * ktt + k0) * 4096 + lane * 16) : kOob3;
+    fjd = ktt * 4096;
+    fj1 = 64 * wave + 32 < n;
   };
   // The fetch cursor opens a stage from a table held in three REGISTERS -- lane s = stage s: the image address as a distance from stage
   // 0's image (two dwords) and nk | n / 4 | kt_total | kt0 packed into one -- with three v_readlane.  Through the kernel-argument segment
@@ -144,7 +166,7 @@ panel_chain4_kernel(const ChainArgs g) {
   };
   auto piece = [&](int u, int j, int i) {
     const bool ok = fleft > (u < 2 ? 0 : (u < 4 ? 2 : 4));
-    const unsigned v = ok ? (j ? fvoff1 : fvoff0) : kOob3;
+    const unsigned v = (ok && (j == 0 || fj1)) ? fvoff0 + (j ? (unsigned)fjd : 0u) : kOob3;      // (one register for both column blocks)
     wreg[u][j][i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, v + i * 1024, fsoff + u * 4096, 0));
   };
   auto advance = [&]() {
@@ -365,8 +387,10 @@ panel_chain4_kernel(const ChainArgs g) {
               }
             }
             h16x8 phi, plo;
+            float pv8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)sacc[8 * tp + e]; phi[e] = hh; plo[e] = (_Float16)(sacc[8 * tp + e] - (float)hh); }
+            for (int e = 0; e < 8; ++e) pv8[e] = sacc[8 * tp + e];
+            split_hi_lo(pv8, phi, plo);
             O[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][0], phi, O[0], 0, 0, 0);
             O[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][1], phi, O[1], 0, 0, 0);
             O[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo[tp][0], phi, O[0], 0, 0, 0);
@@ -545,12 +569,10 @@ panel_chain4_kernel(const ChainArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
+          float x4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = fmaxf(acc[j][4 * q + e] * st.scale + bq[e], floor_v);
-            const _Float16 h = (_Float16)x;
-            xh[j][q][e] = h; xl[j][q][e] = (_Float16)(x - (float)h);
-          }
+          for (int e = 0; e < 4; ++e) x4[e] = fmaxf(acc[j][4 * q + e] * st.scale + bq[e], floor_v);
+          split_hi_lo(x4, xh[j][q], xl[j][q]);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -607,8 +629,10 @@ panel_chain4_kernel(const ChainArgs g) {
             if (R >= mend) continue;
             const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
             h16x8 hi, lo;
+            float x8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)x[j][tp][e]; hi[e] = hh; lo[e] = (_Float16)(x[j][tp][e] - (float)hh); }
+            for (int e = 0; e < 8; ++e) x8[e] = x[j][tp][e];
+            split_hi_lo(x8, hi, lo);
             char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
                          ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
             *reinterpret_cast<h16x8*>(pdst) = hi;
@@ -647,12 +671,10 @@ panel_chain4_kernel(const ChainArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
+          float x4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = acc[j][4 * q + e] * st.scale + bq[e];
-            const _Float16 h = (_Float16)x;
-            xh[j][q][e] = h; xl[j][q][e] = (_Float16)(x - (float)h);
-          }
+          for (int e = 0; e < 4; ++e) x4[e] = acc[j][4 * q + e] * st.scale + bq[e];
+          split_hi_lo(x4, xh[j][q], xl[j][q]);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -714,13 +736,10 @@ panel_chain4_kernel(const ChainArgs g) {
         if (st.dst >= 0) {
           h16x4 xh[4], xl[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float x = v[4 * q + e];
-              const _Float16 hh = (_Float16)x;
-              xh[q][e] = hh; xl[q][e] = (_Float16)(x - (float)hh);
-            }
+          for (int q = 0; q < 4; ++q) {
+            const float x4[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            split_hi_lo(x4, xh[q], xl[q]);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int po = panel_off4(l31, 2 * wave + j, q) + 8 * half;
@@ -812,13 +831,10 @@ panel_chain4_kernel(const ChainArgs g) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float gq[4] = {ga[j][q].x, ga[j][q].y, ga[j][q].z, ga[j][q].w}, eq[4] = {be[j][q].x, be[j][q].y, be[j][q].z, be[j][q].w};
+          float x4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = (v[j][4 * q + e] - mu) * rstd * gq[e] + eq[e];
-            v[j][4 * q + e] = x;
-            const _Float16 hh = (_Float16)x;
-            xh[j][q][e] = hh; xl[j][q][e] = (_Float16)(x - (float)hh);
-          }
+          for (int e = 0; e < 4; ++e) { x4[e] = (v[j][4 * q + e] - mu) * rstd * gq[e] + eq[e]; v[j][4 * q + e] = x4[e]; }
+          split_hi_lo(x4, xh[j][q], xl[j][q]);
         }
       wstamp(si, 2);
       __builtin_amdgcn_sched_barrier(0);
@@ -1046,8 +1062,10 @@ panel_chain4_kernel(const ChainArgs g) {
           if (st.out && row < mend) {
             if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
               h16x4 hi, lo;
+              float x4[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[j][4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[j][4 * q + e] - (float)hh); }
+              for (int e = 0; e < 4; ++e) x4[e] = v[j][4 * q + e];
+              split_hi_lo(x4, hi, lo);
               char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
               *reinterpret_cast<h16x4*>(pd) = hi;
               *reinterpret_cast<h16x4*>(pd + 4096) = lo;

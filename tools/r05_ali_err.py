@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """round 5: decoder alignments of both chain kernels against the float64 oracle, absolute and RELATIVE (is the S^T / softmax path of the
-4-wave kernel's attention phase less accurate?).  VNR_CHAIN_W4_ALI=1 lets the alignment-writing launches run on the 4-wave kernel."""
+4-wave kernel's attention phase less accurate?).  (Written while a rule kept alignment-writing launches on the 8-wave kernel;
+VNR_CHAIN_W4_ALI lifted it.  Rule and switch are gone.)"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from vaenar_tts_amd.configs import LJHPS

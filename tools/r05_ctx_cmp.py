@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+"""round 5 debugging aid: compare two VNR_DBG_CTX dump files (see tools/r05_ctx_dump.py) row by row and head by head."""
 import sys, struct
 import numpy as np
 def load(p):

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+"""round 5 debugging aid: VNR_DBG_CTX dumps of a fused launch against the matching unfused launches; min / max / mean / std of the difference
+in the worst rows (a uniform, bounded difference = one wrong input element times a row of uniform weights)."""
 import sys, struct
 import numpy as np
 def load(p):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""round 5 debugging aid: the decoder on the SAME z under one chain kernel, with VNR_DBG_CTX dumping the attention context of its two
-block launches.  usage: VNR_DBG_CTX=<file> [VNR_CHAIN_W4_ALI=1] r05_ctx_dump.py <chain_waves4> <outs.npy>"""
+"""round 5 debugging aid (needs the VNR_DBG_CTX patch of that day -- a float* dbg_ctx in ChainArgs filled by the kernel and dumped by
+launch_panel_chain; removed again, see profiles/r05_experiments.txt r05i): the decoder on the SAME z under one chain kernel, with VNR_DBG_CTX dumping the attention context of its two
+block launches.  usage: VNR_DBG_CTX=<file> r05_ctx_dump.py <chain_waves4> <outs.npy>"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from vaenar_tts_amd.configs import LJHPS

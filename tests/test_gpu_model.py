@@ -379,9 +379,9 @@ def test_s1_against_fp32_oracle(rows64):
 
 def test_s1_both_chain_kernels_against_float64_oracle():
     """The two generations of the row-panel chain kernel on the bench workload against the float64 oracle: both at fp32 round-off
-    level (3e-6).  The 4-wave kernel once sat at 1.3e-4: its hi / lo splits stored the high halves from v_cvt_pk_f16_f32 and took
-    the low halves from a separate v_cvt_f16_f32, which on gfx950 do not round every input alike (csrc/gemm3c.hip: split_hi_lo;
-    profiles/r05_experiments.txt r05i) -- well inside the 1e-3 contract, invisible to every other test, hence this one."""
+    level (3e-6).  The 4-wave kernel once sat at 1.3e-4: under fp contraction the compiler evaluated the high half of its fp16
+    hi / lo split twice -- fused into the multiply for the value it subtracted, unfused for the value it stored -- and one element
+    in ten thousand came out one fp16 ulp off (csrc/gemm3c.hip: split_hi_lo; profiles/r05_experiments.txt r05i) -- well inside the 1e-3 contract, invisible to every other test, hence this one."""
     hps = LJHPS
     w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
     b = make_batch(16, 128, 800, ragged=False, seed=1234, temperature=1.0)

@@ -44,13 +44,14 @@ __device__ __forceinline__ void lds_barrier4() {
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ int panel_off4(int r, int kt, int c) { return r * 1024 + ((((kt << 3) + c) ^ (r & 15)) << 4); }
-// x = hi + lo in fp16, the low part derived from the STORED high bits.  Written "h = (_Float16)x; hi = h; lo = (_Float16)(x - (float)h)" the
-// compiler is free to convert twice -- it packed the stored halves with v_cvt_pk_f16_f32 and took the low part from a separate
-// v_cvt_f16_f32 -- and on gfx950 the two instructions do not round every input alike: about one element in ten thousand came out one
-// fp16 ulp (2^-9 at |x| in [2, 4)) off, which is how the attention context of this kernel lost 1e-4 at the mel until the last day of
-// round 5 (profiles/r05_experiments.txt r05i).  Vector-typed conversions give the compiler ONE node for the high part: whatever
-// instruction it picks, the stored bits and the subtracted ones are the same.  (An empty asm on the packed register does it too, but pins
-// registers: two spilled.)
+// x = hi + lo in fp16, the low part derived from the STORED high bits.  Written "h = (_Float16)x; hi = h; lo = (_Float16)(x - (float)h)"
+// behind "x = O * linv" the compiler (fp contraction, hipcc's default) evaluated h twice: fused into the multiply for the value it
+// subtracted (v_fma_mixlo_f16: ONE rounding of the exact product) and as v_cvt_pk_f16_f32 of the rounded fp32 product for the value it
+// stored (TWO roundings).  The two differ by one fp16 ulp whenever the fp32 rounding crosses an fp16 tie -- about one element in ten
+// thousand of the attention context came out hi + lo = x +- 2^-9, which cost this kernel 1e-4 at the mel until the last day of round 5
+// (profiles/r05_experiments.txt r05i, profiles/r05_cvt_pk_probe.txt).  Vector-typed conversions give the compiler ONE node for the high
+// part: whatever instruction it picks, the stored bits and the subtracted ones are the same.  (An empty asm on the packed register does
+// it too, but pins registers: two spilled.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split_hi_lo(const float (&x)[4], h16x4& hi, h16x4& lo) {
@@ -902,19 +903,28 @@ panel_chain4_kernel(const ChainArgs g) {
               *reinterpret_cast<float4*>(cx + l31 * cst + 32 * (2 * wave + j) + 8 * q + 4 * half) =
                   make_float4(v[j][4 * q], v[j][4 * q + 1], v[j][4 * q + 2], v[j][4 * q + 3]);
       }
+      // the four pieces of z this thread works on are requested BEFORE the exchange barrier (they do not depend on the heads): one memory
+      // round trip under the barrier instead of four behind it
+      const int c = (tid_s & 15) * 4;
+      float4 zo[2][2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          const int row = m0 + 16 * rr + (tid_s >> 4);
+          zo[rr][which] = row < mend ? *reinterpret_cast<const float4*>(g.cpl_z + (size_t)row * g.cpl_ld + (which ? g.cpl_cond_off : g.cpl_zp_off) + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       lds_barrier4();
       {
         char* Dp = panel_ptr(st.dst);
-        const int c = (tid_s & 15) * 4;
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int prow = 16 * rr + (tid_s >> 4), row = m0 + prow;
 #pragma unroll
           for (int which = 0; which < 2; ++which) {
             const int zoff = which ? g.cpl_cond_off : g.cpl_zp_off;
-            float* zp = g.cpl_z + (size_t)row * g.cpl_ld + zoff + c;
-            const float4 zo = row < mend ? *reinterpret_cast<const float4*>(zp) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float o[4] = {zo.x, zo.y, zo.z, zo.w};
+            float o[4] = {zo[rr][which].x, zo[rr][which].y, zo[rr][which].z, zo[rr][which].w};
             if (which == 0) {
               const float4 ls = *reinterpret_cast<const float4*>(cx + prow * cst + c), sh = *reinterpret_cast<const float4*>(cx + prow * cst + 64 + c);
               const float lv[4] = {ls.x, ls.y, ls.z, ls.w}, sv[4] = {sh.x, sh.y, sh.z, sh.w};
@@ -923,7 +933,7 @@ panel_chain4_kernel(const ChainArgs g) {
                 const float scale = 1.0f / (1.0f + expf(-(lv[e] + 2.0f)));                    // tf.math.sigmoid(log_scale + 2), flow.py:231
                 o[e] = scale * o[e] + sv[e];                                                  // _affine, flow.py:216
               }
-              if (row < mend) out_store4(zp, o[0], o[1], o[2], o[3]);
+              if (row < mend) out_store4(g.cpl_z + (size_t)row * g.cpl_ld + zoff + c, o[0], o[1], o[2], o[3]);
             }
             panel_put4(Dp, prow, (zoff + c) >> 5, (zoff + c) & 31, o);
           }

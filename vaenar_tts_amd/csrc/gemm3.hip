@@ -326,13 +326,17 @@ panel_chain_kernel(const ChainArgs g) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                h16x4 hi, lo;
+                // (vector-typed conversions: ONE node for the high halves -- behind a product like this one the compiler may otherwise fuse the
+                //  multiply into the conversion on one side of the split only, gemm3c.hip: split_hi_lo)
+                typedef float f32x4c __attribute__((ext_vector_type(4)));
+                f32x4c xv4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const int r = 4 * q + e;
-                  const float xv = (O[nb][r] * f0 + xh[l31 * 66 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half] * f1) * linv;
-                  const _Float16 hh = (_Float16)xv; hi[e] = hh; lo[e] = (_Float16)(xv - (float)hh);
+                  xv4[e] = (O[nb][r] * f0 + xh[l31 * 66 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * half] * f1) * linv;
                 }
+                const h16x4 hi = __builtin_convertvector(xv4, h16x4);
+                const h16x4 lo = __builtin_convertvector(xv4 - __builtin_convertvector(hi, f32x4c), h16x4);
                 const int pcol = 8 * q + 4 * half;                     // column inside the 32-channel tile 2 head + nb
                 *reinterpret_cast<h16x4*>(Pc + panel_off(l31, 2 * head + nb, pcol >> 3) + (pcol & 4) * 2) = hi;
                 *reinterpret_cast<h16x4*>(Pc + panel_off(l31, 2 * head + nb, 4 + (pcol >> 3)) + (pcol & 4) * 2) = lo;

@@ -18,7 +18,8 @@
  *   - one handle = one device = one HIP stream; a handle is not thread-safe, different
  *     handles are independent (one per GPU process for data parallelism);
  *   - all module calls are asynchronous on the handle's stream; vnr_memcpy_d2h and
- *     vnr_synchronize are the synchronisation points.
+ *     vnr_synchronize are the synchronisation points -- and the checkpoints of the split path's range sentinel: they return
+ *     VNR_ERR_RANGE when an activation left the fp16 range since the previous one ("Arithmetic contract of the split path").
  */
 #ifndef VAENAR_HIP_H
 #define VAENAR_HIP_H
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VNR_ABI_VERSION 5
+#define VNR_ABI_VERSION 6
 
 typedef struct vnr_context *vnr_handle;
 
@@ -40,7 +41,9 @@ typedef enum vnr_status {
   VNR_ERR_HIP = -2,        /* a HIP runtime call failed */
   VNR_ERR_WEIGHT = -3,     /* unknown weight path, shape mismatch, or weights not finalized */
   VNR_ERR_NOMEM = -4,
-  VNR_ERR_STATE = -5
+  VNR_ERR_STATE = -5,
+  VNR_ERR_RANGE = -6       /* the range sentinel of the split-fp16 path tripped ("Arithmetic contract" below): the results computed since the
+                            * previous synchronisation point are invalid, the modules involved have moved to exact fp32 -- issue those calls again */
 } vnr_status;
 
 enum { VNR_ACT_IDENTITY = 0, VNR_ACT_RELU = 1, VNR_ACT_TANH = 2 };
@@ -306,10 +309,12 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * stages ahead of the workers of their XCD (L2 warming, csrc/chain_prefetch.h).  "chain_segments" (default 1, with chain_waves4):
  * the 32-row panels of a launch with the fused cross-attention start at utterance boundaries (ceil(T / 32) workgroups per
  * utterance) so that no workgroup attends for two utterances.
- * "range_guard" (default 1): see "Arithmetic contract of the split path" below; setting it (to either value) forgets the surveys. */
+ * "range_guard" (default 1): see "Arithmetic contract of the split path" below; setting it (to either value) forgets the surveys.
+ * "range_sentinel" (default 1; 0 = the split products are not watched: measurement only) and "train_fp32" (0 / 1: the training step on
+ * exact fp32 MFMA; set by a sentinel trip inside vnr_train_step): same section. */
 int vnr_set_option(vnr_handle h, const char *name, int value);
 
-/* Arithmetic contract of the split path (ABI version 5).
+/* Arithmetic contract of the split path (ABI version 5; the sentinel and the range-free exact mode: version 6).
  *
  * TensorFlow evaluates every Dense / Conv1D / matmul of the path in fp32 (/root/reference/modules/attention.py:217-246,
  * modules/utils.py:44-53,76-85).  With "split_fp16" = 1 a product a*w is evaluated here as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo with
@@ -328,16 +333,39 @@ int vnr_set_option(vnr_handle h, const char *name, int value);
  *     every later call returns) and later calls cost nothing extra;
  *   - a Dense / Conv1D input outside: the modules of that call run on exact fp32 MFMA from then on (fp32 dynamic range, about half
  *     the speed) until their weights change;
- *   - an attention operand outside: the call fails with VNR_ERR_STATE and a message naming the range -- the attention cores split
- *     Q, K and V in every mode and have no exact-fp32 form.
+ *   - an attention operand outside (either side): likewise -- since ABI version 6 the attention cores of the exact mode take per-launch
+ *     power-of-two operand scales from the maxima of Q, K and V (csrc/attention2.hip), so the exact mode has NO window: fp32's dynamic
+ *     range throughout, like the reference's tf.matmul (round 5 refused such weights with VNR_ERR_STATE).
  * All-zero tensors (the noise at temperature 0) are ignored.  vnr_op_dense with "op_dense_split" applies the same window per ROW of
- * its inputs and falls back to the exact kernel.  vnr_train_step is not covered: it pre-scales gradients by their abs-max (csrc/
- * gemm2.hip) and runs its forward unscaled.  Noise of a far larger standard deviation than the surveyed call's needs a fresh
- * survey (set "range_guard" again).
+ * its inputs and falls back to the exact kernel.
  *
+ * The survey is a SAMPLE (one call's inputs); the guarantee is the RANGE SENTINEL ("range_sentinel", default 1; ABI version 6).  What can
+ * go wrong on the split path after the survey is an activation beyond fp16's 65504 -- a longer text, caller tensors (mels, z, injected
+ * noise) of another magnitude, a temperature above 1.  Its split is (+-inf, -+inf); in the consuming product hi*w_hi and lo*w_hi are
+ * infinities of opposite sign, so EVERY accumulator of that row is NaN whatever the weights, and an activation function may heal it
+ * on the way out (fmaxf(NaN, 0) = 0).  Every split product (csrc/gemm2.hip, gemm3.hip, gemm3c.hip) therefore looks at one accumulator per
+ * row right behind its k-loop and raises a host-visible word.  The host reads the word wherever it synchronises with the stream:
+ *   - vnr_synchronize, vnr_memcpy_d2h, vnr_memcpy_h2d (before its copy) return VNR_ERR_RANGE when it is raised: NOTHING computed since
+ *     the previous such call may be trusted (in particular not the bytes vnr_memcpy_d2h just copied).  The modules that ran on the split
+ *     path since then are in state 2 (exact fp32) from that moment; the caller issues the same calls again -- their inputs are
+ *     untouched, every entry point writes its outputs in full -- and gets fp32-exact results.  The Python layer does this by itself
+ *     (vaenar_tts_amd/_lib.py: Engine._replay): a caller of `.numpy()` never sees the error, only a slower call.
+ *   - entry points that change variables cannot be repeated by the caller and check synchronously: training-mode forwards
+ *     ("training" = 1), vnr_init and vnr_prior_init repeat themselves once on exact fp32 before they return; vnr_train_step copies the
+ *     word behind its backward pass, takes the max over the ranks of the communicator, predicates Adam (and every BatchNormalization
+ *     moving update) on it, and when it is raised repeats the step on exact fp32 MFMA with scaled attention cores and fp32
+ *     kernel-gradient GEMMs -- the handle's later steps stay there ("train_fp32" = 1; the option resets it).  On that path the products
+ *     carry no sentinel; one pass over the flat gradient looks for non-finite values instead (the attention BACKWARD kernels still split
+ *     Q, K, V unscaled: operands beyond 65504 there end in VNR_ERR_RANGE with the variables untouched, never in a silent update).
+ * Below the window nothing is detected at run time: a tensor that sinks under 2^-6 on a later call keeps 2^-25 of ABSOLUTE resolution
+ * (fp16 subnormals) -- graceful, not wrong by orders of magnitude; set "range_guard" again for a fresh survey.
+ *
+ * vnr_range_sentinel: trips = checkpoints that found the word raised so far; train_fp32 = 1 once the training step runs on its exact path;
+ * pending_modules = bit mask (bit 0 encoder .. 3 posterior) of modules whose split-path results have not passed a checkpoint yet.
  * vnr_range_info: states4[0..3] = encoder, prior, decoder, posterior: 0 not surveyed, 1 in window (split path), 2 exact fp32 forced;
  * lo / hi = smallest / largest non-zero tensor maximum of the last survey; surveys = number of surveys run.  Any pointer may be NULL. */
 int vnr_range_info(vnr_handle h, int *states4, float *lo, float *hi, int64_t *surveys);
+int vnr_range_sentinel(vnr_handle h, int64_t *trips, int *train_fp32, int *pending_modules);
 /* "training" (default 0) and "dropout_seed": the reference's `training=` argument (modules call signatures) for
  * vnr_text_encoder_fwd / vnr_posterior_fwd / vnr_decoder_fwd / vnr_elbo_fwd: Dropout layers (encoder.py:87,
  * utils.py:15,17,84, posterior.py:122) draw counter-based masks; BatchNormalization (utils.py:79-83) normalises with the

@@ -7,7 +7,8 @@ UNSCALED fp16 hi/lo pairs, which keeps fp32-class accuracy only inside a magnitu
   (ii)  the range guard: a model whose weights are rescaled so that a GEMM input tensor reaches 1e5 or 1e-5 -- mathematically the
         same function, which the oracle and the reference evaluate without trouble -- must still match (the engine surveys the
         ranges on the first call and keeps those modules on exact fp32 MFMA), an in-window model must stay on the split path,
-        and an out-of-window attention operand must be REFUSED with a message, never answered with an inf.
+        out-of-window attention operands run on the exact mode's scaled cores, and (round 6) the range SENTINEL catches what the
+        survey cannot see -- inputs of a LATER call, a training step -- without ever handing out a non-finite number.
 (The operator-level criterion relative to the row's own scale lives in tests/test_gpu_ops.py::test_dense_split_fp16.)"""
 import numpy as np
 import pytest
@@ -151,12 +152,21 @@ def test_range_guard_keeps_a_rescaled_model_exact(factor):
         assert n_split == 0 and n_exact > 0 and model.engine.range_info()["surveys"] == 1
         assert np.array_equal(mel2.numpy(), got)
         # with the guard off the same weights show what it protects against: inf / NaN (1e5) or a mel error far outside fp32 class (1e-5)
-        model.engine.set_option("range_guard", 0)
+        model.engine.set_option("range_guard", 0)          # (forgets the survey's states: the modules are back on the split path)
+        model.engine.set_option("range_sentinel", 0)       # ... unwatched
         raw, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
         bad = raw.numpy()
         unguarded = np.inf if not np.isfinite(bad).all() else np.abs(bad - ref).max()
         print(f"unguarded split path on the rescaled weights: max-abs mel err {unguarded:.3e}")
         assert unguarded > 20 * np.abs(got - ref).max()
+        if factor > 1:
+            # the survey off, the sentinel on: the overflow is caught at the checkpoint and the call replayed on exact fp32 (round 6)
+            model.engine.set_option("range_sentinel", 1)
+            mel4, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+            got4 = mel4.numpy()
+            i4 = model.engine.range_info()
+            print("survey off, sentinel on:", i4)
+            assert np.isfinite(got4).all() and np.abs(got4 - ref).max() < MEL_TOL and i4["sentinel_trips"] == 1 and i4["replays"] == 1
     finally:
         model.engine.close()
 
@@ -190,18 +200,180 @@ def test_range_guard_leaves_an_in_window_model_on_the_split_path():
         model.engine.close()
 
 
-def test_range_guard_refuses_an_out_of_window_attention_operand():
-    """Query kernel x 2^18, key kernel / 2^18 in a decoder block: the logits are unchanged, but the attention core would split a query of
-    order 1e5 -- it has no exact-fp32 form, so the call must fail with a message that names the range (never an inf)."""
+def test_out_of_window_attention_operands_run_on_scaled_cores():
+    """Query kernel x 2^18, key kernel / 2^18 in a decoder block: the logits are unchanged, but the query is of order 1e5 and the key of
+    order 1e-6.  Round 5 refused such weights (its attention cores split Q, K, V unscaled in every mode); since round 6 the survey moves
+    the modules to the exact mode, whose cores take per-launch power-of-two operand scales (attention2.hip: AttnArgs::qkv_absmax) -- the
+    call must succeed and match the float64 oracle of the RESCALED weights, alignments included (attention.py:224-246 has no window)."""
     hps = LJHPS
     w0 = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
     p = "decoder/attentions/0/cross_attention/"
     w = _rescaled(w0, [(p + "query_layer/kernel", 2.0 ** 18), (p + "key_layer/kernel", 2.0 ** -18)])
     b = _batch(hps, "lj")
+    ref, rali = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
     model = VAENAR(hps, weights=w)
     try:
-        with pytest.raises(_lib.VnrError) as ei:
-            model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
-        assert "attention operand" in str(ei.value) and "window" in str(ei.value)
+        mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        got = mel.numpy()
+        info = model.engine.range_info()
+        print("scaled attention cores:", info)
+        assert np.isfinite(got).all() and info["decoder"] == 2 and info["hi"] >= 32768.0
+        assert np.abs(got - ref).max() < MEL_TOL
+        for k in rali:
+            np.testing.assert_allclose(ali[k].numpy(), rali[k], atol=1e-5, rtol=0)
     finally:
         model.engine.close()
+
+
+@pytest.mark.parametrize("scale,trips", [(8.0e3, None), (3.0e5, True)], ids=["z-past-2^15", "z-past-65504"])
+def test_sentinel_catches_inputs_that_leave_the_range_on_a_later_call(scale, trips):
+    """the survey is a sample of ONE call.  In-window weights, a first call with unit noise (survey: in window, split
+    path), then a SECOND call whose injected noise is `scale` times larger: the latent z -- the input of every flow step's folded
+    ActNorm o InvertibleLinear product and of the pre-projections -- starts at max |eps| ~ 3.6e4, past the survey window's 2^15 (inside
+    fp16 as long as no flow step amplifies it: the split keeps its 22 bits; whether the sentinel trips there is printed, not asserted)
+    resp. ~1.4e6, past 65504 (hi = inf: it must trip).  Nothing may come back non-finite: the sentinel trips at `.numpy()`, the binding
+    replays the call on exact fp32, and the result matches both the engine's own exact mode (bit for bit: same kernels) and the float64
+    oracle (TensorFlow's fp32 carries 1e6 like any other number, /root/reference/modules/flow.py:149-166, transform.py:45-51)."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    b = _batch(hps, "lj")
+    big = (np.asarray(b["eps"], np.float64) * scale).astype(np.float32)
+    print("max |eps| of the second call: %.3g" % np.abs(big).max())
+    ref, _ = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, big)
+    # fp32 itself loses ground at this magnitude (an O(1) shift added to a latent of 1e6 keeps 0.06 of absolute resolution): the yardstick
+    # is what the SAME statement costs in plain fp32 arithmetic (the float32 NumPy restatement), not 1e-3 out of thin air
+    ref32, _ = Oracle(hps, w, np.float32).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, big)
+    exact = VAENAR(hps, weights=w)
+    model = VAENAR(hps, weights=w)
+    try:
+        exact.engine.set_option("split_fp16", 0)
+        want = exact.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big)[0].numpy()
+        mel1, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        first = mel1.numpy()
+        i0 = model.engine.range_info()
+        assert (i0["encoder"], i0["prior"], i0["decoder"], i0["sentinel_trips"]) == (1, 1, 1, 0)
+        mel2, ali2 = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big)     # asynchronous: nothing known yet
+        got = mel2.numpy()                                   # the checkpoint
+        i1 = model.engine.range_info()
+        print("after the second call:", i1)
+        assert np.isfinite(got).all()
+        for k in ali2:
+            assert np.isfinite(ali2[k].numpy()).all()
+        scale_ref = max(1.0, float(np.abs(ref).max()))
+        err = np.abs(got - ref).max() / scale_ref
+        print(f"second call: max-abs mel err {err:.3e} (relative to max |mel| = {scale_ref:.3g}); exact-mode run differs by {np.abs(got - want).max():.3e}")
+        err32 = np.abs(np.asarray(ref32, np.float64) - ref).max() / scale_ref
+        print(f"  the float32 NumPy restatement of the same call: {err32:.3e}")
+        assert err < max(1e-3, 3.0 * err32)                  # the north star's tolerance, or fp32's own round-off at this magnitude
+        if trips:
+            assert i1["sentinel_trips"] == 1 and i1["replays"] == 1
+            assert i1["prior"] == 2 and i1["decoder"] == 2   # the modules of the flagged call stay on exact fp32
+            assert np.array_equal(got, want)                 # the replay ran the exact mode's kernels
+            # ... and the NEXT ordinary call is served from there too, still correct
+            again = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])[0].numpy()
+            assert np.abs(again - first).max() < MEL_TOL and model.engine.range_info()["sentinel_trips"] == 1
+        elif i1["sentinel_trips"]:
+            assert np.array_equal(got, want)
+        # what the sentinel protects against: the same second call with it switched off
+        raw_model = VAENAR(hps, weights=w)
+        try:
+            raw_model.engine.set_option("range_sentinel", 0)
+            raw_model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+            bad = raw_model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big)[0].numpy()
+            unguarded = np.inf if not np.isfinite(bad).all() else np.abs(bad - ref).max() / scale_ref
+            print(f"unwatched split path on the same call: {unguarded:.3e}")
+            if trips:
+                assert not unguarded < 1e-3
+        finally:
+            raw_model.engine.close()
+    finally:
+        model.engine.close(); exact.engine.close()
+
+
+def test_sentinel_c_abi_semantics_without_the_python_replay():
+    """What a C caller sees (include/vaenar_hip.h): the flagged call itself returns VNR_OK (asynchronous); the next synchronisation point
+    returns VNR_ERR_RANGE once, the modules are in state 2, and re-issuing the call gives the exact result."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    b = _batch(hps, "lj")
+    big = (np.asarray(b["eps"], np.float64) * 3.0e5).astype(np.float32)
+    model = VAENAR(hps, weights=w)
+    try:
+        e = model.engine
+        model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])[0].numpy()
+        mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big)
+        e._log.clear()                                        # play the C caller: no replay log
+        rc = e.lib.vnr_synchronize(e.handle)
+        assert rc == _lib.VNR_ERR_RANGE and b"exact fp32" in e.lib.vnr_last_error(e.handle)
+        assert e.lib.vnr_synchronize(e.handle) == 0           # reported once
+        assert e.range_info()["prior"] == 2
+        mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big)
+        assert e.lib.vnr_synchronize(e.handle) == 0 and np.isfinite(mel.numpy()).all()
+    finally:
+        model.engine.close()
+
+
+def test_survey_takes_one_record_per_attention_operand_at_batch_32():
+    """the survey took 3 records per attention call AND batch element, so its 2048-entry table overflowed silently
+    at B = 17 and the later modules were marked in-window unseen.  One batched launch per operand now; a full table is an error."""
+    hps = tiny_hps()
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    b = make_batch(32, 11, 40, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True,
+                   temperature=1.0, text_step=1, mel_step=1)
+    model, oracle = VAENAR(hps, weights=w), Oracle(hps, w, np.float64)
+    try:
+        mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        got = mel.numpy()
+        info = model.engine.range_info()
+        print("B = 32 survey:", info)
+        assert info["surveys"] == 1 and (info["encoder"], info["prior"], info["decoder"]) == (1, 1, 1)
+        ref, _ = oracle.inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
+        assert np.abs(got - ref).max() < MEL_TOL
+    finally:
+        model.engine.close()
+
+
+def test_sentinel_in_the_training_step():
+    """A training step whose mels are 1e6 times larger than anything before (the posterior's PreNet output, a Dense input, leaves fp16's
+    range): the forward's split products raise the sentinel, Adam and the BatchNormalization moving updates are predicated on it, and
+    vnr_train_step repeats the step on exact fp32 MFMA with scaled attention cores and fp32 kernel-gradient GEMMs.  Nothing non-finite may
+    reach the variables, and the outcome must equal a handle that ran on that path from the start."""
+    hps = tiny_hps()
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    r = np.random.Generator(np.random.PCG64(9))
+    B, Tt, Tm = 3, 11, 40
+    ids = r.integers(1, hps.Encoder.Transformer.vocab_size, (B, Tt)).astype(np.int32)
+    tl = np.array([11, 9, 7], np.int32); ml = np.array([40, 33, 26], np.int32)
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, 1, Tm // 2, hps.Common.latent_dim)).astype(np.float32)
+    huge = (mels.astype(np.float64) * 1.0e6).astype(np.float32)
+    probe = ["posterior/prenet/dense1/kernel", "decoder/out_projection/kernel", "text_encoder/prenet/conv_stack/0/bn/moving_mean"]
+
+    def run(force_fp32):
+        m = VAENAR(hps, weights=w)
+        try:
+            m.engine.set_option("deterministic", 1)
+            if force_fp32:
+                m.engine.set_option("train_fp32", 1)
+            out = [m.train_step(ids, mels, tl, ml, 1.0, 2, eps=eps, dropout_seed=3)]
+            out.append(m.train_step(ids, huge, tl, ml, 1.0, 2, eps=eps, dropout_seed=4))
+            out.append(m.train_step(ids, mels, tl, ml, 1.0, 2, eps=eps, dropout_seed=5))
+            info = m.engine.range_info()
+            have = [k for k in probe if k in m.engine._weights_loaded]
+            return out, {k: v for k, v in m.get_weights(have).items()}, info, m.engine.get_optimizer_step()
+        finally:
+            m.engine.close()
+
+    out, wts, info, steps = run(False)
+    print("losses:", out, info)
+    assert all(np.isfinite(o).all() for o in out) and steps == 3
+    assert all(np.isfinite(v).all() for v in wts.values())
+    assert info["train_fp32"] == 1 and info["sentinel_trips"] == 1
+    # the same three steps with the middle and last one forced onto the exact path from the start of step 2 cannot be arranged from outside;
+    # a handle on the exact path throughout differs from ours only in step 1 (split against exact products: fp32 round-off class)
+    out32, wts32, info32, _ = run(True)
+    assert info32["sentinel_trips"] == 0
+    np.testing.assert_allclose(np.asarray(out[1]), np.asarray(out32[1]), rtol=2e-3)
+    np.testing.assert_allclose(np.asarray(out[2]), np.asarray(out32[2]), rtol=2e-3)
+    for k in wts:
+        np.testing.assert_allclose(wts[k], wts32[k], rtol=0, atol=2e-4)          # three Adam steps of 1.25e-4 each: any wrong update shows

@@ -11,13 +11,20 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvaenar_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
+VNR_ERR_RANGE = -6
 
 ACT = {"identity": 0, None: 0, "relu": 1, "tanh": 2}
 
 
 class VnrError(RuntimeError):
     pass
+
+
+class VnrRangeError(VnrError):
+    """VNR_ERR_RANGE: the range sentinel of the split-fp16 path tripped (include/vaenar_hip.h, "Arithmetic contract"): what was computed
+    since the previous synchronisation point is invalid and the modules involved now run on exact fp32.  ``Engine`` answers it by
+    issuing the pending calls again (``Engine._replay``); user code sees it only when the exact path is non-finite too."""
 
 
 class vnr_config(C.Structure):
@@ -111,6 +118,7 @@ PROTOTYPES = {
     "vnr_comm_broadcast_weights": [_vp],
     "vnr_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "vnr_range_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)],
+    "vnr_range_sentinel": [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "vnr_comm_destroy": [_vp],
     "vnr_profile_enable": [_vp, _i],
     "vnr_profile_reset": [_vp],
@@ -170,7 +178,7 @@ def load():
 def check(rc, handle=None):
     if rc != 0:
         msg = load().vnr_last_error(handle)
-        raise VnrError("libvaenar_hip error %d: %s" % (rc, (msg or b"?").decode()))
+        raise (VnrRangeError if rc == VNR_ERR_RANGE else VnrError)("libvaenar_hip error %d: %s" % (rc, (msg or b"?").decode()))
 
 
 def config_from_hps(hps):
@@ -238,16 +246,14 @@ class DeviceArray:
     def numpy(self):
         out = np.empty(self.shape, self.dtype)
         if self.nbytes:
-            check(self.engine.lib.vnr_memcpy_d2h(self.engine.handle, out.ctypes.data, self.ptr, self.nbytes),
-                  self.engine.handle)
+            self.engine._checkpoint("vnr_memcpy_d2h", out.ctypes.data, self.ptr, self.nbytes)
         return out
 
     def copy_from(self, host):
         host = np.ascontiguousarray(host, dtype=self.dtype)
         assert host.shape == self.shape, (host.shape, self.shape)
         if self.nbytes:
-            check(self.engine.lib.vnr_memcpy_h2d(self.engine.handle, self.ptr, host.ctypes.data, self.nbytes),
-                  self.engine.handle)
+            self.engine._checkpoint("vnr_memcpy_h2d", self.ptr, host.ctypes.data, self.nbytes)
         return self
 
     def view(self, offset_elems, shape):
@@ -281,6 +287,51 @@ class Engine:
         self._pool = {}
         self._pool_bytes = 0
         self._pool_cap = 8 << 30
+        # Range sentinel (include/vaenar_hip.h, "Arithmetic contract of the split path"): every compute call issued since the last clean
+        # synchronisation point, as (entry point, arguments).  A checkpoint that answers VNR_ERR_RANGE has moved the modules involved to
+        # exact fp32; the calls are then issued again IN ORDER -- their inputs are untouched (new host data reaches the device only through
+        # vnr_memcpy_h2d, which is a checkpoint itself) and every entry point writes its outputs in full, so the device ends in the state
+        # the original sequence was meant to produce -- and the checkpoint is repeated.  Only raw pointers are recorded: pooled buffers may
+        # be reused meanwhile (in-order replay reproduces the same reuse), but none goes back to the driver while calls are pending.
+        self._log = []
+        self._log_cap = 256
+        self._training_mode = False
+        self.range_replays = 0
+
+    # -- calls ------------------------------------------------------------------
+    def call(self, name, *args, record=True):
+        """One library entry point on this handle.  Compute calls of the inference / evaluation kind are recorded for the range
+        sentinel's replay; calls that change variables (training mode, vnr_init, vnr_train_step: ``record=False``) check and repeat
+        themselves inside the library.  A call that FAILS with VNR_ERR_RANGE has not run yet (the library looks at the sentinel before
+        it starts): the pending calls are replayed and it is issued once more."""
+        fn = getattr(self.lib, name)
+        try:
+            check(fn(self.handle, *args), self.handle)
+        except VnrRangeError:
+            self._replay()
+            check(fn(self.handle, *args), self.handle)
+            self._log.clear()          # that call's own checkpoint was clean
+        if record and not self._training_mode:
+            self._log.append((name, args))
+            if len(self._log) >= self._log_cap:
+                self.synchronize()
+
+    def _replay(self):
+        log, self._log = self._log, []
+        self.range_replays += 1
+        for name, args in log:
+            check(getattr(self.lib, name)(self.handle, *args), self.handle)
+        self._log = log                 # pending until a checkpoint comes back clean
+
+    def _checkpoint(self, name, *args):
+        """vnr_synchronize / vnr_memcpy_d2h / vnr_memcpy_h2d: the synchronisation points at which the library reads the sentinel."""
+        fn = getattr(self.lib, name)
+        try:
+            check(fn(self.handle, *args), self.handle)
+        except VnrRangeError:
+            self._replay()
+            check(fn(self.handle, *args), self.handle)
+        self._log.clear()
 
     def _take(self, nbytes):
         lst = self._pool.get(nbytes)
@@ -292,7 +343,7 @@ class Engine:
         return p.value
 
     def _give(self, nbytes, ptr):
-        if self._pool_bytes + nbytes <= self._pool_cap:
+        if self._pool_bytes + nbytes <= self._pool_cap or self._log:      # (nothing goes back to the driver while calls are pending a checkpoint)
             self._pool.setdefault(nbytes, []).append(ptr)
             self._pool_bytes += nbytes
         else:
@@ -304,7 +355,7 @@ class Engine:
 
     def zeros(self, shape, dtype=np.float32):
         a = DeviceArray(self, shape, dtype)
-        check(self.lib.vnr_memset(self.handle, a.ptr, 0, max(a.nbytes, 1)), self.handle)
+        self.call("vnr_memset", a.ptr, 0, max(a.nbytes, 1))
         return a
 
     def to_device(self, host, dtype=None):
@@ -323,11 +374,11 @@ class Engine:
     def random_normal(self, shape, seed, offset=0, stddev=1.0):
         """tf.random.normal(shape, stddev=stddev) drawn on the device (Philox-4x32-10, vnr_random_normal)."""
         a = DeviceArray(self, shape, np.float32)
-        check(self.lib.vnr_random_normal(self.handle, int(seed) & (2 ** 64 - 1), int(offset), float(stddev), a.ptr, a.size), self.handle)
+        self.call("vnr_random_normal", int(seed) & (2 ** 64 - 1), int(offset), float(stddev), a.ptr, a.size)
         return a
 
     def synchronize(self):
-        check(self.lib.vnr_synchronize(self.handle), self.handle)
+        self._checkpoint("vnr_synchronize")
 
     def device_info(self):
         buf = C.create_string_buffer(128)
@@ -337,6 +388,8 @@ class Engine:
 
     # -- weights ----------------------------------------------------------------
     def set_weight(self, path, array):
+        if self._log:
+            self.synchronize()          # pending calls belong to the OLD variables: their checkpoint (and replay) comes first
         a = np.ascontiguousarray(array, dtype=np.float32)
         shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
         check(self.lib.vnr_set_weight(self.handle, path.encode(), a.ctypes.data, shape, a.ndim), self.handle)
@@ -380,7 +433,10 @@ class Engine:
         st = (C.c_int * 4)()
         lo, hi, n = C.c_float(0), C.c_float(0), C.c_int64(0)
         check(self.lib.vnr_range_info(self.handle, st, C.byref(lo), C.byref(hi), C.byref(n)), self.handle)
-        return {"encoder": st[0], "prior": st[1], "decoder": st[2], "posterior": st[3], "lo": lo.value, "hi": hi.value, "surveys": n.value}
+        trips, tf32, pend = C.c_int64(0), C.c_int(0), C.c_int(0)
+        check(self.lib.vnr_range_sentinel(self.handle, C.byref(trips), C.byref(tf32), C.byref(pend)), self.handle)
+        return {"encoder": st[0], "prior": st[1], "decoder": st[2], "posterior": st[3], "lo": lo.value, "hi": hi.value, "surveys": n.value,
+                "sentinel_trips": trips.value, "train_fp32": tf32.value, "pending_modules": pend.value, "replays": self.range_replays}
 
     def get_gradient(self, path, shape):
         out = np.empty(shape, np.float32)
@@ -415,6 +471,10 @@ class Engine:
 
     def set_option(self, name, value):
         check(self.lib.vnr_set_option(self.handle, name.encode(), int(value)), self.handle)
+        if name == "training":
+            self._training_mode = bool(int(value))
+        elif self._log and not self._training_mode and not name.startswith("range_"):
+            self._log.append(("vnr_set_option", (name.encode(), int(value))))     # options are part of the sequence a replay repeats
 
     # -- instrumentation ----------------------------------------------------------
     def profile(self, on):

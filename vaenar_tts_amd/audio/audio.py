@@ -73,9 +73,8 @@ class Audio:
         B, T, M = d_mel.shape
         assert M == h.num_mels
         S = e.empty((B, T, h.num_freq))
-        _lib.check(e.lib.vnr_voc_mel_to_linear(e.handle, d_mel.ptr, self._inv_mel_basis_t().ptr, B, T, M, h.num_freq, float(h.min_level_db),
-                                               float(h.ref_level_db), float(h.max_abs_value), int(bool(h.symmetric_specs)),
-                                               float(h.power), S.ptr), e.handle)
+        e.call("vnr_voc_mel_to_linear", d_mel.ptr, self._inv_mel_basis_t().ptr, B, T, M, h.num_freq, float(h.min_level_db),
+               float(h.ref_level_db), float(h.max_abs_value), int(bool(h.symmetric_specs)), float(h.power), S.ptr)
         return S
 
     def _griffin_lim_batch(self, S, frames=None, init_angles=None, seed=0, n_iters=None):
@@ -89,8 +88,8 @@ class Audio:
         d_fr = None if frames is None else e.to_device(np.asarray(frames, np.int32), np.int32)
         d_ang = None if init_angles is None else e.to_device(init_angles, np.float32)
         wav = e.empty((B, hop * (T - 1)))
-        _lib.check(e.lib.vnr_voc_griffin_lim(e.handle, S.ptr, None if d_ang is None else d_ang.ptr, C.c_uint64(int(seed)),
-                                             None if d_fr is None else d_fr.ptr, B, T, n_fft, hop, win, n_iters, wav.ptr), e.handle)
+        e.call("vnr_voc_griffin_lim", S.ptr, None if d_ang is None else d_ang.ptr, C.c_uint64(int(seed)),
+               None if d_fr is None else d_fr.ptr, B, T, n_fft, hop, win, n_iters, wav.ptr)
         return wav
 
     def inv_mel_spectrogram_batch(self, mels, lengths=None, init_angles=None, seed=0, n_iters=None):

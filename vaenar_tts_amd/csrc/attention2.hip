@@ -48,11 +48,8 @@ __device__ __forceinline__ float fast_exp(float x) {
 }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    _Float16 h = (_Float16)x0[e]; hi[e] = h; lo[e] = (_Float16)(x0[e] - (float)h);
-    h = (_Float16)x1[e]; hi[4 + e] = h; lo[4 + e] = (_Float16)(x1[e] - (float)h);
-  }
+  const vnr_f8 xs_ = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  vnr_split(xs_, hi, lo);
 }
 // 3-term split product on the f16 matrix pipe: (ah + al) * (bh + bl) ~= ah*bh + al*bh + ah*bl  (fp32 accumulate)
 __device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
@@ -105,6 +102,26 @@ attn2_kernel(const AttnArgs a, int nqb) {
   const int Q0 = qb * 64, q0 = Q0 + qt * 32;
   const int ntiles_all = (a.Tk + KT - 1) / KT;
   const bool wave_active = q0 < a.Tq;
+  // per-launch power-of-two operand scales (AttnArgs::qkv_absmax): max |Q|, |K|, |V| -> ~2^10 before the fp16 hi/lo split, so the core
+  // has fp32's dynamic range (attention.py:224-246 has no window); the logits and the context are scaled back exactly.  The
+  // shifts are clamped to +-60 so that the combined logit factor stays a normal fp32 number.
+  float sc_q = 1.f, sc_k = 1.f, sc_v = 1.f, qk_scale = 0.125f, o_scale = 1.f;      // (wave-uniform: scalar registers)
+  if (a.qkv_absmax) {
+    int sft[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const unsigned bits = a.qkv_absmax[2 * i];          // (max, min) pairs as launch_row_range leaves them
+      const int e = (int)(bits >> 23) & 0xff;
+      int s_ = (e > 0 && e < 255) ? 10 - (e - 127) : 0;
+      s_ = s_ > 60 ? 60 : (s_ < -60 ? -60 : s_);
+      sft[i] = s_;
+    }
+    sc_q = __uint_as_float((unsigned)(sft[0] + 127) << 23);
+    sc_k = __uint_as_float((unsigned)(sft[1] + 127) << 23);
+    sc_v = __uint_as_float((unsigned)(sft[2] + 127) << 23);
+    qk_scale = __uint_as_float((unsigned)(-sft[0] - sft[1] - 3 + 127) << 23);       // 2^-3 / (sc_q sc_k)
+    o_scale = __uint_as_float((unsigned)(-sft[2] + 127) << 23);
+  }
 
   // ---- descriptors & per-lane DMA offsets --------------------------------------------------------------------
   const unsigned kv_span = (unsigned)((((size_t)(a.Tk - 1)) * a.ldk + (size_t)a.H * 64) * 4);
@@ -152,7 +169,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
       f32x4 x0, x1;
       if (qok) { x0 = *reinterpret_cast<const f32x4*>(qp + t * 16); x1 = *reinterpret_cast<const f32x4*>(qp + t * 16 + 4); }
       else { x0[0] = x0[1] = x0[2] = x0[3] = 0.f; x1 = x0; }
-      split8(x0, x1, qhi[t], qlo[t]);
+      split8(x0 * sc_q, x1 * sc_q, qhi[t], qlo[t]);
     }
   }
   const int qlen = a.q_len ? a.q_len[b] : a.Tq;
@@ -187,7 +204,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
       const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + k_rd[t][0]);
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + k_rd[t][1]);
       f16x8 khi, klo;
-      split8(k0, k1, khi, klo);
+      split8(k0 * sc_k, k1 * sc_k, khi, klo);
       st = mfma3(khi, klo, qhi[t], qlo[t], st);
     }
     const int j0 = kt * KT + 32 * kh;                 // first key of this wave's block
@@ -195,12 +212,12 @@ attn2_kernel(const AttnArgs a, int nqb) {
     const bool plain = (!a.causal || j0 + 31 <= q0) && !use_tau && j0 + 32 <= klen && j0 + 32 <= a.Tk && q0 + 32 <= qlen;
     if (plain) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] *= 0.125f;   // / sqrt(64), exact
+      for (int r = 0; r < 16; ++r) st[r] *= qk_scale;   // / sqrt(64) (and the operand scales), exact
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = j0 + frow(r, half);
-        float s = st[r] * 0.125f;
+        float s = st[r] * qk_scale;
         if (use_tau) s = s / tau;
         const bool ok = qvalid && (j < klen) && (!a.causal || j <= iq);
         s = ok ? s : kMaskFill;                       // attention.py:240
@@ -229,9 +246,9 @@ attn2_kernel(const AttnArgs a, int nqb) {
       }
       f16x8 phi, plo, vhi, vlo;
       split8(p0, p1, phi, plo);
-      split8(va0, va1, vhi, vlo);
+      split8(va0 * sc_v, va1 * sc_v, vhi, vlo);
       O[0] = mfma3(phi, plo, vhi, vlo, O[0]);
-      split8(vb0, vb1, vhi, vlo);
+      split8(vb0 * sc_v, vb1 * sc_v, vhi, vlo);
       O[1] = mfma3(phi, plo, vhi, vlo, O[1]);
     }
   };
@@ -482,7 +499,7 @@ attn2_kernel(const AttnArgs a, int nqb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int src = frow(r, half);                   // per-query factors live in lane = query index
-      const float fa = __shfl(sa * linv, src, 64), fb = __shfl(sb * linv, src, 64);
+      const float fa = __shfl(sa * linv, src, 64) * o_scale, fb = __shfl(sb * linv, src, 64) * o_scale;
       const float o = O[nb][r] * fa + mg[pw * 1024 + r * 64 + lane] * fb;
       const int row = q0 + src;
       if (row < a.Tq) __builtin_nontemporal_store(o, ob + (size_t)row * a.ldo);   // nt: streams out during the kernel (see common.h)
@@ -543,16 +560,12 @@ hipError_t launch_attention2(const AttnArgs& a_in, hipStream_t s) {
       FILE* f = fopen(p, "ab"); if (f) { int hdr[8] = {a->B, a->H, a->Tq, a->Tk, a->causal, a->ali ? 1 : 0, (int)(n / 8), nqb}; fwrite(hdr, 4, 8, f); fwrite(h.data(), 8, n, f); fclose(f); } } } dump{ts_path, dts, nts, s, &a, nqb};
   const size_t lds = 2 * (2 * 64 * 256) + (256 + 256) * sizeof(float);
   dim3 grid(nqb * a.H * a.B);
-  if (a.ali && a.Tk > 256 && a.Tk <= 384) {          // (six / seven tiles: 16 / 32 logit registers less than the eight-tile form, which spills 8 VGPRs)
+  if (a.ali && a.Tk > 256 && a.Tk <= 384) {          // (six / seven tiles of logits in registers)
     auto k = attn2_kernel<true, 6>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
   } else if (a.ali && a.Tk > 384 && a.Tk <= 448) {
     auto k = attn2_kernel<true, 7>;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
-  } else if (a.ali && a.Tk > 256) {
-    auto k = attn2_kernel<true, 8>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     vnr_launch(k, grid, dim3(256), lds, s, a, nqb);
   } else if (a.ali && a.Tk > 128) {
@@ -576,7 +589,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return hipErrorInvalidValue;
   if ((a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3)) return hipErrorInvalidValue;
   if (!attention2_supported(a)) return hipErrorInvalidValue;
-  if (a.ali && a.Tk > 512) {                           // two passes: context + row statistics, then the probabilities
+  if (a.ali && a.Tk > 448) {                           // two passes: context + row statistics, then the probabilities (round 6: from 449 keys --
+                                                       // the eight-tile register form of attn2_kernel spilled 8 VGPRs and is gone)
     if (!a.row_max || !a.row_linv) return hipErrorInvalidValue;
     AttnArgs f = a;
     f.ali = nullptr;

@@ -40,8 +40,7 @@ __device__ __forceinline__ f32x16 mfma3x(const h8& ah, const h8& al, const h8& b
   return c;
 }
 __device__ __forceinline__ void split8x(const float* x, h8& hi, h8& lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+  { const vnr_f8 xs_ = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}; vnr_split(xs_, hi, lo); }
 }
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr int kXchg = 8192;                         // bytes of exchange space per wave

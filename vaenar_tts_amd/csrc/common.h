@@ -76,6 +76,8 @@ struct DetState {
   void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); release_retired(); bufs.clear(); }
 };
 inline thread_local DetState* g_det = nullptr;
+// the training step on its exact-fp32 fallback (engine.hip: vnr_context::train_fp32): the kernel-gradient GEMMs take the fp32 MFMA kernel
+inline thread_local bool g_train_exact = false;
 inline void* det_scratch(hipStream_t s, size_t bytes) {
   if (!g_det) return nullptr;
   auto& b = g_det->bufs[s];
@@ -130,12 +132,38 @@ struct AoiDesc {
 };
 constexpr int kAoiTile = 8192;
 #if defined(__HIPCC__)
+// ---- x = hi + lo in fp16: THE split of the 3-term products, one statement for every kernel (round 6) ------------------------------------
+// The low part must be derived from the STORED high bits.  Written per element -- `h = (_Float16)x; hi = h; lo = (_Float16)(x - (float)h)`
+// -- behind a multiply or an fma, the compiler may evaluate `h` twice: fused into the arithmetic for the value it subtracts
+// (v_fma_mixlo_f16 / v_fma_mixhi_f16: ONE rounding of the exact result) and as v_cvt of the rounded fp32 value for the value it stores
+// (TWO roundings); the two differ by one fp16 ulp whenever the fp32 rounding crosses an fp16 tie (round 5: 1.3e-4 at the mel, every
+// test green; profiles/r05_experiments.txt r05i).  Vector-typed conversions give the compiler ONE node for the high part, and it lowers
+// them to v_cvt_pk_f16_f32.  tests/test_isa_split_sites.py disassembles every built object and fails on any v_fma_mix{lo,hi}_f16.
+typedef float vnr_f2 __attribute__((ext_vector_type(2)));
+typedef float vnr_f4 __attribute__((ext_vector_type(4)));
+typedef float vnr_f8 __attribute__((ext_vector_type(8)));
+typedef _Float16 vnr_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vnr_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vnr_h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void vnr_split(const vnr_f4 x, vnr_h4& hi, vnr_h4& lo) {
+  hi = __builtin_convertvector(x, vnr_h4);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, vnr_f4), vnr_h4);
+}
+__device__ __forceinline__ void vnr_split(const vnr_f8 x, vnr_h8& hi, vnr_h8& lo) {
+  hi = __builtin_convertvector(x, vnr_h8);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, vnr_f8), vnr_h8);
+}
+__device__ __forceinline__ void vnr_split(const float x, _Float16& hi, _Float16& lo) {      // one value: the same conversion on a pair
+  const vnr_f2 xv = {x, x};
+  const vnr_h2 h = __builtin_convertvector(xv, vnr_h2);
+  const vnr_h2 l = __builtin_convertvector(xv - __builtin_convertvector(h, vnr_f2), vnr_h2);
+  hi = h[0]; lo = l[0];
+}
 typedef _Float16 aoi_h4 __attribute__((ext_vector_type(4)));
 // 4 consecutive output columns [col, col+4) of row `row` (col % 4 == 0)
 __device__ __forceinline__ void aoi_store4(const AoiDesc& a, int row, int col, const float* v) {
   aoi_h4 hi, lo;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[e]; hi[e] = h; lo[e] = (_Float16)(v[e] - (float)h); }
+  { const vnr_f4 xs_ = {v[0], v[1], v[2], v[3]}; vnr_split(xs_, hi, lo); }
   int c = col, blk = 0;
   bool is_v = a.mode == 2;
   if (a.mode == 3) {
@@ -204,6 +232,7 @@ struct GemmArgs {
                                     // a run of row tiles -- for a weight panel that does not fit one XCD's L2 (set by launch_gemm2, see gemm2.hip)
   int a_split = 0;                  // A1 (and A2) are split rows
   int c_split = 0;                  // C is written as split rows (ldc = C columns, bytes per row = 4 * ldc)
+  unsigned* range_flag = nullptr;   // overflow sentinel of the split path (see range_note below); null = not watched
 };
 
 struct AttnArgs {
@@ -224,6 +253,10 @@ struct AttnArgs {
   // P_ij = exp(s_ij - row_max[i]) * row_linv[i] with s the masked, scaled logit exactly as the kernel formed it; or null
   float* row_max = nullptr;
   float* row_linv = nullptr;
+  // per-launch power-of-two operand scales (attention2.hip): device words [3][2] whose first element holds the bits of max |Q|, max |K|, max |V| of this
+  // call (launch_row_range_batched); the kernel maps each maximum to ~2^10 before the fp16 hi/lo split and scales the logits / the context back
+  // exactly -- fp32 dynamic range for the attention core (exact-fp32 mode of the engine, the training step's fallback).  Null: unscaled.
+  const unsigned* qkv_absmax = nullptr;
 };
 
 // ---- row-panel chain kernel (gemm3.hip) ---------------------------------------------------------------------------
@@ -232,6 +265,21 @@ constexpr int kMaxChainStages = 20;
 // end-of-kernel L2 write-back shrinks -- but cost 10 % of the step on GEMM / chain outputs, whose consumers then
 // miss the cache.)
 #if defined(__HIPCC__)
+// The overflow sentinel of the split-fp16 path.  An activation with |x| >= 65520 splits into hi = +-inf, lo = x - hi = -+inf; in the
+// consuming product the terms hi.w_hi and lo.w_hi are infinities of opposite sign (or inf.0), so EVERY accumulator of that row comes out
+// NaN, whatever the weights -- and an activation function may heal it on the way out (fmaxf(NaN, 0) = 0: a ReLU stage would hand on
+// zeros).  Each split product therefore looks at ONE accumulator per row right behind its k-loop and raises the handle's flag word
+// (host-pinned: the engine reads it at its synchronisation points, engine.hip "range sentinel").  Rare branch, no state kept.
+__device__ __forceinline__ void range_note(unsigned* flag, float acc_elem) {
+  const bool bad = !(__builtin_fabsf(acc_elem) < __builtin_inff());
+  // wave-uniform branch + SCALAR store (s_store_dword exists on the gfx9 family; tools/probes/sstore_probe.hip): the raise needs no vector
+  // register -- with a vector store the one-wave-per-SIMD chain kernel (512 registers in use) spilled.  `flag` is never null (an unwatched
+  // launch gets the handle's scrap word): a null test in front would keep the pointer live across the kernel's stage loop.
+  if (__builtin_amdgcn_ballot_w64(bad)) {
+    const unsigned one = 1u;
+    asm volatile("s_store_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::"s"(one), "s"(flag) : "memory");
+  }
+}
 __device__ __forceinline__ void out_store4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
@@ -303,6 +351,7 @@ struct ChainArgs {
   int pf_wgs;                   // (set by launch_panel_chain) prefetch workgroups appended to the grid
   int vt_lds;                   // (set by launch_panel_chain, waves4 only) byte offset of the V-stage transpose scratch [4 waves][32][33] fp32 in LDS
   int waves4;                   // 1: the one-wave-per-SIMD kernel (gemm3c.hip: 4 waves x 64 columns, 8 k-tiles in flight; 32-row panels only), 0: panel_chain_kernel
+  unsigned* range_flag;         // overflow sentinel of the split path (range_note); null = not watched
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage
   ChainStage st[kMaxChainStages];
 };
@@ -402,7 +451,8 @@ hipError_t launch_col_sum_grad(const float* x, int M, int C, int ld, float* grad
 hipError_t launch_col_sum_grad_act(float* dy, const float* y, int act, int M, int C, int ld, float* grad, unsigned* amax, hipStream_t s);
 hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s);
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
-                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw = 0);
+                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw = 0,
+                                  const unsigned* skip_moving = nullptr);      // skip_moving: the handle's sentinel word -- no moving update once it is set
 hipError_t launch_actnorm_init_finish(const double* mean, const double* sq, int M, int C, float* log_scale, float* bias,
                                       float* scale, hipStream_t s);
 hipError_t launch_rowop(const float* x, int M, int C, const float* scale, const float* shift, const float* pe, int T, float pe_w,
@@ -413,6 +463,8 @@ hipError_t launch_gemm_tn(const float* A, int lda, const float* B, int ldb, floa
 hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned* out, hipStream_t s);
 // out[0] = max over rows of the row maximum of |x|, out[1] = min over rows with a non-zero maximum (float bits; misc.hip)
 hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s);
+hipError_t launch_row_range_batched(const float* x, long long ld, int T, long long bs, int B, int cols, unsigned* out, hipStream_t s);
+hipError_t launch_finite_check(const float* x, size_t n, unsigned* flag, hipStream_t s);
 #if defined(__HIPCC__)
 // Publish a candidate maximum (bits of a non-negative float; the word is zero on entry and only grows).  Same-address atomics serialise at
 // ~15-20 ns each: one per wave was 1024-4096 per attention-backward launch, 6-25 us of a 40-90 us kernel (profiles/r03_experiments.txt).
@@ -460,7 +512,7 @@ hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, con
 hipError_t launch_length_loss(const float* x, const float* w, const float* bias, const int32_t* text_len, const int32_t* mel_len,
                               int B, int T, int D, float seed, float* pred, float* ll, float* dw, float* db, hipStream_t s);
 hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
-                       float lr_t, float b1, float b2, float eps, hipStream_t s);
+                       float lr_t, float b1, float b2, float eps, hipStream_t s, const unsigned* skip = nullptr);
 hipError_t launch_conv_flip(const float* W, int k, int cin, int cout, float* Wb, hipStream_t s);
 hipError_t launch_invert(const float* W, int C, float* Winv, float* WinvT, float* logabsdet, hipStream_t s);
 hipError_t launch_invert_batch(const float* const* W, float* const* Winv, float* const* WinvT, float* const* lad, int n, int C, hipStream_t s);

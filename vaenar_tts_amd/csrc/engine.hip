@@ -171,6 +171,23 @@ struct vnr_context {
   std::vector<int> survey_kind;                              // 0: input of a Dense / Conv1D product, 1: operand of an attention core
   float range_lo = 0.f, range_hi = 0.f;                      // last survey: smallest / largest tensor maximum
   int64_t range_surveys = 0;                                 // surveys run so far (tests)
+  // ---- range sentinel (round 6): the guarantee behind the survey's sample -------------------------------------------------------------
+  // The survey looks at ONE call's inputs.  A later call can still drive an activation past fp16's 65504 (a longer text, larger caller
+  // tensors -- mels, z, injected noise --, a temperature above 1): its split is then (+-inf, -+inf), every accumulator of that row in the
+  // consuming product is NaN, and an activation may heal it silently (fmaxf(NaN, 0) = 0).  Every split product (gemm2 / gemm3 / gemm3c)
+  // therefore probes one accumulator per row behind its k-loop and raises THIS word (common.h: range_note; host-pinned memory the
+  // kernels write through the unified address space).  The host looks at it wherever it synchronises with the stream anyway
+  // (vnr_synchronize, vnr_memcpy_d2h / h2d: range_checkpoint): a raised word fails that call with VNR_ERR_RANGE -- nothing computed since
+  // the previous checkpoint may be trusted --, moves the modules that ran since then to exact fp32 (state 2: fp32 MFMA products, attention
+  // cores with per-launch operand scales, i.e. no window at all) and the caller re-issues its calls (vaenar_tts_amd/_lib.py does that by
+  // itself: Engine._replay).  Calls that change variables (training-mode forwards, vnr_init, vnr_train_step) check synchronously and repeat
+  // themselves on exact fp32 before they return; their BatchNormalization / Adam updates are predicated on the word.
+  unsigned* range_flag = nullptr;      // host-pinned sentinel word
+  bool range_sentinel = true;          // engine option "range_sentinel" (0: the products are not watched; measurement only)
+  unsigned mods_pending = 0;           // modules that ran on the split path since the last checkpoint
+  int64_t range_trips = 0;             // checkpoints that found the word raised
+  bool train_fp32 = false;             // the training step runs on exact fp32 MFMA with scaled attention cores (VNR_TRAIN_FP32, or a trip inside a step)
+  unsigned* d_step_flag = nullptr;     // device copy of the word the training step's Adam launch is predicated on (all-reduced over the ranks)
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
 
   // workspace arena (chunks; bump allocation, reset at every top-level call)
@@ -249,9 +266,13 @@ constexpr int kSurveyMax = 2048;
 constexpr float kRangeLo = 0.015625f, kRangeHi = 32768.f;      // [2^-6, 2^15)
 inline bool split_active(vnr_handle h) { return h->split_enabled && !h->split_suspended; }
 // survey: one (max, min non-zero row max) record per matrix
-int survey_matrix(vnr_handle h, const float* x, long long ld, int rows, int cols, int kind) {
-  if (!x || rows <= 0 || cols <= 0 || h->survey_n >= kSurveyMax) return VNR_OK;
-  const hipError_t e = launch_row_range(x, ld, rows, cols, h->survey_words + 2 * h->survey_n, h->stream);
+// (T > 0: a batch of B matrices of T rows, bs floats apart -- the operand of one attention call is ONE record whatever the batch; round 5
+//  took one per batch element and ran out of records at B = 17, silently: ADVICE round 5)
+int survey_matrix(vnr_handle h, const float* x, long long ld, int rows, int cols, int kind, int T = 0, long long bs = 0, int B = 1) {
+  if (!x || rows <= 0 || cols <= 0) return VNR_OK;
+  if (h->survey_n >= kSurveyMax) return fail(h, VNR_ERR_STATE, "range survey: more than " + std::to_string(kSurveyMax) + " tensors in one call (raise kSurveyMax)");
+  const hipError_t e = T > 0 ? launch_row_range_batched(x, ld, T, bs, B, cols, h->survey_words + 2 * h->survey_n, h->stream)
+                             : launch_row_range(x, ld, rows, cols, h->survey_words + 2 * h->survey_n, h->stream);
   if (e != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("range survey: ") + hipGetErrorString(e));
   h->survey_n++;
   h->survey_kind.push_back(kind);
@@ -280,6 +301,7 @@ int run_gemm(vnr_handle h, const GemmArgs& g_in) {
   }
   g.wide_tiles = h->gemm_wide_tiles ? 1 : 0;
   g.no_loader_waves = h->in_train_step ? 1 : 0;
+  g.range_flag = (g.Wsplit && h->range_sentinel) ? h->range_flag : nullptr;
   if ((g.a_split || g.c_split) && !g.Wsplit) return fail(h, VNR_ERR_STATE, "split-row activations need the split-fp16 weight image of the layer");
   ProfScope ps(h, g.Wsplit ? CLS_GEMM : CLS_GEMM_F32, 2.0 * g.M * (double)g.N * g.K, 0.0);
   hipError_t e = launch_gemm(g, h->stream);
@@ -348,6 +370,7 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   //  64-row panels = several batches in flight: the idle CUs belong to them)
   g.pf_progress = (h->chain_prefetch && g.waves4 && !h->chain_rows64) ? h->chain_progress : nullptr;
   g.pf_epoch = ++h->chain_epoch;
+  g.range_flag = (h->range_sentinel && h->range_flag) ? h->range_flag : h->d_step_flag + 4;      // (never null: common.h range_note; an unwatched launch raises a scrap word)
   // bytes of a launch that also writes alignments: the attention core's own traffic as SURVEY D3 counts it (Q + K, V + context +
   // alignments) -- Q and the context never reach HBM here, the figure is what a stand-alone core would move
   const double ali_bytes = (g.att_stage > 0 && g.att_ali)
@@ -360,14 +383,25 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
 
 int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
   AttnArgs a = a_in;
-  if (h->surveying) {                                     // the attention cores split Q, K and V in every mode: their ranges have no exact fallback
-    for (int b = 0; b < a.B; ++b) {
-      TRY(survey_matrix(h, a.Q + (size_t)b * a.q_bs, a.ldq, a.Tq, a.H * 64, 1));
-      TRY(survey_matrix(h, a.K + (size_t)b * a.k_bs, a.ldk, a.Tk, a.H * 64, 1));
-      TRY(survey_matrix(h, a.V + (size_t)b * a.v_bs, a.ldv, a.Tk, a.H * 64, 1));
-    }
+  if (h->surveying) {                                     // the attention cores of the split path take Q, K and V unscaled
+    TRY(survey_matrix(h, a.Q, a.ldq, a.Tq * a.B, a.H * 64, 1, a.Tq, a.q_bs, a.B));
+    TRY(survey_matrix(h, a.K, a.ldk, a.Tk * a.B, a.H * 64, 1, a.Tk, a.k_bs, a.B));
+    TRY(survey_matrix(h, a.V, a.ldv, a.Tk * a.B, a.H * 64, 1, a.Tk, a.v_bs, a.B));
   }
-  if (a.ali && a.Tk > 512 && !a.row_max) {             // two-pass alignment form (attention2.hip): scratch for the row statistics
+  if (!split_active(h) || (h->in_train_step && h->train_fp32)) {
+    // exact-fp32 mode: the core still multiplies fp16 hi/lo pairs, so its operands get per-launch power-of-two scales from their
+    // maxima (attention2.hip: AttnArgs::qkv_absmax) -- fp32's dynamic range, like the reference's tf.matmul (attention.py:224-246)
+    unsigned* words = reinterpret_cast<unsigned*>(ws_alloc(h, 8));
+    if (!words) return fail(h, VNR_ERR_NOMEM, "attention operand scales");
+    HIP_TRY(h, hipMemsetAsync(words, 0, 8 * sizeof(unsigned), h->stream));
+    hipError_t e1 = launch_row_range_batched(a.Q, a.ldq, a.Tq, a.q_bs, a.B, a.H * 64, words, h->stream);
+    if (e1 == hipSuccess) e1 = launch_row_range_batched(a.K, a.ldk, a.Tk, a.k_bs, a.B, a.H * 64, words + 2, h->stream);
+    if (e1 == hipSuccess) e1 = launch_row_range_batched(a.V, a.ldv, a.Tk, a.v_bs, a.B, a.H * 64, words + 4, h->stream);
+    if (e1 != hipSuccess) return fail(h, VNR_ERR_HIP, std::string("attention operand scales: ") + hipGetErrorString(e1));
+    h->launches += 3;
+    a.qkv_absmax = words;
+  }
+  if (a.ali && a.Tk > 448 && !a.row_max) {             // two-pass alignment form (attention2.hip): scratch for the row statistics
     const size_t n = (size_t)a.B * a.H * a.Tq;
     a.row_max = ws_alloc(h, n); a.row_linv = ws_alloc(h, n);
     if (!a.row_max || !a.row_linv) return fail(h, VNR_ERR_NOMEM, "attention row statistics");
@@ -870,7 +904,7 @@ int run_conv(vnr_handle h, const ConvL& c, const float* x, const int32_t* gather
   RUN_MISC(h, launch_col_sum(y, M, C, C, nullptr, mean, h->stream));
   RUN_MISC(h, launch_scale_d(mean, C, 1.0 / (double)M, h->stream));
   RUN_MISC(h, launch_col_sum(y, M, C, C, mean, sq, h->stream));
-  RUN_MISC(h, launch_bn_train_finish(mean, sq, M, C, c.gamma, c.beta, 0.99f, c.moving_mean, c.moving_var, sc, sh, h->stream));
+  RUN_MISC(h, launch_bn_train_finish(mean, sq, M, C, c.gamma, c.beta, 0.99f, c.moving_mean, c.moving_var, sc, sh, h->stream, 0, h->range_flag));
   RUN_MISC(h, launch_rowop(y, M, C, sc, sh, nullptr, 1, 0.f, c.drop_rate, site_key(h->drop_seed, c.site), y, h->stream));
   return VNR_OK;
 }
@@ -1428,8 +1462,8 @@ int survey_begin(vnr_handle h) {
   h->surveying = true;
   return VNR_OK;
 }
-// verdict: 1 every surveyed tensor maximum inside [kRangeLo, kRangeHi), 2 a Dense / Conv1D input outside (exact fp32 from now on),
-// 3 an attention operand outside (no exact form of the attention core exists: the call fails)
+// verdict: 1 every surveyed tensor maximum inside [kRangeLo, kRangeHi), 2 a Dense / Conv1D input or an attention operand outside
+// (exact fp32 products and scaled attention cores from now on)
 int survey_end(vnr_handle h, int* verdict) {
   h->surveying = false;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1440,22 +1474,99 @@ int survey_end(vnr_handle h, int* verdict) {
     float mx; memcpy(&mx, &w[2 * i], 4);
     if (mx == 0.f) continue;                               // an all-zero matrix (temperature 0: the noise) splits exactly
     lo = fminf(lo, mx); hi = fmaxf(hi, mx);
-    if (!(mx >= kRangeLo && mx < kRangeHi)) v = (h->survey_kind[i] == 1) ? 3 : (v == 3 ? 3 : 2);
+    if (!(mx >= kRangeLo && mx < kRangeHi)) v = 2;         // (an attention operand too: round 6 gave the exact mode's cores per-launch operand scales)
   }
   h->range_lo = (lo == INFINITY) ? 0.f : lo; h->range_hi = hi;
   h->range_surveys++;
   *verdict = v;
   return VNR_OK;
 }
+// The one range statement that holds for EVERY input: a LayerNormalization output obeys |y_k| <= |gamma_k| sqrt(n) + |beta_k|
+// (the normalised row has 2-norm <= sqrt(n)).  Two epilogue paths of the one-wave-per-SIMD chain kernel multiply such outputs without
+// a sentinel probe of their own (gemm3c.hip) -- so a module whose LayerNorm variables would allow an output beyond fp16's range is kept
+// on exact fp32 from the start (state 2), whatever the survey samples.  Runs inside vnr_finalize_weights (a few hundred small copies).
+int ln_static_bound(vnr_handle h) {
+  std::vector<float> ga, be;
+  for (auto& kv : h->w) {
+    const std::string& p = kv.first;
+    const size_t cut = p.rfind("/gamma");
+    if (cut == std::string::npos || cut + 6 != p.size()) continue;
+    const size_t prev = p.rfind('/', cut - 1);
+    if (p.compare(prev == std::string::npos ? 0 : prev + 1, 10, "layer_norm") != 0) continue;      // (not the BatchNormalization gammas)
+    const Tensor& g = kv.second;
+    const Tensor* b = find_w(h, p.substr(0, cut) + "/beta");
+    if (!g.d || g.n <= 0) continue;
+    ga.resize((size_t)g.n); be.assign((size_t)g.n, 0.f);
+    HIP_TRY(h, hipMemcpy(ga.data(), g.d, (size_t)g.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (b && b->d && b->n == g.n) HIP_TRY(h, hipMemcpy(be.data(), b->d, (size_t)g.n * sizeof(float), hipMemcpyDeviceToHost));
+    double bound = 0.0; bool finite = true;
+    const double rn = sqrt((double)g.n);
+    for (int64_t i = 0; i < g.n; ++i) {
+      const double v = fabs((double)ga[(size_t)i]) * rn + fabs((double)be[(size_t)i]);
+      if (!(v < INFINITY)) finite = false;
+      if (v > bound) bound = v;
+    }
+    if (finite && bound < 65504.0) continue;
+    const int m = p.compare(0, 13, "text_encoder/") == 0 ? 0 : p.compare(0, 6, "prior/") == 0 ? 1 : p.compare(0, 8, "decoder/") == 0 ? 2 :
+                  p.compare(0, 10, "posterior/") == 0 ? 3 : -1;
+    if (m >= 0) h->range_state[m] = 2;
+  }
+  return VNR_OK;
+}
+
+// ---- range sentinel: checkpoints (see vnr_context::range_flag) --------------------------------------------------------------------
+// Called behind a stream synchronisation.  Raised word: everything since the previous checkpoint is suspect -> VNR_ERR_RANGE, the
+// modules that ran on the split path since then move to exact fp32 (they stay there until their weights change).
+int range_checkpoint(vnr_handle h) {
+  if (!h->range_flag) return VNR_OK;
+  const unsigned mods = h->mods_pending;
+  h->mods_pending = 0;
+  if (!*reinterpret_cast<volatile unsigned*>(h->range_flag)) return VNR_OK;
+  *reinterpret_cast<volatile unsigned*>(h->range_flag) = 0u;
+  h->range_trips++;
+  for (int m = 0; m < 4; ++m) if (mods & (1u << m)) h->range_state[m] = 2;
+  return fail(h, VNR_ERR_RANGE, "an activation left the fp16 range (|x| >= 65504) inside a split-fp16 product since the last synchronisation point: the "
+              "results computed since then are invalid.  The modules involved now run on exact fp32 (products on fp32 MFMA, attention cores with "
+              "per-launch operand scales): issue those calls again");
+}
+// has the word been raised since it was last cleared?  (synchronous users: the stream is idle)  Clears it.
+bool range_tripped(vnr_handle h) {
+  if (!h->range_flag || !*reinterpret_cast<volatile unsigned*>(h->range_flag)) return false;
+  *reinterpret_cast<volatile unsigned*>(h->range_flag) = 0u;
+  h->range_trips++;
+  return true;
+}
+// A call that changes variables (Dropout / batch-statistics forwards with their moving update, vnr_init): it cannot be replayed by the
+// caller, so it checks itself -- synchronise, look at the word, and on a trip run once more on exact fp32 (the BatchNormalization moving
+// update of the first pass was predicated on the word: the variables see one update).
+template <class F> int range_checked_sync(vnr_handle h, F body) {
+  if (!h->range_sentinel || !h->range_flag || !h->split_enabled) return body();
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (range_checkpoint(h) != VNR_OK) { /* an earlier asynchronous call tripped: reported at ITS checkpoint below */ return VNR_ERR_RANGE; }
+  int rc = body();
+  if (rc != VNR_OK) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!range_tripped(h)) return VNR_OK;
+  h->split_suspended = true;
+  rc = body();
+  h->split_suspended = false;
+  if (rc != VNR_OK) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (range_tripped(h)) return fail(h, VNR_ERR_RANGE, "non-finite values on the exact-fp32 path as well: the inputs or the variables hold NaN / inf");
+  return VNR_OK;
+}
 template <class F> int range_guarded(vnr_handle h, unsigned mods, F body) {
   if (!h) return body();
   TRY(check_ready(h));                                     // (a stale pack is rebuilt here: that resets the states before they are read)
   h->split_suspended = false;
-  if (!h->range_guard || !h->split_enabled || h->training || h->in_train_step) return body();
+  if (h->in_train_step) return body();                     // (vnr_train_step checks and repeats itself)
+  if (h->training) return range_checked_sync(h, body);     // a forward that updates variables: synchronous check, no survey
+  if (!h->split_enabled) return body();
   bool any_exact = false, any_unknown = false;
   for (int m = 0; m < 4; ++m) if (mods & (1u << m)) { any_exact |= h->range_state[m] == 2; any_unknown |= h->range_state[m] == 0; }
-  if (!any_exact && !any_unknown) return body();
-  if (!any_unknown) { h->split_suspended = true; const int rc = body(); h->split_suspended = false; return rc; }
+  // "range_guard" = 0 switches the SURVEY off; a state 2 that the sentinel or the static LayerNorm bound has set is honoured either way
+  if (any_exact && (!any_unknown || !h->range_guard)) { h->split_suspended = true; const int rc = body(); h->split_suspended = false; return rc; }
+  if (!h->range_guard || (!any_exact && !any_unknown)) { h->mods_pending |= mods; return body(); }
   TRY(survey_begin(h));
   h->split_suspended = true;
   const int rc = body();
@@ -1464,14 +1575,8 @@ template <class F> int range_guarded(vnr_handle h, unsigned mods, F body) {
   const int rc2 = survey_end(h, &verdict);
   if (rc != VNR_OK) return rc;
   if (rc2 != VNR_OK) return rc2;
-  if (verdict == 3) {
-    char msg[256];
-    snprintf(msg, sizeof msg, "an attention operand (query / key / value projection output) has magnitude %.3g .. %.3g, outside the split-fp16 "
-             "window [2^-6, 2^15): rescale those kernels (the attention cores have no exact-fp32 form)", (double)h->range_lo, (double)h->range_hi);
-    return fail(h, VNR_ERR_STATE, msg);
-  }
   for (int m = 0; m < 4; ++m) if (mods & (1u << m)) h->range_state[m] = (any_exact || verdict == 2) ? 2 : 1;
-  if (verdict == 1 && !any_exact) return body();           // in window: the call returns what every later call returns (split path)
+  if (verdict == 1 && !any_exact) { h->mods_pending |= mods; return body(); }   // in window: the call returns what every later call returns (split path)
   return VNR_OK;                                           // exact fp32 results stand
 }
 
@@ -1562,6 +1667,18 @@ int vnr_create(const vnr_config* cfg, int device, vnr_handle* out) {
     delete h;
     return fail(nullptr, VNR_ERR_NOMEM, "hipMalloc of the chain kernels' pacing words failed");
   }
+  // the range sentinel's word: host-pinned (the kernels store through the unified address space, the host reads it behind a
+  // synchronisation without a copy) + the device word the training step's Adam launch reads
+  if (hipHostMalloc((void**)&h->range_flag, 64, hipHostMallocDefault) != hipSuccess) h->range_flag = nullptr;
+  if (h->range_flag) *h->range_flag = 0u;
+  if (hipMalloc((void**)&h->d_step_flag, 64) != hipSuccess || hipMemset(h->d_step_flag, 0, 64) != hipSuccess) {
+    if (h->range_flag) hipHostFree(h->range_flag);
+    hipFree(h->chain_progress);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return fail(nullptr, VNR_ERR_NOMEM, "hipMalloc of the range sentinel's word failed");
+  }
+  if (getenv("VNR_TRAIN_FP32")) h->train_fp32 = true;       // A/B switch: exact fp32 MFMA GEMMs in the training step
   *out = h;
   return VNR_OK;
 }
@@ -1580,6 +1697,8 @@ int vnr_destroy(vnr_handle h) {
   for (auto& kv : h->voc_tables) hipFree(kv.second);
   if (h->survey_words) hipFree(h->survey_words);
   if (h->chain_progress) hipFree(h->chain_progress);
+  if (h->range_flag) hipHostFree(h->range_flag);
+  if (h->d_step_flag) hipFree(h->d_step_flag);
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : h->event_pool) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
@@ -1614,6 +1733,11 @@ int vnr_free(vnr_handle h, void* d_ptr) {
 int vnr_memcpy_h2d(vnr_handle h, void* d, const void* s, size_t n) {
   if (!h) return fail(h, VNR_ERR_ARG, "null handle");
   HIP_TRY(h, hipSetDevice(h->device));
+  // a checkpoint of the range sentinel BEFORE the copy: what a flagged call read must still be there when the caller repeats it
+  if (h->mods_pending || (h->range_flag && *reinterpret_cast<volatile unsigned*>(h->range_flag))) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    TRY(range_checkpoint(h));
+  }
   HIP_TRY(h, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // pageable host memory may be reused by the caller
   return VNR_OK;
@@ -1623,7 +1747,7 @@ int vnr_memcpy_d2h(vnr_handle h, void* dst, const void* s, size_t n) {
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpyAsync(dst, s, n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return VNR_OK;
+  return range_checkpoint(h);                     // (range sentinel: the bytes just copied are not to be trusted when the word is raised)
 }
 int vnr_memcpy_d2d(vnr_handle h, void* dst, const void* s, size_t n) {
   if (!h) return fail(h, VNR_ERR_ARG, "null handle");
@@ -1641,7 +1765,7 @@ int vnr_synchronize(vnr_handle h) {
   if (!h) return fail(h, VNR_ERR_ARG, "null handle");
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return VNR_OK;
+  return range_checkpoint(h);
 }
 
 int vnr_set_weight(vnr_handle h, const char* path, const float* host, const int64_t* shape, int ndim) {
@@ -1685,6 +1809,7 @@ int vnr_finalize_weights(vnr_handle h) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->packed_stale = false;
   for (int m = 0; m < 4; ++m) h->range_state[m] = 0;      // activation ranges are a property of the weights: surveyed again on the next call
+  TRY(ln_static_bound(h));                                // ... except where the variables alone already say "outside"
   for (auto& kv : h->w) if (kv.second.n == 1 && kv.second.d) HIP_TRY(h, hipMemcpy(&kv.second.scalar, kv.second.d, sizeof(float), hipMemcpyDeviceToHost));
   for (auto p : h->packed_allocs) hipFree(p);
   h->packed_allocs.clear();
@@ -2038,11 +2163,13 @@ int vnr_prior_init(vnr_handle h, const int32_t* d_z_lengths, const float* d_text
                    const float* d_eps, float* d_z, float* d_logprobs) {
   TRY(check_ready(h));
   if (!d_z_lengths || !d_text_embd || !d_z || B <= 0 || Tz <= 0 || Tt <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
-  ws_reset(h);
-  WS(kv, (size_t)B * Tt * h->prior_kv_n);
-  TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
   h->derived_fresh = false;
-  TRY(prior_init_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs));
+  TRY(range_checked_sync(h, [&]() -> int {                // (range sentinel: the ActNorm variables are ASSIGNED -- a repeat on exact fp32 overwrites them)
+    ws_reset(h);
+    WS(kv, (size_t)B * Tt * h->prior_kv_n);
+    TRY(run_kv(h, d_text_embd, B, Tt, h->cfg.enc_pre_hidden, h->prior_kv_wt, h->prior_kv_n, kv, h->cfg.prior_attention_dim));
+    return prior_init_body(h, d_z_lengths, d_text_lengths, kv, h->prior_kv_n, B, Tz, Tt, d_eps, d_z, d_logprobs);
+  }));
   return vnr_finalize_weights(h);
 }
 
@@ -2151,16 +2278,43 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
     return fail(h, VNR_ERR_ARG, "bad argument");
   if (h->cfg.num_mels != h->cfg.output_dim) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");
   if (rf > h->cfg.max_reduction_factor) return fail(h, VNR_ERR_ARG, "reduction_factor out of range");
-  ws_reset(h);
+  // range sentinel: whatever asynchronous calls are still pending get their checkpoint first (their verdict is theirs, not this step's)
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  TRY(range_checkpoint(h));
   const bool saved_split = h->split_scope, saved_training = h->training;
-  h->split_scope = false;            // exact fp32 GEMMs throughout the training step
-  h->training = true;
-  h->in_train_step = true;
-  g_det = h->deterministic ? &h->det : nullptr;          // kernels that would end in float atomics leave ordered partials instead (common.h: DetState)
-  const int rc = train_step_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps,
-                                 kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
-  g_det = nullptr;
-  h->split_scope = saved_split; h->training = saved_training; h->in_train_step = false;
+  int rc = VNR_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    ws_reset(h);
+    h->split_scope = false;            // exact fp32 GEMMs throughout the training step
+    h->training = true;
+    h->in_train_step = true;
+    g_det = h->deterministic ? &h->det : nullptr;          // kernels that would end in float atomics leave ordered partials instead (common.h: DetState)
+    g_train_exact = h->train_fp32;
+    if (h->range_flag) h->range_flag[1] = 0u;
+    rc = train_step_impl(h, d_ids, d_text_lengths, d_mel_targets, d_mel_lengths, d_reduced_lengths, B, Tt, Tm, rf, pos_step, d_eps,
+                         kl_weight, length_weight, learning_rate, beta1, beta2, epsilon, apply_update, h_scalars);
+    g_det = nullptr; g_train_exact = false;
+    h->split_scope = saved_split; h->training = saved_training; h->in_train_step = false;
+    if (rc != VNR_OK || !h->range_flag || !h->range_sentinel) { if (h->range_flag) *h->range_flag = 0u; break; }
+    // The step's verdict (train_step_impl copied the word behind the backward pass, all-reduced it over the ranks and predicated Adam and
+    // the BatchNormalization moving updates on it).  Raised: the variables, Adam's moments and the moving statistics are as before the
+    // step; the step is repeated ONCE on exact fp32 MFMA with scaled attention cores and fp32 kernel-gradient GEMMs, and the handle
+    // stays on that path (its weights produce activations the split path cannot carry).
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const bool tripped = h->range_flag[1] != 0u;
+    *h->range_flag = 0u; h->range_flag[1] = 0u;
+    HIP_TRY(h, hipMemsetAsync(h->d_step_flag, 0, sizeof(unsigned), h->stream));
+    if (!tripped) break;
+    h->range_trips++;
+    if (apply_update) train_step_rollback(h);
+    if (h->train_fp32) {
+      rc = fail(h, VNR_ERR_RANGE, "vnr_train_step: non-finite gradients on the exact-fp32 path as well (inputs or variables hold NaN / inf, or the "
+                                  "attention backward's operands left the fp16 range): the variables were NOT updated");
+      break;
+    }
+    h->train_fp32 = true;
+    h->derived_fresh = false;
+  }
   if (h->det.alloc_failed) {                               // never lose bit-reproducibility silently under memory pressure
     h->det.alloc_failed = false;
     return fail(h, VNR_ERR_NOMEM, "deterministic mode: a scratch buffer for ordered partial sums could not be allocated -- that launch fell back to "
@@ -2291,10 +2445,10 @@ int vnr_init(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_lengths, 
              int Tt, int Tz, float pos_step, const float* d_eps, float* d_mel) {
   TRY(check_ready(h));
   if (!d_ids || !d_reduced_lengths || B <= 0 || Tt <= 0 || Tz <= 0) return fail(h, VNR_ERR_ARG, "bad argument");
-  ws_reset(h);
   const bool saved = h->training;
   h->training = true;
-  const int rc = init_impl(h, d_ids, d_text_lengths, d_reduced_lengths, B, Tt, Tz, pos_step, d_eps, d_mel);
+  // (range sentinel: ActNormFlow.init ASSIGNS its variables from the statistics of its input -- a repeat on exact fp32 overwrites them)
+  const int rc = range_checked_sync(h, [&] { ws_reset(h); return init_impl(h, d_ids, d_text_lengths, d_reduced_lengths, B, Tt, Tz, pos_step, d_eps, d_mel); });
   h->training = saved;
   h->derived_fresh = false;
   TRY(rc);
@@ -2508,6 +2662,8 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "n_sample")) { if (value < 1 || value > 64) return fail(h, VNR_ERR_ARG, "n_sample: 1..64"); h->n_sample = value; return VNR_OK; }
   if (!strcmp(name, "deterministic")) { h->deterministic = value != 0; return VNR_OK; }
   if (!strcmp(name, "range_guard")) { h->range_guard = value != 0; for (int m = 0; m < 4; ++m) h->range_state[m] = 0; return VNR_OK; }
+  if (!strcmp(name, "range_sentinel")) { h->range_sentinel = value != 0; return VNR_OK; }
+  if (!strcmp(name, "train_fp32")) { h->train_fp32 = value != 0; h->derived_fresh = false; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }
 
@@ -2517,6 +2673,15 @@ int vnr_range_info(vnr_handle h, int* states4, float* lo, float* hi, int64_t* su
   if (lo) *lo = h->range_lo;
   if (hi) *hi = h->range_hi;
   if (surveys) *surveys = h->range_surveys;
+  return VNR_OK;
+}
+// the range sentinel (vnr_context::range_flag): checkpoints that found the word raised so far, whether the training step has moved to its
+// exact-fp32 path, and the modules (bit 0 encoder .. bit 3 posterior) whose split-path results still wait for a checkpoint
+int vnr_range_sentinel(vnr_handle h, int64_t* trips, int* train_fp32, int* pending_modules) {
+  if (!h) return fail(h, VNR_ERR_ARG, "null handle");
+  if (trips) *trips = h->range_trips;
+  if (train_fp32) *train_fp32 = h->train_fp32 ? 1 : 0;
+  if (pending_modules) *pending_modules = (int)h->mods_pending;
   return VNR_OK;
 }
 

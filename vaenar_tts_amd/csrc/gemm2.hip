@@ -44,11 +44,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits carried by two fp16 values
-__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)x;
-  lo = (_Float16)(x - (float)hi);
-}
+// (x = hi + lo with hi = fp16(x), lo = fp16(x - hi), 22 significant bits carried by two fp16 values: common.h, vnr_split)
 
 }  // namespace
 
@@ -344,13 +340,11 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
         blo[set][j] = *reinterpret_cast<const f16x8*>(Bs + j * 4096 + rdB[t][1]);
       }
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          _Float16 h, l;
-          split_f16(x0[i][e] * a_sc, h, l); ahi[set][i][e] = h; alo[set][i][e] = l;
-          split_f16(x1[i][e] * a_sc, h, l); ahi[set][i][4 + e] = h; alo[set][i][4 + e] = l;
-        }
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 s0 = x0[i] * a_sc, s1 = x1[i] * a_sc;
+        const vnr_f8 xs_ = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        vnr_split(xs_, ahi[set][i], alo[set][i]);
+      }
       }
     };
     // VT (tile-uniform, chosen once per workgroup): the tile holds only V-type columns of an attention operand image -> the
@@ -486,6 +480,20 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
       slot = nx;
     }
 }
+  if constexpr (SPLIT != 0) {
+    // overflow sentinel (common.h: range_note): an A element that left the fp16 range made every accumulator of its row NaN
+    if (g.range_flag) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float probe = acc[i][0][0];                   // D^T layout: this lane's row
+        if (vtile) {                                  // un-transposed layout: the 16 registers are 16 rows of the block
+#pragma unroll
+          for (int r = 1; r < 16; ++r) probe += acc[i][0][r];
+        }
+        range_note(g.range_flag, probe);
+      }
+    }
+  }
   if (PRM_LATE) load_params();
   wait_vmcnt<0>();                                    // drain the dummy tail tiles before LDS is reused / exit
 
@@ -513,8 +521,12 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
           if (R >= g.M) continue;
           const int bb = R / g.aoi.T, tt = R - bb * g.aoi.T;
           f16x8 hi, lo;
+          {
+            vnr_f8 xs_;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { _Float16 hh, ll; split_f16(acc[i][j][8 * tp + e] * ascale, hh, ll); hi[e] = hh; lo[e] = ll; }
+            for (int e = 0; e < 8; ++e) xs_[e] = acc[i][j][8 * tp + e] * ascale;
+            vnr_split(xs_, hi, lo);
+          }
           char* pd = g.aoi.vt + (size_t)blk * g.aoi.blk_bytes + ((size_t)(bb * Hh + head) * g.aoi.TT + (tt >> 5)) * kAoiTile +
                      ((tt >> 4) & 1) * 2048 + ((dch >> 5) & 1) * 1024 + ((half * 32 + (dch & 31)) << 4);
           *reinterpret_cast<f16x8*>(pd) = hi;
@@ -562,8 +574,7 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
             else if (g.c_split) {                                // split rows: 4 x fp16 hi at its place in the 32-channel tile, lo 64 bytes on
               typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
               h4_t hi, lo;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split_f16(v[e], hh, ll); hi[e] = hh; lo[e] = ll; }
+              { const vnr_f4 xs_ = {v[0], v[1], v[2], v[3]}; vnr_split(xs_, hi, lo); }
               char* pc = reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4 + (col >> 5) * 128 + (col & 31) * 2;
               *reinterpret_cast<h4_t*>(pc) = hi;
               *reinterpret_cast<h4_t*>(pc + 64) = lo;

@@ -172,8 +172,7 @@ panel_chain_kernel(const ChainArgs g) {
         const int kt = j >> 3, p = (j & 7) * 4;                    // position inside the 32-k tile
         h16x4 hi, lo;
         const float xv[4] = {x[pi][it].x, x[pi][it].y, x[pi][it].z, x[pi][it].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const _Float16 h = (_Float16)xv[q]; hi[q] = h; lo[q] = (_Float16)(xv[q] - (float)h); }
+        { const vnr_f4 xs_ = {xv[0], xv[1], xv[2], xv[3]}; vnr_split(xs_, hi, lo); }
         *reinterpret_cast<h16x4*>(panel_ptr(pi) + panel_off(r, kt, p >> 3) + (p & 4) * 2) = hi;
         *reinterpret_cast<h16x4*>(panel_ptr(pi) + panel_off(r, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
       }
@@ -290,8 +289,7 @@ panel_chain_kernel(const ChainArgs g) {
               }
             }
             h8a phi, plo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)sacc[8 * tp + e]; phi[e] = hh; plo[e] = (_Float16)(sacc[8 * tp + e] - (float)hh); }
+            { const vnr_f8 xs_ = {sacc[8 * tp + 0], sacc[8 * tp + 1], sacc[8 * tp + 2], sacc[8 * tp + 3], sacc[8 * tp + 4], sacc[8 * tp + 5], sacc[8 * tp + 6], sacc[8 * tp + 7]}; vnr_split(xs_, phi, plo); }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
               O[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi[tp][nb], phi, O[nb], 0, 0, 0);
@@ -470,6 +468,17 @@ panel_chain_kernel(const ChainArgs g) {
     else kloop(std::integral_constant<int, 1>{});
     stamp(2 + 2 * si);
     wstamp(si, 1);
+    if (g.range_flag && wave_on) {                       // overflow sentinel (common.h: range_note): a row with a split operand out of range is all NaN
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float probe = acc[rt][0];                        // D^T layout: this lane's row
+        if (vswap) {                                     // un-transposed stage: the 16 registers are 16 rows
+#pragma unroll
+          for (int r = 1; r < 16; ++r) probe += acc[rt][r];
+        }
+        range_note(g.range_flag, probe);
+      }
+    }
     // ---- FFN second layer: accumulate over hidden chunks (modes 1,2: no epilogue yet) ----------------------------------
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -498,8 +507,7 @@ panel_chain_kernel(const ChainArgs g) {
           const float x[4] = {fmaxf(acc[rt][4 * q] * st.scale + bi.x, 0.f), fmaxf(acc[rt][4 * q + 1] * st.scale + bi.y, 0.f),
                               fmaxf(acc[rt][4 * q + 2] * st.scale + bi.z, 0.f), fmaxf(acc[rt][4 * q + 3] * st.scale + bi.w, 0.f)};
           h16x4 hi, lo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+          { const vnr_f4 xs_ = {x[0], x[1], x[2], x[3]}; vnr_split(xs_, hi, lo); }
           const int p = 8 * q + 4 * half;
           *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
           *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
@@ -523,8 +531,12 @@ panel_chain_kernel(const ChainArgs g) {
             if (R >= g.M) continue;
             const int bb = R / st.aoi_T, tt = R - bb * st.aoi_T;
             h16x8 hi, lo;
+            {
+              vnr_f8 xs_;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float x = acc[rt][8 * tp + e] * st.scale + bv; const _Float16 hh = (_Float16)x; hi[e] = hh; lo[e] = (_Float16)(x - (float)hh); }
+              for (int e = 0; e < 8; ++e) xs_[e] = acc[rt][8 * tp + e] * st.scale + bv;
+              vnr_split(xs_, hi, lo);
+            }
             char* pdst = reinterpret_cast<char*>(st.out) + 2 * st.aoi_img_bytes + ((size_t)(bb * Hh + (cv >> 6)) * TT + (tt >> 5)) * kAoiTile +
                          ((tt >> 4) & 1) * 2048 + ((cv >> 5) & 1) * 1024 + ((half * 32 + l31) << 4);
             *reinterpret_cast<h16x8*>(pdst) = hi;
@@ -614,8 +626,7 @@ panel_chain_kernel(const ChainArgs g) {
               if (row < g.M) out_store4(zp, o[0], o[1], o[2], o[3]);
             }
             h16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)o[e]; hi[e] = hh; lo[e] = (_Float16)(o[e] - (float)hh); }
+            { const vnr_f4 xs_ = {o[0], o[1], o[2], o[3]}; vnr_split(xs_, hi, lo); }
             const int kt = (zoff + c) >> 5, p = (zoff + c) & 31;
             *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
             *reinterpret_cast<h16x4*>(Dp + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;
@@ -755,8 +766,7 @@ panel_chain_kernel(const ChainArgs g) {
         if (st.out && row < g.M) {
           if (img_row) {                                   // channel d = (cw & 63) + 8q + 4 half: t = d >> 4, g = q & 1
             h16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)v[rt][4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(v[rt][4 * q + e] - (float)hh); }
+            { const vnr_f4 xs_ = {v[rt][4 * q + 0], v[rt][4 * q + 1], v[rt][4 * q + 2], v[rt][4 * q + 3]}; vnr_split(xs_, hi, lo); }
             char* pd = img_row + (q >> 1) * 1024 + (q & 1) * 512;
             *reinterpret_cast<h16x4*>(pd) = hi;
             *reinterpret_cast<h16x4*>(pd + 4096) = lo;
@@ -769,8 +779,7 @@ panel_chain_kernel(const ChainArgs g) {
         }
         if (st.dst >= 0) {
           h16x4 hi, lo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)v[rt][4 * q + e]; hi[e] = h; lo[e] = (_Float16)(v[rt][4 * q + e] - (float)h); }
+          { const vnr_f4 xs_ = {v[rt][4 * q + 0], v[rt][4 * q + 1], v[rt][4 * q + 2], v[rt][4 * q + 3]}; vnr_split(xs_, hi, lo); }
           const int kt = col >> 5, p = col & 31;
           *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(prow, kt, p >> 3) + (p & 4) * 2) = hi;
           *reinterpret_cast<h16x4*>(panel_ptr(st.dst) + panel_off(prow, kt, 4 + (p >> 3)) + (p & 4) * 2) = lo;

@@ -150,8 +150,7 @@ bwd_chain_kernel(const BwdChainArgs g) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         h16x4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const _Float16 hh = (_Float16)x[rt][4 * q + e]; hi[e] = hh; lo[e] = (_Float16)(x[rt][4 * q + e] - (float)hh); }
+        { const vnr_f4 xs_ = {x[rt][4 * q + 0], x[rt][4 * q + 1], x[rt][4 * q + 2], x[rt][4 * q + 3]}; vnr_split(xs_, hi, lo); }
         const int p = 8 * q + 4 * half;
         *reinterpret_cast<h16x4*>(Dp + panel_off_b(32 * rt + l31, wave, p >> 3) + (p & 4) * 2) = hi;
         *reinterpret_cast<h16x4*>(Dp + panel_off_b(32 * rt + l31, wave, 4 + (p >> 3)) + (p & 4) * 2) = lo;

@@ -537,6 +537,14 @@ panel_chain4_kernel(const ChainArgs g) {
     }
     stamp(2 + 2 * si);
     wstamp(si, 1);
+    // (overflow sentinel, common.h: range_note -- lane = row, and a row with a split operand out of the fp16 range is all NaN.  The probe
+    //  sits in every epilogue path, on the first value the path derives from its accumulators anyway: read here, straight from the
+    //  accumulator file, it cost the kernel its first spilled register.  TWO paths carry none -- the Q | K image tails and the plain
+    //  Dense stages of a pre-chain: there the probe's branch spilled a register too.  What they would see is seen elsewhere: the tails
+    //  multiply a LayerNorm output, |y| <= |gamma| sqrt(D) + |beta| whatever the input -- a property of the variables that
+    //  vnr_finalize_weights checks (engine.hip: ln_static_bound) --; the pre-chain stages multiply z and the pre-projection's x, which
+    //  leave as fp32 rows and are split AGAIN by the next launch's panel load in front of a probed stage (att_proj1 reads x and adds it
+    //  as the residual), and a NaN they hand on reaches that probe as well)
     // ---- FFN second layer: accumulate over hidden chunks (modes 1, 2: no epilogue yet) ---------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -572,7 +580,10 @@ panel_chain4_kernel(const ChainArgs g) {
           const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
           float x4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x4[e] = fmaxf(acc[j][4 * q + e] * st.scale + bq[e], floor_v);
+          for (int e = 0; e < 4; ++e) x4[e] = acc[j][4 * q + e] * st.scale + bq[e];
+          if (j == 0 && q == 0) range_note(g.range_flag, x4[0]);          // (before the ReLU: fmaxf(NaN, 0) = 0 would heal the row)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x4[e] = fmaxf(x4[e], floor_v);
           split_hi_lo(x4, xh[j][q], xl[j][q]);
         }
       __builtin_amdgcn_sched_barrier(0);
@@ -608,7 +619,11 @@ panel_chain4_kernel(const ChainArgs g) {
           for (int q = 0; q < 4; ++q) {
             const float bq[4] = {bi[j][q].x, bi[j][q].y, bi[j][q].z, bi[j][q].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tb[j * (32 * 33) + (8 * q + 4 * half + e) * 33 + l31] = acc[j][4 * q + e] * st.scale + bq[e];
+            for (int e = 0; e < 4; ++e) {
+              const float tv = acc[j][4 * q + e] * st.scale + bq[e];
+              if (j == 0 && q == 0 && e == 0) range_note(g.range_flag, tv);
+              tb[j * (32 * 33) + (8 * q + 4 * half + e) * 33 + l31] = tv;
+            }
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -795,6 +810,7 @@ panel_chain4_kernel(const ChainArgs g) {
             ps[e] += x;
           }
         }
+      range_note(g.range_flag, v[0][0]);
       wstamp(si, 6);
       // gamma / beta do not depend on the statistics: their reads travel while the row sums are exchanged
       float4 ga[2][4], be[2][4];
@@ -876,6 +892,7 @@ panel_chain4_kernel(const ChainArgs g) {
         v[j][4 * q + 2] = acc[j][4 * q + 2] * st.scale + bi.z;
         v[j][4 * q + 3] = acc[j][4 * q + 3] * st.scale + bi.w;
       }
+    range_note(g.range_flag, v[0][0]);
     if (st.act == ACT_RELU) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)

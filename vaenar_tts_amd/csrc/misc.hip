@@ -282,8 +282,8 @@ __global__ void split_weights_kernel(const float* __restrict__ Wt, int N, int K,
   const int p = idx & 31; const size_t nk = idx >> 5; const int kt = nk % KT; const size_t n = nk / KT;
   const int k = kt * 32 + p;
   const float w = k < K ? Wt[n * K + k] * scale : 0.f;
-  const _Float16 hi = (_Float16)w;
-  const _Float16 lo = (_Float16)(w - (float)hi);
+  _Float16 hi, lo;
+  vnr_split(w, hi, lo);
   out[nk * 64 + p] = hi;
   out[nk * 64 + 32 + p] = lo;
 }
@@ -307,8 +307,9 @@ __global__ void opmajor_weights_kernel(const float* __restrict__ Wt, int N, int 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float w = (n < N && k0 + e < K) ? Wt[(size_t)n * K + k0 + e] * scale : 0.f;
-    const _Float16 h = (_Float16)w;
-    hi[e] = h; lo[e] = (_Float16)(w - (float)h);
+    _Float16 h, l;
+    vnr_split(w, h, l);
+    hi[e] = h; lo[e] = l;
   }
 }
 hipError_t launch_opmajor_weights(const float* Wt, int N, int K, float scale, void* out, hipStream_t s) {
@@ -341,8 +342,7 @@ gather_rows_split_kernel(const float* __restrict__ table, const int32_t* __restr
     const float4 v = *reinterpret_cast<const float4*>(src + c);
     const float x[4] = {v.x, v.y, v.z, v.w};
     h4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+    { const vnr_f4 xs_ = {x[0], x[1], x[2], x[3]}; vnr_split(xs_, hi, lo); }
     char* p = dst + (c >> 5) * 128 + (c & 31) * 2;
     *reinterpret_cast<h4*>(p) = hi;
     *reinterpret_cast<h4*>(p + 64) = lo;
@@ -699,7 +699,7 @@ hipError_t launch_scale_d(double* v, int n, double f, hipStream_t s) {
 // what the backward pass reads (float64: sum x^2 - M mean^2 keeps ~1e-13 of the variance for activations of unit order)
 __global__ void bn_train_finish_kernel(double* mean, double* sq, int M, int C, const float* gamma,
                                        const float* beta, float momentum, float* moving_mean, float* moving_var,
-                                       float* scale, float* shift, int raw) {
+                                       float* scale, float* shift, int raw, const unsigned* skip_moving) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   if (raw) {
@@ -712,13 +712,17 @@ __global__ void bn_train_finish_kernel(double* mean, double* sq, int M, int C, c
   const float inv = gamma[c] * (1.0f / sqrtf(var + kBnEps));
   scale[c] = inv;
   shift[c] = beta[c] - mu * inv;
+  // (the overflow sentinel of the split path has tripped in this call: its statistics may come from non-finite rows, the call will be
+  //  repeated on exact fp32 -- the variables must see ONE update, that of the repeat)
+  if (skip_moving && *reinterpret_cast<const volatile unsigned*>(skip_moving)) return;
   moving_mean[c] = moving_mean[c] * momentum + mu * (1.0f - momentum);
   moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
 }
 hipError_t launch_bn_train_finish(const double* mean, const double* sq, int M, int C, const float* gamma, const float* beta,
-                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw) {
+                                  float momentum, float* moving_mean, float* moving_var, float* scale, float* shift, hipStream_t s, int raw,
+                                  const unsigned* skip_moving) {
   vnr_launch(bn_train_finish_kernel, dim3((C + 127) / 128), dim3(128), 0, s, const_cast<double*>(mean), const_cast<double*>(sq), M, C, gamma, beta, momentum,
-                     moving_mean, moving_var, scale, shift, raw);
+                     moving_mean, moving_var, scale, shift, raw, skip_moving);
   return hipGetLastError();
 }
 // ActNormFlow.init (flow.py:189-196): log_scale = log(1 / (std + 1e-8)), bias = -mean / (std + 1e-8) from the
@@ -912,10 +916,12 @@ hipError_t launch_philox_normal(float* out, size_t n, unsigned long long seed, u
 // out[0] = bits of the largest row maximum max_r max_c |x[r][c]| (atomicMax), out[1] = bits of the smallest NON-ZERO row maximum
 // (atomicMin; the caller initialises it to 0x7f800000).  Non-negative floats order like their bit patterns; a NaN counts as +inf.
 namespace {
-__global__ void __launch_bounds__(256) row_range_kernel(const float* x, long long ld, int rows, int cols, unsigned* out) {
+__global__ void __launch_bounds__(256) row_range_kernel(const float* x, long long ld, int rows, int cols, unsigned* out, int T, long long bs) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* p = x + (size_t)row * ld;
+  // T > 0: a batch of matrices -- row r is row r % T of element r / T, elements bs floats apart (the attention operands of one call)
+  const int bb = T > 0 ? row / T : 0;
+  const float* p = x + (size_t)bb * bs + (size_t)(row - bb * T) * ld;
   float m = 0.f;
   for (int c = lane; c < cols; c += 64) { const float v = p[c]; m = fmaxf(m, (v != v) ? INFINITY : fabsf(v)); }
 #pragma unroll
@@ -926,10 +932,33 @@ __global__ void __launch_bounds__(256) row_range_kernel(const float* x, long lon
     if (b != 0u && b < __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out + 1, b);
   }
 }
+// true (word 0 of flag set) when any element of x[0, n) is NaN or infinite: the training step's last look at the flat gradient on the
+// exact-fp32 fallback, whose products carry no sentinel of their own (engine.hip, "range sentinel")
+__global__ void __launch_bounds__(256) finite_check_kernel(const float* x, size_t n, unsigned* flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    bad |= !(fabsf(v) < INFINITY);
+  }
+  if (bad) *reinterpret_cast<volatile unsigned*>(flag) = 1u;
+}
 }  // namespace
 hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return hipSuccess;
-  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, rows, cols, out);
+  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, rows, cols, out, 0, (long long)0);
+  return hipGetLastError();
+}
+// the same over a batch of B matrices of T rows each, `bs` floats apart: ONE record for the whole operand
+hipError_t launch_row_range_batched(const float* x, long long ld, int T, long long bs, int B, int cols, unsigned* out, hipStream_t s) {
+  if (T <= 0 || B <= 0 || cols <= 0) return hipSuccess;
+  const long long rows = (long long)T * B;
+  if (rows > 0x7fffffffLL) return hipErrorInvalidValue;
+  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, (int)rows, cols, out, T, bs);
+  return hipGetLastError();
+}
+hipError_t launch_finite_check(const float* x, size_t n, unsigned* flag, hipStream_t s) {
+  if (!n) return hipSuccess;
+  vnr_launch(finite_check_kernel, dim3(1024), dim3(256), 0, s, x, n, flag);
   return hipGetLastError();
 }
 

@@ -142,16 +142,14 @@ gemm_tn_split_kernel(const float* A, int lda, const float* B, int ldb, float* C,
 #pragma unroll
     for (int c = 0; c < TK; ++c) {
       h16x8_t ah, al;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)ra[c][e]; ah[e] = h; al[e] = (_Float16)(ra[c][e] - (float)h); }
+      { const vnr_f8 xs_ = {ra[c][0], ra[c][1], ra[c][2], ra[c][3], ra[c][4], ra[c][5], ra[c][6], ra[c][7]}; vnr_split(xs_, ah, al); }
       const int o = buf * KW * CS + (col + 64 * c) * CS + 8 * rg;
       *reinterpret_cast<h16x8_t*>(&Ah[o]) = ah; *reinterpret_cast<h16x8_t*>(&Al[o]) = al;
     }
 #pragma unroll
     for (int c = 0; c < TN; ++c) {
       h16x8_t bh, bl;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)rb[c][e]; bh[e] = h; bl[e] = (_Float16)(rb[c][e] - (float)h); }
+      { const vnr_f8 xs_ = {rb[c][0], rb[c][1], rb[c][2], rb[c][3], rb[c][4], rb[c][5], rb[c][6], rb[c][7]}; vnr_split(xs_, bh, bl); }
       const int o = buf * NW * CS + (col + 64 * c) * CS + 8 * rg;
       *reinterpret_cast<h16x8_t*>(&Bh[o]) = bh; *reinterpret_cast<h16x8_t*>(&Bl[o]) = bl;
     }
@@ -579,7 +577,7 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   static const bool skip_all = getenv("VNR_TRAIN_SKIP_TN") != nullptr;      // measurement only (WRONG gradients): the step without its kernel-gradient GEMMs = the main chain alone
   if (skip_all) return hipSuccess;
   static const bool v1 = getenv("VNR_GEMM_TN_V1") != nullptr;      // A/B switch: exact fp32 MFMA 32x32x2 kernel
-  if (v1) {
+  if (v1 || g_train_exact) {
     const int tk = (K + 63) / 64, tn = (N + 63) / 64;
     int splits = target / (tk * tn); if (splits < 1) splits = 1;
     int max_splits = (M + 127) / 128; if (splits > max_splits) splits = max_splits;
@@ -786,8 +784,7 @@ attn_bwd_dkv_kernel(const AttnBwdArgs a) {
 //   kernel B (grid: 128-key blocks x H x B; wave = 32 keys): per 32-query tile   dV^T += dO^T.P, dK^T += Q^T.dS
 // Operand tiles are split to fp16 hi/lo ONCE by the staging threads and stored reduction-major in LDS.
 __device__ __forceinline__ void split8_t(const float* x, h16x8_t& hi, h16x8_t& lo) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)(x[e] - (float)h); }
+  { const vnr_f8 xs_ = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}; vnr_split(xs_, hi, lo); }
 }
 __device__ __forceinline__ f32x16 mfma3_t(const h16x8_t& ah, const h16x8_t& al, const h16x8_t& bh, const h16x8_t& bl, f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
@@ -1216,8 +1213,7 @@ __device__ __forceinline__ h16x8_t lds_tr8(const _Float16* p0, const _Float16* p
   return __builtin_bit_cast(h16x8_t, c);
 }
 __device__ __forceinline__ void split8_m(const float* x, h16x8_t& hi, h16x8_t& lo) {      // lo through one mixed-precision fma per value
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { const _Float16 h = (_Float16)x[e]; hi[e] = h; lo[e] = (_Float16)__builtin_fmaf((float)h, -1.f, x[e]); }
+  { const vnr_f8 xs_ = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}; vnr_split(xs_, hi, lo); }
 }
 // QG = 2 (launches of few workgroups: the cross-attentions, one 128-key block per (b, h) = 128 workgroups of 13 serial tiles on 256 CUs):
 // eight waves, the second four take the odd query tiles of the same keys with their own LDS tiles, and the two halves' accumulators
@@ -2484,9 +2480,10 @@ hipError_t launch_length_loss(const float* x, const float* w, const float* bias,
 // ---- optimizer: tf.keras.optimizers.Adam (train.py:116-117), one launch over a table of tensors -----------------------------
 // m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t * m / (sqrt(v) + eps), lr_t = lr sqrt(1-b2^t) / (1-b1^t)
 __global__ void adam_kernel(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
-                            float lr_t, float b1, float b2, float eps) {
+                            float lr_t, float b1, float b2, float eps, const unsigned* skip) {
   const int t = blockIdx.y;
   if (t >= ntensors) return;
+  if (skip && *skip) return;      // the step's overflow sentinel tripped (engine.hip, "range sentinel"): the variables and Adam's moments stay as they were
   float* wp = w[t]; const float* gp = g[t]; float* mp = m[t]; float* vp = v[t];
   const int64_t cnt = n[t];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2498,8 +2495,8 @@ __global__ void adam_kernel(float* const* w, const float* const* g, float* const
   }
 }
 hipError_t launch_adam(float* const* w, const float* const* g, float* const* m, float* const* v, const int64_t* n, int ntensors,
-                       float lr_t, float b1, float b2, float eps, hipStream_t s) {
-  vnr_launch(adam_kernel, dim3(64, ntensors), dim3(256), 0, s, w, g, m, v, n, ntensors, lr_t, b1, b2, eps);
+                       float lr_t, float b1, float b2, float eps, hipStream_t s, const unsigned* skip) {
+  vnr_launch(adam_kernel, dim3(64, ntensors), dim3(256), 0, s, w, g, m, v, n, ntensors, lr_t, b1, b2, eps, skip);
   return hipGetLastError();
 }
 
@@ -2747,8 +2744,7 @@ split_batch_kernel(const SplitJob* jobs, float scale) {
       const float4 a = src[0], b = src[1];
       const float w[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
       h8 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)w[e]; hi[e] = hh; lo[e] = (_Float16)(w[e] - (float)hh); }
+      { const vnr_f8 xs_ = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]}; vnr_split(xs_, hi, lo); }
       const size_t o = (j.dst_kt ? (size_t)r * (size_t)j.dst_kt + kt : (size_t)nk) * 64 + q * 8;
       *reinterpret_cast<h8*>(out + o) = hi;
       *reinterpret_cast<h8*>(out + o + 32) = lo;
@@ -2763,10 +2759,11 @@ split_batch_kernel(const SplitJob* jobs, float scale) {
     const size_t r = nk / KT;
     const int k = kt * 32 + p;
     const float w = k < j.cols ? j.src[r * j.cols + k] * scale : 0.f;
-    const _Float16 hi = (_Float16)w;
+    _Float16 hi, lo;
+    vnr_split(w, hi, lo);
     const size_t o = (j.dst_kt ? r * (size_t)j.dst_kt + kt : nk) * 64;
     out[o + p] = hi;
-    out[o + 32 + p] = (_Float16)(w - (float)hi);
+    out[o + 32 + p] = lo;
   }
 }
 __global__ void max_words_kernel(const WordList w, unsigned* out) {
@@ -2803,14 +2800,14 @@ opmajor_batch_kernel(const OpmJob* jobs, float scale) {
       const float4* src = reinterpret_cast<const float4*>(j.src + (size_t)n * j.K + k0);
       const float4 a = src[0], b = src[1];
       const float w[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const _Float16 hh = (_Float16)w[e]; hi[e] = hh; lo[e] = (_Float16)(w[e] - (float)hh); }
+      { const vnr_f8 xs_ = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]}; vnr_split(xs_, hi, lo); }
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float w = (n < j.N && k0 + e < j.K) ? j.src[(size_t)n * j.K + k0 + e] * scale : 0.f;
-        const _Float16 hh = (_Float16)w;
-        hi[e] = hh; lo[e] = (_Float16)(w - (float)hh);
+        _Float16 hh, ll;
+        vnr_split(w, hh, ll);
+        hi[e] = hh; lo[e] = ll;
       }
     }
     _Float16* ph = out + ((blk * 4 + 2 * t) * 512) + lane * 8;

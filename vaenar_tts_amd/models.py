@@ -110,9 +110,9 @@ class VAENAR:
         dec = self.decoder
         mel = eng.empty((B, Tz * rf, dec.out_dim))
         ali = eng.empty((dec.nblk, B, dec.heads, Tz, Tt)) if return_alignments else None
-        check(eng.lib.vnr_inference(eng.handle, ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, rf, float(pos_step),
+        eng.call("vnr_inference", ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, rf, float(pos_step),
                                     None if eps_d is None else eps_d.ptr, mel.ptr,
-                                    None if ali is None else ali.ptr, None), eng.handle)
+                                    None if ali is None else ali.ptr, None)
         alignments = {}
         if ali is not None:
             n = B * dec.heads * Tz * Tt
@@ -166,9 +166,9 @@ class VAENAR:
         try:
             if training:
                 eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
-            check(eng.lib.vnr_elbo_fwd(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+            eng.call("vnr_elbo_fwd", ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
                                        eps_d.ptr, outs.ptr, l2.ptr, kl.ptr, ll.ptr, None if ali is None else ali.ptr,
-                                       aux.ptr), eng.handle)
+                                       aux.ptr)
         finally:                       # a failing call must not leave the handle in training mode (the next inference would run
             eng.set_option("training", 0)      # with Dropout and batch statistics)
             eng.set_option("n_sample", 1)
@@ -207,8 +207,7 @@ class VAENAR:
         pos_step = np.float32(self.mel_text_len_ratio) / np.float32(rf)          # models.py:214
         mel = eng.empty((B, Tz * rf, self.decoder.out_dim))
         eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
-        check(eng.lib.vnr_init(eng.handle, ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, float(pos_step), eps_d.ptr, mel.ptr),
-              eng.handle)
+        eng.call("vnr_init", ids.ptr, tl.ptr, rl.ptr, B, Tt, Tz, float(pos_step), eps_d.ptr, mel.ptr, record=False)
         self._len_cache = {}
         return mel
 
@@ -241,9 +240,9 @@ class VAENAR:
         eng.set_option("dropout_seed", int(dropout_seed) & 0x7FFFFFFF)
         eng.set_option("n_sample", ns)
         try:
-            check(eng.lib.vnr_train_step(eng.handle, ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
+            eng.call("vnr_train_step", ids.ptr, tl.ptr, mel.ptr, ml.ptr, rl.ptr, B, Tt, Tm, rf, float(pos_step),
                                          eps_d.ptr, float(kl_weight), float(tr.length_weight), float(lr), 0.9, 0.999, 1e-7,
-                                         1 if apply_update else 0, scal.ctypes.data), eng.handle)
+                                         1 if apply_update else 0, scal.ctypes.data, record=False)
         finally:
             eng.set_option("n_sample", 1)
         self._len_cache = {}

@@ -29,8 +29,8 @@ class TransformerDecoder(EngineModule):
         outputs = e.empty((B, Tz * rf, self.out_dim))
         ali = e.empty((self.nblk, B, self.heads, Tz, Tt)) if return_alignments else None
         with self._training(training, dropout_seed):
-            check(e.lib.vnr_decoder_fwd(e.handle, z.ptr, mem.ptr, zl.ptr, tl.ptr, B, Tz, Tt, rf, initial.ptr,
-                                        outputs.ptr, self._ptr(ali)), e.handle)
+            e.call("vnr_decoder_fwd", z.ptr, mem.ptr, zl.ptr, tl.ptr, B, Tz, Tt, rf, initial.ptr,
+                                        outputs.ptr, self._ptr(ali))
         alignments = {}
         if ali is not None:
             n = B * self.heads * Tz * Tt

@@ -20,7 +20,7 @@ class TransformerEncoder(EngineModule):
         lens = self._i32(input_lengths, B, T)
         out = e.empty((B, T, self.pre_hidden))
         with self._training(training, dropout_seed):
-            check(e.lib.vnr_text_encoder_fwd(e.handle, ids.ptr, lens.ptr, B, T, float(pos_step), out.ptr), e.handle)
+            e.call("vnr_text_encoder_fwd", ids.ptr, lens.ptr, B, T, float(pos_step), out.ptr)
         return out
 
     call = __call__

@@ -16,7 +16,7 @@ class DenseLengthPredictor(EngineModule):
         B, T, _ = x.shape
         lens = self._i32(input_lengths, B, T)
         out = e.empty((B,))
-        check(e.lib.vnr_length_predictor_fwd(e.handle, x.ptr, lens.ptr, B, T, out.ptr), e.handle)
+        e.call("vnr_length_predictor_fwd", x.ptr, lens.ptr, B, T, out.ptr)
         return out
 
     call = __call__

@@ -27,8 +27,7 @@ class TransformerPosterior(EngineModule):
         mu = e.empty((B, Tz, self.latent_dim))
         logvar = e.empty((B, Tz, self.latent_dim))
         with self._training(training, dropout_seed):
-            check(e.lib.vnr_posterior_fwd(e.handle, x.ptr, mem.ptr, sl.ptr, tl.ptr, B, Tz, Tt, mu.ptr, logvar.ptr),
-                  e.handle)
+            e.call("vnr_posterior_fwd", x.ptr, mem.ptr, sl.ptr, tl.ptr, B, Tz, Tt, mu.ptr, logvar.ptr)
         return mu, logvar, None
 
     call = __call__
@@ -52,7 +51,7 @@ class TransformerPosterior(EngineModule):
         else:
             eps_d = e.zeros((B, ns, T, C))
         samples = e.empty((B, ns, T, C))
-        check(e.lib.vnr_posterior_reparameterize(e.handle, m.ptr, lv.ptr, eps_d.ptr, B, ns, T, samples.ptr), e.handle)
+        e.call("vnr_posterior_reparameterize", m.ptr, lv.ptr, eps_d.ptr, B, ns, T, samples.ptr)
         return samples, eps_d
 
     # BasePosterior.log_probability (posterior.py:42-72) -----------------------------------------------------------------
@@ -70,9 +69,9 @@ class TransformerPosterior(EngineModule):
         ns = sd.shape[1]
         lens = None if seq_lengths is None else self._i32(seq_lengths)
         out = e.empty((B, ns))
-        check(e.lib.vnr_posterior_log_probability(e.handle, m.ptr, lv.ptr, None if eps is not None else sd.ptr,
+        e.call("vnr_posterior_log_probability", m.ptr, lv.ptr, None if eps is not None else sd.ptr,
                                                   sd.ptr if eps is not None else None, self._ptr(lens), B, ns, T,
-                                                  float(epsilon), out.ptr), e.handle)
+                                                  float(epsilon), out.ptr)
         return out
 
     # TransformerPosterior.sample (posterior.py:132-138) -----------------------------------------------------------------

@@ -42,8 +42,8 @@ class TransformerPrior(EngineModule):
         B, Tz, Tt, zl, cond, tl, eps_d = self._flow_args(targets_lengths, condition_inputs, condition_lengths, temperature, eps)
         z = e.empty((B, Tz, self.channels))
         logp = e.empty((B,)) if return_logprobs else None
-        check(e.lib.vnr_prior_sample(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr,
-                                     self._ptr(logp)), e.handle)
+        e.call("vnr_prior_sample", zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr,
+                                     self._ptr(logp))
         return z, logp
 
     def _flow_args(self, targets_lengths, condition_inputs, condition_lengths, temperature, eps):
@@ -79,7 +79,7 @@ class TransformerPrior(EngineModule):
         B, Tz, Tt, zl, cond, tl, eps_d = self._flow_args(targets_lengths, conditions, condition_lengths, 1.0, eps)
         z = e.empty((B, Tz, self.channels))
         logp = e.empty((B,))
-        check(e.lib.vnr_prior_init(e.handle, zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr, logp.ptr), e.handle)
+        e.call("vnr_prior_init", zl.ptr, cond.ptr, tl.ptr, B, Tz, Tt, self._ptr(eps_d), z.ptr, logp.ptr, record=False)
         return z, logp
 
     def log_probability(self, z, condition_inputs, z_lengths=None, condition_lengths=None, training=None):
@@ -92,5 +92,5 @@ class TransformerPrior(EngineModule):
         zl = self._i32(z_lengths, B, Tz)
         tl = self._i32(condition_lengths, B, Tt)
         out = e.empty((B,))
-        check(e.lib.vnr_prior_log_probability(e.handle, zd.ptr, cond.ptr, zl.ptr, tl.ptr, B, Tz, Tt, out.ptr), e.handle)
+        e.call("vnr_prior_log_probability", zd.ptr, cond.ptr, zl.ptr, tl.ptr, B, Tz, Tt, out.ptr)
         return out

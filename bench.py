@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--global-batch", type=int, default=0,
                     help="training block: GLOBAL batch of the data-parallel step, split evenly over the ranks (strong-scaled reading of BASELINE "
                          "config 5: 32 -> 4 utterances per rank at 8 GPUs); 0 = 32 utterances per rank (weak scaling)")
+    ap.add_argument("--plan", action="store_true",
+                    help="no GPU work: every rank reports how the job is dealt (inference batch and training batch per rank, seeds) over the "
+                         "control plane and rank 0 prints the gathered plan -- what the N-rank run WOULD do, checkable on a CPU box")
     ap.add_argument("--streams", type=int, default=1,
                     help="engine handles (= HIP streams) the K timed steps of `value` are dealt to.  1 (default) = the strictly "
                          "sequential schedule the roofline blocks are measured on; >1 is an experiment switch")
@@ -178,6 +181,36 @@ def load_traffic_record():
 
 
 # ---- one rank -------------------------------------------------------------------------------------------------------------
+def train_batch_per_rank(global_batch, world, default=32):
+    """Utterances per rank of the data-parallel training block: `default` each (weak scaling, BASELINE config 5 read per GPU) unless
+    --global-batch G deals G / world (the strong-scaled reading).  Returns (per-rank batch, error text or None)."""
+    if global_batch and world > 1:
+        if global_batch % world:
+            return 0, "--global-batch %d is not a multiple of the %d ranks" % (global_batch, world)
+        return global_batch // world, None
+    return default, None
+
+
+def run_plan(args):
+    """`--plan`: the dealing logic of an N-rank run without a GPU -- same launcher, same control plane, same arithmetic as run_rank."""
+    import numpy as np
+    from vaenar_tts_amd import dist as vdist
+    rank, local_rank, world = vdist.init()
+    TB, err = train_batch_per_rank(getattr(args, "global_batch", 0), world)
+    mine = np.array([[rank, local_rank, S1["B"], TB, 99 + rank, 7 + rank]], np.int64)   # (rank, device, inference batch, training batch, batch seed, noise seed)
+    vdist.barrier()
+    allr = vdist.gather_to_rank0(mine)
+    slowest = vdist.max_over_ranks(float(rank))
+    if rank == 0:
+        print(json.dumps({"plan": True, "n_gpus": world, "error": err, "max_rank_seen": slowest,
+                          "inference": {"batch_per_rank": S1["B"], "global_batch": S1["B"] * world, "collective": None, "scaling": "weak"},
+                          "training": {"batch_per_rank": TB, "global_batch": TB * world, "collective": "RCCL all-reduce of the flat gradient (4 buckets)"},
+                          "ranks": [{"rank": int(r[0]), "device": int(r[1]), "inference_batch": int(r[2]), "train_batch": int(r[3]),
+                                     "batch_seed": int(r[4]), "noise_seed": int(r[5])} for r in allr]}), flush=True)
+    vdist.barrier()
+    vdist.shutdown()
+
+
 def run_rank(args):
     import numpy as np
     from vaenar_tts_amd import dist as vdist
@@ -695,11 +728,10 @@ def training_block(args, hps, device, rank, world):
             uid = vdist.broadcast_bytes(tm.engine.comm_unique_id() if rank == 0 else None)
             tm.engine.comm_init(world, rank, uid)
             tm.engine.comm_broadcast_weights()
-        TB, trf = 32, 2
-        if getattr(args, "global_batch", 0) and world > 1:
-            if args.global_batch % world:
-                return {"error": "--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world)}
-            TB = args.global_batch // world
+        trf = 2
+        TB, tb_err = train_batch_per_rank(getattr(args, "global_batch", 0), world)
+        if tb_err:
+            return {"error": tb_err}
         tb = make_batch(TB, Tt, Tm, ragged=False, seed=99 + rank)
         r = np.random.Generator(np.random.PCG64(7 + rank))
         t_mels = tm.engine.to_device(r.standard_normal((TB, Tm, hps.Audio.num_mels)).astype(np.float32), np.float32)
@@ -773,7 +805,10 @@ def main(argv=None):
         if rc == 0 and not line:
             rc = 1
         sys.exit(rc)
-    run_rank(args)
+    if args.plan:
+        run_plan(args)
+    else:
+        run_rank(args)
 
 
 if __name__ == "__main__":

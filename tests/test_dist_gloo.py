@@ -91,7 +91,7 @@ def test_shard_bounds_cover_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def _dp_case():
+def _dp_case(databaker=False):
     """Global batch [a, b, a, b]: the two contiguous shards hold the same two utterances, so the per-replica BatchNormalization
     batch statistics (not synchronised) EQUAL the global-batch statistics and the average of the shard
     gradients must equal the global-batch gradient exactly -- for every variable, not just in direction."""
@@ -99,8 +99,15 @@ def _dp_case():
     from vaenar_tts_amd.synthetic import make_batch
     from vaenar_tts_amd.weights import init_weights
     hps = tiny_hps()
+    if databaker:
+        # BASELINE config 5's model (reference configs/hparams.py:351-474): what sets DataBakerHPS apart on the text -> mel path is the
+        # vocabulary (39 symbols, :411) and the mel / text length ratio (4.21, :407: the encoder's positional step); widths as tiny_hps
+        from vaenar_tts_amd.configs import DataBakerHPS
+        hps.Encoder.Transformer.vocab_size = DataBakerHPS.Encoder.Transformer.vocab_size
+        hps.Common.mel_text_len_ratio = DataBakerHPS.Common.mel_text_len_ratio
+        assert hps.Encoder.Transformer.vocab_size == 39 and abs(hps.Common.mel_text_len_ratio - 4.21) < 1e-12
     w = init_weights(hps, seed=5)
-    half = make_batch(2, 7, 16, latent_dim=hps.Common.latent_dim, ragged=True, text_step=2, mel_step=4)
+    half = make_batch(2, 7, 16, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, text_step=2, mel_step=4)
     r = np.random.Generator(np.random.PCG64(1))
     half["mels"] = r.standard_normal((2, 16, hps.Audio.num_mels))
     half["eps"] = r.standard_normal((2, 8, hps.Common.latent_dim))
@@ -123,7 +130,7 @@ def _train_worker(rank, world, port, out_dir):
     tdist.init_process_group("gloo", rank=rank, world_size=world)           # stands in for the device all-reduce (RCCL) below
     uid = dist.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
     assert uid == bytes(range(128))
-    hps, w, batch = _dp_case()
+    hps, w, batch = _dp_case(databaker=bool(os.environ.get("VNR_TEST_DATABAKER")))
     sh = dist.shard_batch(batch, rank, world)
     assert sh["mels"].shape[0] == 2
     o = TorchOracle(hps, w)
@@ -142,12 +149,20 @@ def _train_worker(rank, world, port, out_dir):
     tdist.destroy_process_group()
 
 
-def test_data_parallel_gradient_average_world2(tmp_path):
+@pytest.mark.parametrize("databaker", [False, True], ids=["lj-shaped", "databaker-shaped"])
+def test_data_parallel_gradient_average_world2(tmp_path, databaker, monkeypatch):
+    """Rank shards + the flat-bucket average reproduce the 1-rank gradient of the global batch for every variable; since round 6 also for
+    the DataBakerHPS shape of BASELINE config 5 (vocabulary 39, length ratio 4.21 -- reference datasets/datasets.py:179-192 is the
+    only rank / size vestige of the reference, its train.py has no distribution strategy)."""
     world = 2
+    if databaker:
+        monkeypatch.setenv("VNR_TEST_DATABAKER", "1")
+    else:
+        monkeypatch.delenv("VNR_TEST_DATABAKER", raising=False)
     mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from oracle.vaenar_torch import TorchOracle
-    hps, w, batch = _dp_case()
+    hps, w, batch = _dp_case(databaker)
     o = TorchOracle(hps, w)
     o.update_moving_stats = False
     g, _ = o.gradients(batch["ids"], batch["mels"], batch["mel_lengths"], batch["text_lengths"], 2, batch["eps"], kl_weight=1.0,

@@ -43,7 +43,7 @@ def test_oracle_reproduces_golden(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_path_reproduces_golden(name):
-    """north_star: mels within 1e-3 max-abs, integer frame counts bit-exact.  Asserted at 2e-4."""
+    """north_star: mels within 1e-3 max-abs, integer frame counts bit-exact.  Asserted at 2e-5 (round 6; 2e-4 before)."""
     from vaenar_tts_amd.models import VAENAR
     g = _load(name)
     hps, w = _weights(name, g)
@@ -52,7 +52,7 @@ def test_hip_path_reproduces_golden(name):
         eps = g["eps"] if g["eps"].any() else None
         mel, ali = model.inference(g["ids"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, eps=eps,
                                    temperature=0.0 if eps is None else 1.0)
-        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-4
+        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-5
         for k in ali:
             np.testing.assert_allclose(ali[k].numpy(), g["ali_" + k], atol=1e-5)
         # test_step (inference.py:128-143)
@@ -66,7 +66,7 @@ def test_hip_path_reproduces_golden(name):
         reduced = (pred.astype(np.int32) + 80 + rf - 1) // rf
         z, _ = model.prior.sample(reduced, te, g["text_lengths"], temperature=0.0)
         _, outs, _ = model.decoder(z, te, reduced, g["text_lengths"], reduction_factor=rf)
-        assert np.abs(outs.numpy() - g["ts_mel"]).max() < 2e-4
+        assert np.abs(outs.numpy() - g["ts_mel"]).max() < 2e-5
     finally:
         model.engine.close()
 
@@ -130,12 +130,12 @@ def test_hip_path_matches_reference_python(name):
     model = VAENAR(hps, weights=w)
     try:
         mel, ali = model.inference(g["ids"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, eps=g["eps"])
-        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-4
+        assert np.abs(mel.numpy() - g["mel"]).max() < 2e-5
         for k in ali:
             np.testing.assert_allclose(ali[k].numpy(), g["ali_" + k], atol=1e-5)
         outs, l2, kl, ll, _ = model(g["ids"], g["call_mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2,
                                     training=False, reduce_loss=False, eps=g["call_eps"])
-        assert np.abs(outs.numpy() - g["call_outs"]).max() < 2e-4
+        assert np.abs(outs.numpy() - g["call_outs"]).max() < 2e-5
         np.testing.assert_allclose(l2.numpy(), g["call_l2"], rtol=1e-4)
         np.testing.assert_allclose(ll.numpy(), g["call_length"], rtol=1e-3, atol=1e-7)
         np.testing.assert_allclose(kl.numpy(), g["call_kl"], rtol=1e-3, atol=6e-2)

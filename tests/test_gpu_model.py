@@ -15,7 +15,7 @@ from vaenar_tts_amd.weights import init_weights
 
 pytestmark = pytest.mark.gpu
 
-MEL_TOL = 2e-4          # asserted; contract is 1e-3
+MEL_TOL = 2e-5          # asserted (round 6: was 2e-4 with 3e-6 .. 6e-6 measured -- 40x of slack hid a 1.3e-4 defect in round 5); contract is 1e-3
 CONTRACT_TOL = 1e-3
 
 
@@ -490,3 +490,38 @@ def test_self_attention_block_alone(name):
     ref = ref[0] if isinstance(ref, tuple) else ref
     assert np.abs(y - x).max() > 0.1                                   # the block does something
     assert np.abs(y - ref).max() < 5e-5, np.abs(y - ref).max()
+
+
+def test_s1_elbo_forward_against_float64_oracle():
+    """VERDICT round 5 "next round" #3 (ii): the ELBO forward (VAENAR.call, models.py:105-197) at the bench SIZE (B = 16, T_text = 128,
+    T_mel = 800, rf = 2, ragged) against the float64 oracle at fp32 round-off tolerances -- decoded mels 1e-5 absolute, the three
+    per-utterance losses 1e-5 relative (the KL as the difference of two log-probabilities of order 1e5: relative to those).  The
+    inference twin of this test (above) is what found the round-5 split defect; the posterior, the reparameterisation, both
+    log-probabilities and the L2 terms had no test of this class."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    b = make_batch(16, 128, 800, ragged=True, seed=4321, text_step=3, mel_step=17)
+    r = np.random.Generator(np.random.PCG64(31))
+    B, Tm = 16, 800
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, 1, Tm // 2, hps.Common.latent_dim)).astype(np.float32)
+    oracle = Oracle(hps, w, np.float64)
+    routs, rl2, rkl, rll, rali = oracle.call(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, False, False, eps.astype(np.float64))
+    model = VAENAR(hps, weights=w)
+    try:
+        outs, l2, kl, ll, ali = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=2, training=False,
+                                      reduce_loss=False, eps=eps)
+        aux = model.last_aux.numpy()
+        e_mel = float(np.abs(outs.numpy() - routs).max())
+        e_l2 = float(np.abs(l2.numpy() / rl2 - 1).max())
+        e_ll = float(np.abs(ll.numpy() - rll).max() / max(1e-30, np.abs(rll).max()))
+        lp_scale = np.maximum(np.abs(oracle.last["post_lp"][:, 0]), np.abs(oracle.last["prior_lp"]))
+        e_post = float((np.abs(aux[1] - oracle.last["post_lp"][:, 0]) / lp_scale).max())
+        e_prior = float((np.abs(aux[2] - oracle.last["prior_lp"]) / lp_scale).max())
+        e_kl = float((np.abs(kl.numpy() - rkl) / lp_scale).max())
+        e_ali = max(float(np.abs(ali[k].numpy() - rali[k]).max()) for k in rali)
+        print(f"S1 ELBO forward vs float64: mel {e_mel:.2e}, l2 rel {e_l2:.2e}, length rel {e_ll:.2e}, posterior lp rel {e_post:.2e}, "
+              f"prior lp rel {e_prior:.2e}, kl (relative to the log-probs, {lp_scale.max():.3g}) {e_kl:.2e}, alignments {e_ali:.2e}")
+        assert e_mel < 1e-5 and e_l2 < 1e-5 and e_ll < 1e-5 and e_post < 1e-5 and e_prior < 1e-5 and e_kl < 1e-5 and e_ali < 1e-5
+    finally:
+        model.engine.close()

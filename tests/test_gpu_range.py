@@ -21,7 +21,7 @@ from vaenar_tts_amd.synthetic import make_batch
 from vaenar_tts_amd.weights import init_weights
 
 pytestmark = pytest.mark.gpu
-MEL_TOL = 2e-4          # asserted; the contract is 1e-3 (north star)
+MEL_TOL = 2e-5          # asserted (round 6: was 2e-4); the contract is 1e-3 (north star)
 
 
 def _hps(name):

@@ -171,7 +171,7 @@ def test_inference_harness_lj_single_utterance(tmp_path):
         pred = orc.last["pred_float"]
         assert np.abs(pred - np.round(pred)).min() > 1e-3        # the truncation is not decided by rounding noise
         assert got.shape == (int(pl80[0]), hps.Audio.num_mels) and got.dtype == np.float32
-        assert np.abs(got - mel[0, :got.shape[0]]).max() < 2e-4
+        assert np.abs(got - mel[0, :got.shape[0]]).max() < 2e-5
 
 
 # ---- BASELINE config 3's harness: train.py end to end (init step, schedules, dev pass, checkpoints, resume), deterministic by default ---------
@@ -234,7 +234,7 @@ def test_databaker_inference_and_train_step():
         assert abs(model.mel_text_len_ratio - 4.21) < 1e-9
         mel, ali = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], eps=b["eps"])
         ref, rali = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, b["eps"])
-        assert np.abs(mel.numpy() - ref).max() < 2e-4
+        assert np.abs(mel.numpy() - ref).max() < 2e-5
         for k in rali:
             assert np.abs(ali[k].numpy() - rali[k]).max() < 1e-4
         loss, mel_l2, kl, len_l2 = model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, eps=eps, dropout_seed=4,
@@ -302,7 +302,7 @@ def test_t1_full_size_train_step_properties(rf):
         n0 = model.engine.launch_count()
         sc = model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1e-5, rf, eps=eps, dropout_seed=9, apply_update=False)
         launches = model.engine.launch_count() - n0
-        g = model.gradients(probe)
+        g = model.gradients()                                   # every trainable variable (round 6: was 8 probes)
         assert all(np.isfinite(x) for x in sc) and launches < 3000
         # dropout OFF for the equivariance checks (the masks are indexed by row position): per-utterance ELBO terms, dev_step mode
         _, l2, kl, ll, _ = model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=rf, training=False, reduce_loss=False,
@@ -329,6 +329,22 @@ def test_t1_full_size_train_step_properties(rf):
     for k in probe:
         tol = 3e-2 if ref[k].size == 1 else 5e-3
         assert np.abs(g[k] - ref[k]).max() <= tol * np.abs(ref[k]).max() + 1e-7, (k, float(np.abs(g[k] - ref[k]).max()), float(np.abs(ref[k]).max()))
+    # ALL variables, by relative 2-norm per tensor (VERDICT round 5 "next round" #3 (ii)): a unit on its ReLU kink moves single entries, not a
+    # tensor's norm -- a wrong kernel, a missing term or a split defect moves the norm.  The reference is the fp32 restatement (its own
+    # round-off and kink flips are in the budget): 1e-3 for tensors, 3e-2 for scalar variables (one signed sum with cancellation, as above)
+    assert set(g) == set(ref), sorted(set(g) ^ set(ref))[:5]
+    rows = []
+    for k in sorted(g):
+        a, r_ = np.asarray(g[k], np.float64).ravel(), np.asarray(ref[k], np.float64).ravel()
+        nr = float(np.linalg.norm(r_))
+        rows.append((float(np.linalg.norm(a - r_)) / nr if nr > 0 else float(np.linalg.norm(a)), a.size, k))
+    rows.sort(reverse=True)
+    print("T1 rf=%d: %d gradient tensors; worst relative 2-norm errors against the fp32 autograd restatement:" % (rf, len(rows)))
+    for e, n, k in rows[:8]:
+        print("   %.3e  (%d elements)  %s" % (e, n, k))
+    print("   median %.3e" % float(np.median([e for e, _, _ in rows])))
+    bad = [(e, n, k) for e, n, k in rows if e > (3e-2 if n == 1 else 1e-3)]
+    assert not bad, bad[:10]
 
 
 # ---- integer frame counts: population test (inference.py:135-137, length_predictor.py:35-42) ---------------------------------
@@ -402,7 +418,7 @@ def test_n_sample_2_matches_reference_python():
         assert model.n_sample == 2
         outs, l2, kl, ll, ali = model(g["ids"], g["mels"], g["mel_lengths"], g["text_lengths"], reduction_factor=2, training=False,
                                       reduce_loss=False, eps=g["eps"])
-        assert outs.shape == g["outs"].shape and np.abs(outs.numpy() - g["outs"]).max() < 2e-4
+        assert outs.shape == g["outs"].shape and np.abs(outs.numpy() - g["outs"]).max() < 2e-5
         np.testing.assert_allclose(l2.numpy(), g["l2"], rtol=1e-4)
         np.testing.assert_allclose(ll.numpy(), g["length"], rtol=1e-3, atol=1e-7)
         np.testing.assert_allclose(kl.numpy(), g["kl"], rtol=1e-3, atol=6e-2)
@@ -441,7 +457,7 @@ def test_blocks_without_alignments_fused_and_unfused(B, Tt, Tm, text_step):
                 mels[fuse] = mel.numpy()
                 launches[fuse] = model.engine.launch_count() - n0
             assert not ali
-            assert np.abs(mels[fuse] - rmel).max() < 2e-4
+            assert np.abs(mels[fuse] - rmel).max() < 2e-5
         # (the fused launches run on the 4-wave chain kernel with panels that start at utterance boundaries, the three-launch form's chain C
         #  + coupling tail does not fit that kernel's LDS budget and runs on the 8-wave kernel: another accumulation order of the same
         #  split products)

@@ -355,8 +355,9 @@ int vnr_set_option(vnr_handle h, const char *name, int value);
  *     word behind its backward pass, takes the max over the ranks of the communicator, predicates Adam (and every BatchNormalization
  *     moving update) on it, and when it is raised repeats the step on exact fp32 MFMA with scaled attention cores and fp32
  *     kernel-gradient GEMMs -- the handle's later steps stay there ("train_fp32" = 1; the option resets it).  On that path the products
- *     carry no sentinel; one pass over the flat gradient looks for non-finite values instead (the attention BACKWARD kernels still split
- *     Q, K, V unscaled: operands beyond 65504 there end in VNR_ERR_RANGE with the variables untouched, never in a silent update).
+ *     carry no sentinel (the attention backward runs on the plain fp32 kernels of round 1 there: nothing is split); one pass over the
+ *     flat gradient looks for non-finite values instead -- inputs or variables that hold NaN / inf end in VNR_ERR_RANGE with the
+ *     variables untouched, never in a silent update.
  * Below the window nothing is detected at run time: a tensor that sinks under 2^-6 on a later call keeps 2^-25 of ABSOLUTE resolution
  * (fp16 subnormals) -- graceful, not wrong by orders of magnitude; set "range_guard" again for a fresh survey.
  *

@@ -202,3 +202,18 @@ def test_control_plane_world3_with_a_foreign_listener_and_late_rank0():
     finally:
         if squat is not None:
             squat.close()
+
+
+def test_rank0_bind_address_choice(monkeypatch):
+    """rank 0 binds MASTER_ADDR's interface only when that is an address of this host the other ranks can reach; a name
+    that resolves to a loopback alias (Debian's 127.0.1.1) or to nothing local falls back to every interface; VNR_CTL_BIND overrides."""
+    sys.path.insert(0, ROOT)
+    from vaenar_tts_amd import dist
+    monkeypatch.delenv("VNR_CTL_BIND", raising=False)
+    assert dist._bind_address("127.0.0.1") == "127.0.0.1" and dist._bind_address("localhost") == "127.0.0.1"
+    assert dist._bind_address("no-such-host.invalid") == ""
+    assert dist._bind_address("10.255.255.1") == ""                  # not an address of a local interface
+    monkeypatch.setattr(socket, "getaddrinfo", lambda *a, **k: [(socket.AF_INET, socket.SOCK_STREAM, 6, "", ("127.0.1.1", 0))])
+    assert dist._bind_address("node0") == ""                          # the loopback alias of a real host name
+    monkeypatch.setenv("VNR_CTL_BIND", "192.0.2.7")
+    assert dist._bind_address("node0") == "192.0.2.7"

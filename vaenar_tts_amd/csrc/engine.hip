@@ -369,6 +369,13 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
   // (measured: the 4-wave kernel's k-loops wait on first-touch L2 misses, -13 % with the prefetchers; the 8-wave kernel's do not, +-0 %;
   //  64-row panels = several batches in flight: the idle CUs belong to them)
   g.pf_progress = (h->chain_prefetch && g.waves4 && !h->chain_rows64) ? h->chain_progress : nullptr;
+  // the pacing words hold launch epoch x 32 + stage and only ever grow (atomic max, never reset): before epoch x 32 wraps the 32-bit word
+  // -- 2^27 chain launches, a few hours of back-to-back inference -- the words are cleared in stream order and the count starts over
+  // (after the wrap every prefetcher would have seen "a later launch owns the word" and left, for the rest of the process)
+  if (h->chain_epoch >= (1u << 27) - 2u) {
+    if (h->chain_progress) HIP_TRY(h, hipMemsetAsync(h->chain_progress, 0, 1024, h->stream));
+    h->chain_epoch = 0;
+  }
   g.pf_epoch = ++h->chain_epoch;
   g.range_flag = (h->range_sentinel && h->range_flag) ? h->range_flag : h->d_step_flag + 4;      // (never null: common.h range_note; an unwatched launch raises a scrap word)
   // bytes of a launch that also writes alignments: the attention core's own traffic as SURVEY D3 counts it (Q + K, V + context +
@@ -585,7 +592,7 @@ int get_pe(vnr_handle h, int T, int dim, float step, const float** out) {
 
 // self-attention Q|K|V as attention operand images (three images of img_bytes each instead of the fp32 [M, 3D] panel)
 bool self_aoi_on(vnr_handle h, int D, int heads) {
-  return h->aoi_enabled && h->aoi_self && !h->split_suspended && D > 0 && D == heads * 64;
+  return h->aoi_enabled && h->aoi_self && split_active(h) && D > 0 && D == heads * 64;      // (the exact mode's cores take fp32 operands and scale them: run_attention)
 }
 long long aoi_img_bytes(int B, int T, int D) { return (long long)B * (D / 64) * ((T + 31) / 32) * kAoiTile; }
 size_t qkv_floats(bool aoi, int B, int T, int D) { return aoi ? (size_t)(3 * aoi_img_bytes(B, T, D) / 4) : (size_t)B * T * 3 * D; }
@@ -934,7 +941,7 @@ int refresh_bn_affine(vnr_handle h) {
 int run_kv(vnr_handle h, const float* text_embd, int B, int Tt, int mem, const float* panel, int n, float* out, int D) {
   GemmArgs g;
   g.A1 = text_embd; g.lda1 = mem; g.K1 = mem; g.K = mem; g.Wt = panel; g.ldw = mem; g.C = out; g.ldc = n; g.M = B * Tt; g.N = n;
-  if (h->aoi_enabled && !h->split_suspended && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g)) {
+  if (h->aoi_enabled && split_active(h) && D > 0 && !(D & 63) && Tt <= 128 && n % (2 * D) == 0 && gemm2_supported(g)) {
     const int nblk = n / (2 * D), TT = (Tt + 31) / 32;
     const size_t blk_bytes = (size_t)B * (D / 64) * TT * kAoiTile;
     WS(img, 2 * nblk * blk_bytes / 4);
@@ -2308,8 +2315,8 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
     h->range_trips++;
     if (apply_update) train_step_rollback(h);
     if (h->train_fp32) {
-      rc = fail(h, VNR_ERR_RANGE, "vnr_train_step: non-finite gradients on the exact-fp32 path as well (inputs or variables hold NaN / inf, or the "
-                                  "attention backward's operands left the fp16 range): the variables were NOT updated");
+      rc = fail(h, VNR_ERR_RANGE, "vnr_train_step: non-finite gradients on the exact-fp32 path as well (inputs or variables hold NaN / inf): the "
+                                  "variables were NOT updated");
       break;
     }
     h->train_fp32 = true;

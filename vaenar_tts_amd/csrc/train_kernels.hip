@@ -1560,7 +1560,7 @@ hipError_t launch_attention_bwd(const float* Q, int ldq, const float* K, int ldk
   a.scale = 0.125f / temperature;
   static const bool v1 = getenv("VNR_ATTN_BWD_V1") != nullptr;       // A/B switch: plain-FMA fp32 kernels
   const bool aligned = !(lddq & 3) && !(lddk & 3) && !(lddv & 3);
-  if (v1 || !amax_slot || !aligned) {
+  if (v1 || g_train_exact || !amax_slot || !aligned) {      // (g_train_exact: the step's exact-fp32 fallback -- these kernels split nothing)
     vnr_launch(attn_bwd_dq_kernel, dim3((Tq + 31) / 32, H, B), dim3(256), 0, s, a);
     vnr_launch(attn_bwd_dkv_kernel, dim3((Tk + 63) / 64, H, B), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -70,6 +70,35 @@ def _exchange_timeout():
         return 1800.0
 
 
+def _bind_address(addr):
+    """The interface rank 0 listens on.  MASTER_ADDR's own interface when the name resolves to an address of THIS host that the other
+    ranks can reach (loopback only when the job itself is on loopback); every interface otherwise -- a name that /etc/hosts maps to
+    127.0.1.1 on node 0 (Debian's default), a virtual / NAT address that is not on a local interface: binding those would lock the
+    remote ranks out.  The handshake's job key authenticates peers either way.  VNR_CTL_BIND overrides ("" = all)."""
+    forced = os.environ.get("VNR_CTL_BIND")
+    if forced is not None:
+        return forced
+    if addr in ("localhost", "127.0.0.1"):
+        return "127.0.0.1"
+    try:
+        infos = socket.getaddrinfo(addr, None, socket.AF_INET, socket.SOCK_STREAM)
+    except OSError:
+        return ""
+    for info in infos:
+        ip = info[4][0]
+        if ip.startswith("127."):
+            continue                      # a loopback alias of a real host name: the other nodes cannot reach it
+        probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        try:
+            probe.bind((ip, 0))           # succeeds only for an address of a local interface
+            return ip
+        except OSError:
+            pass
+        finally:
+            probe.close()
+    return ""
+
+
 def init(backend=None, timeout=300.0):
     """Join the control plane.  Returns (rank, local_rank, world).  `backend` is accepted for the callers' old signature."""
     rank, local_rank, world = env_rank()
@@ -83,18 +112,20 @@ def init(backend=None, timeout=300.0):
     _state.update(rank=rank, world=world)
     if rank == 0:
         srv = None
+        bind_addr, last_err = _bind_address(addr), None
         for p in range(base, base + _CANDIDATES):
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind((addr if addr != "localhost" else "127.0.0.1", p))      # MASTER_ADDR's interface only, never every interface
+                s.bind((bind_addr, p))
                 s.listen(world + 8)
                 srv = s
                 break
-            except OSError:
+            except OSError as e:
+                last_err = e
                 s.close()
         if srv is None:
-            raise RuntimeError("control plane: no free port in [%d, %d)" % (base, base + _CANDIDATES))
+            raise RuntimeError("control plane: could not listen on %r, ports [%d, %d): %s" % (bind_addr or "*", base, base + _CANDIDATES, last_err))
         peers = {}
         srv.settimeout(1.0)
         while len(peers) < world - 1:

@@ -415,6 +415,29 @@ def run_rank(args):
                                                              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS}
             finally:
                 eng.set_option("fuse_xattn", 1)
+            # (round 6) the MEASURED floor of that kernel's decomposition: the same grid, loads and store addresses with the arithmetic taken
+            # out (traffic only) and with the global stores taken out (arithmetic only) -- tools/xattn_floor.py, one child process per build
+            # of the kernel (csrc/attention3.hip: SKEL).  floor_us = the slower of the two halves; frac_of_floor = floor / the shipped kernel.
+            if not args.no_attn_phase:
+                try:
+                    import subprocess
+                    res = {}
+                    for mode in (0, 1, 2):
+                        env = dict(os.environ, VNR_ATTN3_SKEL=str(mode))
+                        cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "xattn_floor.py")],
+                                            capture_output=True, text=True, timeout=300, env=env)
+                        res[mode] = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])["avg_launch_us"]
+                    floor = max(res[1], res[2])
+                    byt = 4.0 * (2.0 * B * (Tm // rf) * 256 + 2.0 * B * Tt * 256) + ali_bytes
+                    rca["floor"] = {"shipped_kernel_us": res[0], "traffic_only_us": res[1], "arithmetic_no_stores_us": res[2], "floor_us": floor,
+                                    "frac_of_floor": floor / res[0] if res[0] > 0 else None,
+                                    "hbm_frac_of_the_traffic_only_skeleton": byt / (res[1] * 1e-6) / 1e9 / PEAK_HBM_GBPS if res[1] > 0 else None,
+                                    "hbm_frac_at_the_floor": byt / (floor * 1e-6) / 1e9 / PEAK_HBM_GBPS if floor > 0 else None,
+                                    "definition": "attn3_kernel<true> (stand-alone decoder cross-attention with alignments, SURVEY D3's 30.41 MB per launch) rebuilt "
+                                                  "with its arithmetic removed (traffic only: same grid, loads and store addresses) and with its global stores "
+                                                  "removed (arithmetic only); dispatch-event durations in child processes; floor = the slower half"}
+                except Exception as e:
+                    rca["floor"] = {"error": repr(e)}
         if a["launches"]:
             gbps = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             out["roofline_cross_attention"] = {

@@ -53,7 +53,11 @@ constexpr int kXchg = 8192;                         // bytes of exchange space p
 // instead of all 19.7 MB leaving at the same moment at the end of 832 simultaneous one-tile workgroups.
 // LDS hazards across iterations: the exchange space is only written after barrier 1 of an iteration, which every wave reaches
 // after its merge reads of the previous iteration -- no extra barrier, no double buffer.
-template <bool ALI>
+// SKEL (measurement only, VNR_ATTN3_SKEL; bench.py: roofline_cross_attention.floor): the two halves of the kernel apart, on the SAME grid, the
+// same loads and the same store addresses -- 1 = traffic only (operand images read, alignments and context written; no MFMA, no
+// softmax, no LDS transposes: what the memory system alone needs for this access pattern), 2 = all the arithmetic and LDS traffic
+// but no global store.  The slower of the two is the floor of THIS decomposition; results are meaningless in both.
+template <bool ALI, int SKEL = 0>
 __global__ void __launch_bounds__(256, 2)
 attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,7 +160,15 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    if (active) {
+    if (SKEL == 1) {                                  // every loaded register is consumed (no load may be optimised away), nothing else happens
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float u = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) u += (float)khi[t][r & 7] + (float)klo[t][r & 7] + (float)qhi[t][r & 7] + (float)qlo[t][r & 7];
+        st[r] = u;
+      }
+    } else if (active) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) st = mfma3x(khi[t], klo[t], qhi[t], qlo[t], st);
     }
@@ -165,7 +177,8 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
 
     // ---- logits (log2 domain) and masks ----------------------------------------------------------------------------------
     const int iq = q0 + l31;
-    if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen) {          // wave-uniform: nothing masked in this block
+    if (SKEL == 1) {
+    } else if (!partial && kb0 + 32 <= klen && q0 + 32 <= qlen) {          // wave-uniform: nothing masked in this block
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] *= c;
     } else {
@@ -179,16 +192,18 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
         st[r] = s;
       }
     }
-    float mt = -INFINITY;
+    float mt = -INFINITY, m_w = 0.f, ls = 1.f;
+    if (SKEL != 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_w = fmaxf(mt, -3.0e38f);                            // finite floor: a wave without keys gives p = 0, not NaN
-    float ls = 0.f;
+    m_w = fmaxf(mt, -3.0e38f);                            // finite floor: a wave without keys gives p = 0, not NaN
+    ls = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const float p = __builtin_amdgcn_exp2f(st[r] - m_w); st[r] = p; ls += p; }
     ls += __shfl_xor(ls, 32, 64);
     if (half == 0) { stats[wave * 64 + l31] = m_w; stats[wave * 64 + 32 + l31] = ls; }
+    }
 
     // ---- O^T partial = V^T.P^T over this wave's 32 keys, from the UNNORMALISED p (relative to this wave's maximum): issued
     //      before the statistics barrier so that the exchange latency hides under the MFMAs.  Transposed accumulation (as in
@@ -198,7 +213,12 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[nb][r] = 0.f;
-    if (active) {
+    if (SKEL == 1) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[nb][r] = (float)vhi[r >> 3][nb][r & 7] + (float)vlo[r >> 3][nb][r & 7];
+    } else if (active) {
 #pragma unroll
       for (int tp = 0; tp < 2; ++tp) {
         float pv[8];
@@ -218,8 +238,8 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     stamp(sb + 1);
     if (more) { __builtin_amdgcn_s_waitcnt(0x0F70); park_q(); }
     stamp(sb + 2);
-    float f;
-    {
+    float f = 1.f;
+    if (SKEL != 1) {
       float mw[4], lw[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) { mw[w] = stats[w * 64 + l31]; lw[w] = stats[w * 64 + 32 + l31]; }
@@ -233,17 +253,21 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     if (ALI && active) {
       // alignment rows: normalise, 32x32 transpose through LDS (chunk = 4 keys, XOR-swizzled by row), 128-byte row pieces out
       float* xw = reinterpret_cast<float*>(xb);
+      if (SKEL != 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 p4 = {st[4 * j] * f, st[4 * j + 1] * f, st[4 * j + 2] * f, st[4 * j + 3] * f};
         *reinterpret_cast<f32x4*>(xw + l31 * 32 + (((2 * j + half) ^ (l31 & 7)) << 2)) = p4;
       }
+      }
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const int rr = 8 * x + (lane >> 3), kc = lane & 7;
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
+        f32x4 v4;
+        if (SKEL == 1) v4 = f32x4{st[4 * x], st[4 * x + 1], st[4 * x + 2], st[4 * x + 3]};
+        else v4 = *reinterpret_cast<const f32x4*>(xw + rr * 32 + ((kc ^ (rr & 7)) << 2));
         const int qrow = q0 + rr, key = kb0 + 4 * kc;
-        if (qrow < a.Tq) {
+        if (qrow < a.Tq && (SKEL != 2 || a.Tq < 0)) {
           float* dst = a.ali + (((size_t)b * a.H + hd) * a.Tq + qrow) * a.Tk + key;
           if (key + 3 < a.Tk && !(a.Tk & 3)) __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dst));
           else
@@ -254,6 +278,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     }
     stamp(sb + 3);
     // ---- sum the four partial tiles: rows [query l31][16-byte chunk = nb*8 + 2j + half, XOR-swizzled by row], already scaled ---
+    if (SKEL != 1) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -261,6 +286,7 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
         const f32x4 o4 = {O[nb][4 * jj] * f, O[nb][4 * jj + 1] * f, O[nb][4 * jj + 2] * f, O[nb][4 * jj + 3] * f};
         *reinterpret_cast<f32x4*>(xb + l31 * 256 + (((nb * 8 + 2 * jj + half) ^ (l31 & 15)) << 4)) = o4;
       }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -269,10 +295,12 @@ attn3_kernel(const Attn3Args a, int nqt, int nchunk) {
     for (int u = 0; u < 2; ++u) {
       const int rr = 8 * wave + 4 * u + (lane >> 4), ch = lane & 15;   // query row of the tile, 16-byte chunk (4 channels)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (SKEL == 1) acc = f32x4{O[u][0], O[u][1], O[u][2], O[u][3]};
+      else
 #pragma unroll
       for (int w = 0; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * kXchg + rr * 256 + ((ch ^ (rr & 15)) << 4));
       const int row = q0 + rr;
-      if (row < a.Tq) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
+      if (row < a.Tq && (SKEL != 2 || a.Tq < 0)) __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(a.ctx + (size_t)b * a.o_bs + (size_t)row * a.ldo + hd * 64 + 4 * ch));
     }
     stamp(sb + 5);
   }
@@ -501,7 +529,10 @@ hipError_t launch_attention3(const Attn3Args& a, hipStream_t s) {
     if (f) { int hdr[4] = {a.B * a.H, a.Tq, nchunk, (int)grid1.x}; fwrite(hdr, 4, 4, f); fwrite(hbuf.data(), 8, n, f); fclose(f); }
     return hipGetLastError();
   }
-  if (a.ali) vnr_launch(attn3_kernel<true>, grid1, dim3(256), lds, s, a, nqt, nchunk);
+  static const int skel = getenv("VNR_ATTN3_SKEL") ? atoi(getenv("VNR_ATTN3_SKEL")) : 0;      // measurement only (see attn3_kernel): WRONG results
+  if (a.ali && skel == 1) vnr_launch(attn3_kernel<true, 1>, grid1, dim3(256), lds, s, a, nqt, nchunk);
+  else if (a.ali && skel == 2) vnr_launch(attn3_kernel<true, 2>, grid1, dim3(256), lds, s, a, nqt, nchunk);
+  else if (a.ali) vnr_launch(attn3_kernel<true>, grid1, dim3(256), lds, s, a, nqt, nchunk);
   else if (!force_general && a.Tk <= 128 && !a.causal) vnr_launch(attn3_kernel<false>, grid1, dim3(256), lds, s, a, nqt, nchunk);
   else vnr_launch(attn3g_kernel, grid, dim3(256), lds, s, a, nqt);
   return hipGetLastError();

@@ -465,6 +465,8 @@ hipError_t launch_absmax2d(const float* x, int ld, int rows, int cols, unsigned*
 hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s);
 hipError_t launch_row_range_batched(const float* x, long long ld, int T, long long bs, int B, int cols, unsigned* out, hipStream_t s);
 hipError_t launch_finite_check(const float* x, size_t n, unsigned* flag, hipStream_t s);
+struct CopyJob { const float* src; float* dst; long long n; };
+hipError_t launch_copy_batch(const CopyJob* jobs, int njobs, hipStream_t s);      // jobs: device table
 #if defined(__HIPCC__)
 // Publish a candidate maximum (bits of a non-negative float; the word is zero on entry and only grows).  Same-address atomics serialise at
 // ~15-20 ns each: one per wave was 1024-4096 per attention-backward launch, 6-25 us of a 40-90 us kernel (profiles/r03_experiments.txt).

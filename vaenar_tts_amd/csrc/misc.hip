@@ -932,6 +932,12 @@ __global__ void __launch_bounds__(256) row_range_kernel(const float* x, long lon
     if (b != 0u && b < __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out + 1, b);
   }
 }
+// a table of small device-to-device copies in ONE launch (engine.hip: the BatchNormalization moving statistics are saved in front of a
+// call that may have to repeat itself, and put back before the repeat)
+__global__ void __launch_bounds__(256) copy_batch_kernel(const CopyJob* jobs) {
+  const CopyJob j = jobs[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < j.n; i += (long long)gridDim.x * blockDim.x) j.dst[i] = j.src[i];
+}
 // true (word 0 of flag set) when any element of x[0, n) is NaN or infinite: the training step's last look at the flat gradient on the
 // exact-fp32 fallback, whose products carry no sentinel of their own (engine.hip, "range sentinel")
 __global__ void __launch_bounds__(256) finite_check_kernel(const float* x, size_t n, unsigned* flag) {
@@ -954,6 +960,11 @@ hipError_t launch_row_range_batched(const float* x, long long ld, int T, long lo
   const long long rows = (long long)T * B;
   if (rows > 0x7fffffffLL) return hipErrorInvalidValue;
   vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, (int)rows, cols, out, T, bs);
+  return hipGetLastError();
+}
+hipError_t launch_copy_batch(const CopyJob* jobs, int njobs, hipStream_t s) {
+  if (njobs <= 0) return hipSuccess;
+  vnr_launch(copy_batch_kernel, dim3(4, njobs), dim3(256), 0, s, jobs);
   return hipGetLastError();
 }
 hipError_t launch_finite_check(const float* x, size_t n, unsigned* flag, hipStream_t s) {

@@ -6,7 +6,7 @@ data = open(sys.argv[1], "rb").read(); off = 0; seen = {}
 while off < len(data):
     M, Dw, ns, nw = struct.unpack_from("4i", data, off); off += 16
     ts = np.frombuffer(data, dtype=np.uint64, count=nw * 128, offset=off).reshape(nw, 128).astype(np.int64); off += nw * 1024
-    seen[(M, Dw, ns)] = ts[ts[:, 63] < 1000]               # (rows of prefetch workgroups carry 1000 + rank in slot 63: tools/r05_ts_xcd.py reads them)
+    seen[(M, Dw, ns)] = ts[ts[:, 63] < 1000]               # (rows of prefetch workgroups carry 1000 + rank in slot 63: tools/archive/r05_ts_xcd.py reads them)
 for (M, Dw, ns), ts in seen.items():
     D, ali, att = Dw & 0xffff, (Dw >> 16) & 1, Dw >> 20        # (round 5: the header's D word carries the fused-attention flags)
     print("M=%d D=%d stages=%d wgs=%d%s   lifetime median %.1f kcyc" % (M, D, ns, len(ts), (" attention in front of stage %d%s" % (att, " + alignments" if ali else "")) if att else "",

@@ -7,7 +7,7 @@ import sys
 
 src = open(sys.argv[1]).read().split('\n\n')
 digest = sys.argv[2] if len(sys.argv) > 2 else "?"
-out = ["# SQ counters of the S1 inference step per kernel (tools/collect_profiles_r05.sh: three separate `rocprofv3 --kernel-trace --pmc ...`",
+out = ["# SQ counters of the S1 inference step per kernel (tools/collect_profiles_r06.sh: three separate `rocprofv3 --kernel-trace --pmc ...`",
        "# passes of tools/s1_once.py, averages per dispatch; weight-preparation kernels of vnr_finalize_weights left out).  Kernel sources %s." % digest,
        "# panel_chain4_kernel (panel_chain_kernel<1> before the 4-wave kernel became the default): 15 launches per step (13 block launches with everything of a block behind its self-attention, the coupling and",
        "# the next pre-chain, + the first pre-chain): see the ratios at the end."]

@@ -145,7 +145,7 @@ def load():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     # The setting only counts if the HIP runtime has not initialised yet.  A profiler's preloaded library (rocprofv3 --pmc ...) or another
     # HIP user in the process initialises it BEFORE this line runs: the collection scripts therefore export the variable themselves
-    # (tools/collect_profiles_r05.sh), and this is said out loud instead of letting a profiled run use another queue mapping silently.
+    # (tools/collect_profiles_r06.sh), and this is said out loud instead of letting a profiled run use another queue mapping silently.
     early = [m for m in ("torch",) if m in sys.modules and getattr(sys.modules[m], "cuda", None) is not None
              and sys.modules[m].cuda.is_initialized()]
     if os.environ.get("LD_PRELOAD", "").find("rocprof") >= 0 or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_LIBRARY_CTOR"):

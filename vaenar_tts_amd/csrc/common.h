@@ -70,11 +70,13 @@ inline void vnr_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned
 // of that stream (the finish kernel of launch i precedes the producer of launch i + 1 in stream order).
 struct DetState {
   std::map<hipStream_t, std::pair<void*, size_t>> bufs;
+  std::map<hipStream_t, unsigned*> tickets;                // per stream: [2][kDetTickets] arrival / departure counters of the in-kernel ordered finish (gemm_tn3_kernel), all zero between launches
   std::vector<void*> retired;                              // outgrown buffers: possibly still read by kernels in flight; freed once the step has synchronised
   bool alloc_failed = false;                               // a scratch allocation failed: the launcher fell back to float atomics -- the step reports it
   void release_retired() { for (void* p : retired) (void)hipFree(p); retired.clear(); }
-  void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); release_retired(); bufs.clear(); }
+  void release() { for (auto& kv : bufs) (void)hipFree(kv.second.first); for (auto& kv : tickets) (void)hipFree(kv.second); release_retired(); bufs.clear(); tickets.clear(); }
 };
+constexpr int kDetTickets = 1024;
 inline thread_local DetState* g_det = nullptr;
 // the training step on its exact-fp32 fallback (engine.hip: vnr_context::train_fp32): the kernel-gradient GEMMs take the fp32 MFMA kernel
 inline thread_local bool g_train_exact = false;
@@ -89,6 +91,16 @@ inline void* det_scratch(hipStream_t s, size_t bytes) {
     b = {p, cap};
   }
   return b.first;
+}
+// the counters of the in-kernel ordered finish for launches on stream s (zeroed once; every launch leaves them at zero), or null
+inline unsigned* det_tickets(hipStream_t s) {
+  if (!g_det) return nullptr;
+  auto it = g_det->tickets.find(s);
+  if (it != g_det->tickets.end()) return it->second;
+  unsigned* p = nullptr;
+  if (hipMalloc((void**)&p, 2 * kDetTickets * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 2 * kDetTickets * sizeof(unsigned)) != hipSuccess) return nullptr;
+  g_det->tickets[s] = p;
+  return p;
 }
 // out[i] += sum_{p < nparts} part[p * n + i], partials added in index order (i < n)
 hipError_t launch_det_finish_dd(const double* part, int nparts, size_t n, double* out, hipStream_t s);

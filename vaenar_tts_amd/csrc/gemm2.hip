@@ -55,8 +55,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // 64x64 tiles every multiplier wave paid four of them per k-tile beside 192 cycles of MFMA, and with one wave per SIMD nothing ran
 // meanwhile.  A loader wave shares its SIMD with one multiplier wave and takes those stalls (and the conv tap walker's address
 // arithmetic) off the matrix pipe's critical path.
+// (round 6) the loader-wave variants ask for FOUR waves per SIMD, i.e. two co-resident 8-wave workgroups per CU: with fp32 activations
+// (SPLIT = 1) the kernel took 140 registers -- occupancy 3 -- so a launch of 384 or 512 workgroups (the encoder's Q|K|V and FFN dense1
+// products) ran as two rounds of 9 us on 256 CUs although its 64 KB rings fit twice into a CU's LDS
 template <int BM, int BN, int WM, int WN, int NSTAGE, int MODE, bool LN, int SPLIT, int LW = 0>
-__global__ void __launch_bounds__((WM * WN + LW) * 64)
+__global__ void __launch_bounds__((WM * WN + LW) * 64, (LW > 0 && NSTAGE <= 4) ? 4 : 1)
 gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int NW = WM * WN;
   constexpr int DW = LW ? LW : NW;                                   // waves that issue the DMA
@@ -217,28 +220,33 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
   // spilled, and their one exposed latency is small beside 40 k-tiles)
   constexpr bool PRM_LATE = MI * NI >= 4;
   float4 p_bias[NI][4], p_sc[NI][4], p_sh[NI][4];     // per-lane column groups: col = .. + j*32 + 8q + 4*half
-  auto load_params = [&]() {
+  // (round 6) the loader-wave variants fetch the folded BatchNorm scale / shift AFTER the loop: 32 registers less through the k-loop,
+  // which is what lets two of their 8-wave workgroups share a CU (4 waves per SIMD = 128 registers); only the three prenet
+  // convolutions pay the one exposed latency
+  constexpr bool AFFINE_LATE = LW > 0 && !LN;
+  auto load_params = [&](bool want_bias, bool want_affine) {
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int col = (LN ? 0 : n0) + wn * TN + j * 32 + 8 * q + 4 * half;
-        p_bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        p_sc[j][q] = make_float4(1.f, 1.f, 1.f, 1.f);
-        p_sh[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (want_bias) p_bias[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (want_affine) { p_sc[j][q] = make_float4(1.f, 1.f, 1.f, 1.f); p_sh[j][q] = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (vec_ok && col < g.N && !is_loader) {
-          if (g.bias) p_bias[j][q] = *reinterpret_cast<const float4*>(g.bias + col);
-          if (LN) {
-            p_sc[j][q] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
-            p_sh[j][q] = *reinterpret_cast<const float4*>(g.ln_beta + col);
-          } else if (g.bn_scale) {
-            p_sc[j][q] = *reinterpret_cast<const float4*>(g.bn_scale + col);
-            p_sh[j][q] = *reinterpret_cast<const float4*>(g.bn_shift + col);
+          if (want_bias && g.bias) p_bias[j][q] = *reinterpret_cast<const float4*>(g.bias + col);
+          if (want_affine) {
+            if (LN) {
+              p_sc[j][q] = *reinterpret_cast<const float4*>(g.ln_gamma + col);
+              p_sh[j][q] = *reinterpret_cast<const float4*>(g.ln_beta + col);
+            } else if (g.bn_scale) {
+              p_sc[j][q] = *reinterpret_cast<const float4*>(g.bn_scale + col);
+              p_sh[j][q] = *reinterpret_cast<const float4*>(g.bn_shift + col);
+            }
           }
         }
       }
   };
-  if (!PRM_LATE) load_params();
+  if (!PRM_LATE) load_params(true, !AFFINE_LATE);
 
   // Software pipeline over k-tiles (32 k each = four 8-k groups G0..G3):
   //   * the DMA of tile kt+NSTAGE-1 is issued in EVERY iteration, one instruction per MFMA issue gap of G0
@@ -494,7 +502,8 @@ gemm2_kernel(const GemmArgs g, int tiles_m, int tiles_n) {
       }
     }
   }
-  if (PRM_LATE) load_params();
+  if (PRM_LATE) load_params(true, true);
+  else if (AFFINE_LATE) load_params(false, true);
   wait_vmcnt<0>();                                    // drain the dummy tail tiles before LDS is reused / exit
 
   // Result layout (operands swapped, D^T): lane (l31, half) owns output ROW m = .. + l31 and, per 32x32 block,

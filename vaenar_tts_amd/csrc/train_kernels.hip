@@ -235,7 +235,8 @@ __device__ __forceinline__ void tn3_barrier() {           // LDS traffic of this
 // waves in lock step between barriers), and a second workgroup per CU did not get scheduled beside it.
 __global__ void __launch_bounds__(768)
 gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
-                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det) {
+                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det,
+                unsigned* tickets) {
   constexpr int TS = 2048 + 64;                            // one 32-column tile of a plane: [2 steps][2 halves][8 rows][32 halves] + pad
   constexpr int PL = 4 * TS;                               // one plane of one stage: 32 rows x 128 halves
   extern __shared__ __attribute__((aligned(16))) char tn3_smem[];      // [2 stages][A hi | A lo | B hi | B lo][PL]
@@ -486,6 +487,46 @@ gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int 
           }
         }
     }
+  // ---- deterministic mode, round 6: the ordered finish INSIDE the launch (292 det_finish launches per step before) -----------------
+  // The row splits of an output tile are `splits` workgroups of this launch -- at most ~136 of them in all, co-resident by construction
+  // (two fit a CU).  Every multiplier wave publishes its partial (release fence, one ticket), waits until all 4 x splits tickets of its
+  // tile are in, and then adds up ITS share of the tile -- rows of 128 outputs dealt round-robin over the 4 x splits waves -- over the
+  // splits in index order: the same sums in the same order as det_finish_2d_kernel, at the width of the whole launch instead of a
+  // second launch behind it.  The wave that leaves last puts both counters back to zero for the next launch of the stream.
+  if (det && tickets) {
+    unsigned* arrive = tickets + tile;
+    unsigned* depart = tickets + kDetTickets + tile;
+    const unsigned want = 4u * (unsigned)splits;
+    __threadfence();
+    if (lane == 0) {
+      __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence();
+    const int kmax = (K - k0) < 128 ? (K - k0) : 128, nmax = (N - n0) < 128 ? (N - n0) : 128;
+    const size_t kn = (size_t)K * N;
+    const int me = 4 * split + wave, nw = 4 * splits;
+    for (int kk = me; kk < kmax; kk += nw) {
+      const size_t base = (size_t)(k0 + kk) * N + n0;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int nn = lane + 64 * h2;
+        if (nn < nmax) {
+          float a = __builtin_nontemporal_load(det + base + nn);
+          for (int p = 1; p < splits; ++p) a += __builtin_nontemporal_load(det + (size_t)p * kn + base + nn);
+          C[(size_t)(k0 + kk) * ldc + n0 + nn] += a;
+        }
+      }
+    }
+    if (lane == 0) {
+      const unsigned left = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (left == want - 1u) {
+        __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arrive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 // max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0.
 // Second generation (round 2): the first version gave a contiguous 13 MB gradient 50 workgroups of one 256 KB pseudo-row each
@@ -614,7 +655,7 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
       unsigned long long* d = nullptr;
       if (hipMalloc((void**)&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
       (void)hipMemset(d, 0, n * 8);
-      vnr_launch(gemm_tn3_kernel, dim3(wgs), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, dbg_out, tk, tn, splits, d, (float*)nullptr);
+      vnr_launch(gemm_tn3_kernel, dim3(wgs), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps, b_absmax, dbg_out, tk, tn, splits, d, (float*)nullptr, (unsigned*)nullptr);
       (void)hipStreamSynchronize(s);
       std::vector<unsigned long long> hbuf(n);
       (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
@@ -624,9 +665,12 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
       return hipGetLastError();
     }
     float* det = static_cast<float*>(det_scratch(s, (size_t)splits * K * N * sizeof(float)));
+    // (round 6) the ordered finish rides inside the launch when its workgroups are certain to be co-resident (they wait for each other)
+    static const bool sep_finish = getenv("VNR_DET_SEPARATE_FINISH") != nullptr;       // A/B switch: the round-4 second launch
+    unsigned* tk_words = (det && !sep_finish && tk * tn <= kDetTickets && splits * tk * tn <= 400) ? det_tickets(s) : nullptr;
     vnr_launch(gemm_tn3_kernel, dim3((unsigned)((splits + 7) / 8 * 8 * tk * tn)), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps,
-               b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr, det);
-    if (det) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);
+               b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr, det, tk_words);
+    if (det && !tk_words) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);
     return hipGetLastError();
   }
   const bool big = force == 2 && K >= 128 && N >= 128 && (long long)((K + 127) / 128) * ((N + 127) / 128) * ((M + 127) / 128) >= 256;

@@ -665,9 +665,13 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
       return hipGetLastError();
     }
     float* det = static_cast<float*>(det_scratch(s, (size_t)splits * K * N * sizeof(float)));
-    // (round 6) the ordered finish rides inside the launch when its workgroups are certain to be co-resident (they wait for each other)
-    static const bool sep_finish = getenv("VNR_DET_SEPARATE_FINISH") != nullptr;       // A/B switch: the round-4 second launch
-    unsigned* tk_words = (det && !sep_finish && tk * tn <= kDetTickets && splits * tk * tn <= 400) ? det_tickets(s) : nullptr;
+    // (round 6 experiment, VNR_DET_INKERNEL_FINISH=1; default OFF) the ordered finish inside the launch -- bit-identical sums, one launch
+    // instead of two, and 47.0 against 21.0 ms per T1 step: the row splits of a tile wait for each other, and on the kernel-gradient
+    // stream the launch shares the GPU with the main stream's chain launches (whole CUs for ~100 us each) -- the splits that got a
+    // CU spin until the others find one, where the two-launch form lets every split leave as soon as its partial is written
+    // (profiles/r06_experiments.txt)
+    static const bool inkernel = getenv("VNR_DET_INKERNEL_FINISH") != nullptr;
+    unsigned* tk_words = (det && inkernel && tk * tn <= kDetTickets && splits * tk * tn <= 400) ? det_tickets(s) : nullptr;
     vnr_launch(gemm_tn3_kernel, dim3((unsigned)((splits + 7) / 8 * 8 * tk * tn)), dim3(768), lds, s, A, lda, B, ldb, C, ldc, M, K, N, T > 0 ? T : M, shift, rps,
                b_absmax, dbg_out, tk, tn, splits, (unsigned long long*)nullptr, det, tk_words);
     if (det && !tk_words) return launch_det_finish_2d(det, splits, K, N, C, ldc, s);

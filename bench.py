@@ -634,7 +634,7 @@ def cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact=None):
         "sample": "the full S1 batch (16 x 800 frames), best run of %s; the reference's TF2-CPU path cannot run here (no "
                   "TensorFlow)" % ("oracle/vaenar_torch.py in fp32 (torch CPU: oneDNN/MKL, %d threads)" % t_threads if use_torch
                                    else "oracle/vaenar_numpy.py in fp32 (NumPy/OpenBLAS)"),
-        "seconds_per_batch": best, "host_cpus": os.cpu_count(),
+        "seconds_per_batch": best, "host_cpus": os.cpu_count(), "host_cpu_model": _cpu_model(),
         "thread_sweep_seconds": {str(k): v for k, v in sorted(sweep.items())},
         "candidates_mel_frames_per_s": {"numpy_fp32_oracle": B * Tm / best_np,
                                         "torch_cpu_fp32_restatement": (B * Tm / best_t) if best_t else None},
@@ -645,6 +645,25 @@ def cpu_baseline_block(args, hps, weights, batch, mel, value, mel_exact=None):
         res["_exact_err"] = float(np.abs(mel_exact.numpy() - ref).max())
     res["speedup_vs_cpu_baseline"] = value / res["cpu_baseline"]["value"]
     return res
+
+
+def _cpu_model():
+    """The box's CPU as /proc/cpuinfo names it, with socket / core / thread counts (VERDICT round 5 #6: stated beside cpu_baseline)."""
+    try:
+        names, phys, cores = set(), set(), set()
+        cur = {}
+        for ln in open("/proc/cpuinfo"):
+            if ":" in ln:
+                k, v = [x.strip() for x in ln.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                names.add(cur.get("model name", "?")); phys.add(cur.get("physical id", "0")); cores.add((cur.get("physical id", "0"), cur.get("core id", "0")))
+                cur = {}
+        if cur:
+            names.add(cur.get("model name", "?")); phys.add(cur.get("physical id", "0")); cores.add((cur.get("physical id", "0"), cur.get("core id", "0")))
+        return "%s; %d socket(s), %d cores, %d hardware threads" % (" / ".join(sorted(names)), len(phys), len(cores), os.cpu_count() or 0)
+    except Exception as e:
+        return "unknown (%r)" % (e,)
 
 
 def _time_train_steps(tm, vdist, t_ids, t_mels, tb, t_eps, trf, world, rank, deterministic, nst, seed):

@@ -208,9 +208,9 @@ def test_train_harness_runs_resumes_and_is_reproducible(tmp_path):
 
 def test_training_soak_changing_shapes_memory_steady():
     """60 optimizer steps at LJ widths per mode (float atomics / deterministic) with batch shapes and reduction factors changing from step
-    to step (tools/r04_soak.py): every loss finite, the loss falls, and free device memory is the same at the last checkpoint as at the
+    to step (tools/train_soak.py): every loss finite, the loss falls, and free device memory is the same at the last checkpoint as at the
     third -- the workspace arena, the activation-gradient chunks, the deterministic scratch and the event pool reach a steady state."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r04_soak.py"), "60"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_soak.py"), "60"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "soak ok" in out.stdout and out.stdout.count("non-finite 0") == 2
     first = [float(ln.split("loss")[1].split()[0]) for ln in out.stdout.splitlines() if " step   0 " in ln]

@@ -88,7 +88,7 @@ def test_adam_update_matches_keras_formula():
     model = VAENAR(hps, weights=w)
     # hps.Train.learning_rate (1e-3, the reference's).  On this trajectory the weights reached after one update put ONE hidden unit of
     # one FFN within float32 rounding of zero: its ReLU mask is not defined at fp32 resolution (it follows the last bits of the
-    # forward pass) and one flipped mask is a 4e-3 error in that FFN's kernel gradients (tools/r03_adam_err.py).  oracle/kinks.py finds
+    # forward pass) and one flipped mask is a 4e-3 error in that FFN's kernel gradients (tools/archive/r03_adam_err.py).  oracle/kinks.py finds
     # such units and compares against the oracle run on the engine's side of the kink, at the usual 2e-3.
     LR = 1e-3
     try:

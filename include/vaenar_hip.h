@@ -309,6 +309,9 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * stages ahead of the workers of their XCD (L2 warming, csrc/chain_prefetch.h).  "chain_segments" (default 1, with chain_waves4):
  * the 32-row panels of a launch with the fused cross-attention start at utterance boundaries (ceil(T / 32) workgroups per
  * utterance) so that no workgroup attends for two utterances.
+ * "kv_overlap" (default 0; a round-6 experiment that measured 1 % SLOWER): vnr_inference computes the prior's cross K | V projection on a
+ * second stream beside the first flow step's pre-chain and self-attention (which do not read it); the first launch that reads it waits
+ * for it.  Same results.
  * "range_guard" (default 1): see "Arithmetic contract of the split path" below; setting it (to either value) forgets the surveys.
  * "range_sentinel" (default 1; 0 = the split products are not watched: measurement only) and "train_fp32" (0 / 1: the training step on
  * exact fp32 MFMA; set by a sentinel trip inside vnr_train_step): same section. */

@@ -192,6 +192,13 @@ struct vnr_context {
   // (the layers in FRONT of the trip have already taken their update -- predicating the update on the word protects only the ones behind it)
   CopyJob* bn_save_jobs = nullptr; CopyJob* bn_restore_jobs = nullptr; float* bn_backup = nullptr; int bn_njobs = 0; size_t bn_table_gen = (size_t)-1;
   size_t w_generation = 0;             // bumped whenever a variable is (re)allocated
+  // (round 6) vnr_inference: the prior's cross K | V projection (one GEMM of the text encoding, 3072 workgroups, ~63 us) runs on a SECOND
+  // stream beside the first flow step's pre-chain and self-attention, which do not read it; the first launch that does (a chain launch
+  // with the fused cross-attention, or a cross-attention core) waits for `kv_wait`.  Engine option "kv_overlap" (default 0: measured slower; off while the
+  // dispatch-event profile is on: its per-class sums are meant to add up to the wall time).
+  bool kv_overlap = false;             // (measured: 2.254 against 2.228 ms per S1 step with the overlap -- the GEMM's workgroups on the CUs the chain launch leaves idle
+                                       //  slow the chain down by more than the projection's own time they hide; profiles/r06_experiments.txt r06e)
+  hipStream_t kv_stream = nullptr; hipEvent_t kv_fork = nullptr, kv_done = nullptr; hipEvent_t kv_wait = nullptr;
   std::vector<std::pair<const float*, std::pair<int, int>>> panel_registry;   // (base, (N, K)) recorded while packing
 
   // workspace arena (chunks; bump allocation, reset at every top-level call)
@@ -366,7 +373,13 @@ int chain_params(vnr_handle h, ChainArgs& g) {
   return VNR_OK;
 }
 
+// the first reader of the cross K | V projection joins the stream it was computed on (vnr_context::kv_overlap)
+int kv_join(vnr_handle h) {
+  if (h->kv_wait) { HIP_TRY(h, hipStreamWaitEvent(h->stream, h->kv_wait, 0)); h->kv_wait = nullptr; }
+  return VNR_OK;
+}
 int run_chain(vnr_handle h, ChainArgs& g, double flops) {
+  if (g.att_stage > 0) TRY(kv_join(h));
   TRY(chain_params(h, g));
   g.rows64 = h->chain_rows64 ? 1 : 0;
   g.waves4 = (h->chain_waves4 && !h->chain_rows64) ? 1 : 0;
@@ -394,6 +407,7 @@ int run_chain(vnr_handle h, ChainArgs& g, double flops) {
 
 int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
   AttnArgs a = a_in;
+  if (cross) TRY(kv_join(h));
   if (h->surveying) {                                     // the attention cores of the split path take Q, K and V unscaled
     TRY(survey_matrix(h, a.Q, a.ldq, a.Tq * a.B, a.H * 64, 1, a.Tq, a.q_bs, a.B));
     TRY(survey_matrix(h, a.K, a.ldk, a.Tk * a.B, a.H * 64, 1, a.Tk, a.k_bs, a.B));
@@ -426,6 +440,7 @@ int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
   return VNR_OK;
 }
 int run_attention3(vnr_handle h, const Attn3Args& a, bool cross) {
+  if (cross) TRY(kv_join(h));
   const double io = 4.0 * ((double)a.B * a.Tq * a.H * 64 * 2 + (double)a.B * a.Tk * a.H * 64 * 2) +
                     (a.ali ? 4.0 * (double)a.B * a.H * a.Tq * a.Tk : 0.0);
   const double fl = 4.0 * (double)a.B * a.H * a.Tq * (double)a.Tk * 64;
@@ -1758,6 +1773,9 @@ int vnr_destroy(vnr_handle h) {
   if (h->chain_progress) hipFree(h->chain_progress);
   if (h->range_flag) hipHostFree(h->range_flag);
   if (h->d_step_flag) hipFree(h->d_step_flag);
+  if (h->kv_stream) { hipStreamSynchronize(h->kv_stream); hipStreamDestroy(h->kv_stream); }
+  if (h->kv_fork) hipEventDestroy(h->kv_fork);
+  if (h->kv_done) hipEventDestroy(h->kv_done);
   if (h->bn_save_jobs) hipFree(h->bn_save_jobs);
   if (h->bn_restore_jobs) hipFree(h->bn_restore_jobs);
   if (h->bn_backup) hipFree(h->bn_backup);
@@ -2144,7 +2162,26 @@ static int vnr_inference_impl(vnr_handle h, const int32_t* d_ids, const int32_t*
     // the decoder's cross K|V are produced right before the decoder instead of ~2 ms earlier with the prior's: the decoder
     // cross-attention (the HBM-bound kernel of the path) then finds them in L2 / Infinity Cache (12.5 -> ? us per launch)
     WS(kvp, (size_t)B * Tt * h->prior_kv_n);
-    TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n, kvp, h->cfg.prior_attention_dim));
+    if (h->kv_overlap && !h->profiling && !h->surveying && !h->flow.empty()) {
+      // fork: the projection on the side stream behind the encoder; the main stream goes on with the first pre-chain + self-attention
+      if (!h->kv_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->kv_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->kv_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->kv_done, hipEventDisableTiming));
+      }
+      HIP_TRY(h, hipEventRecord(h->kv_fork, h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->kv_stream, h->kv_fork, 0));
+      hipStream_t main_s = h->stream;
+      h->stream = h->kv_stream;
+      const int rc_kv = run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n, kvp, h->cfg.prior_attention_dim);
+      const hipError_t e_rec = hipEventRecord(h->kv_done, h->kv_stream);
+      h->stream = main_s;
+      TRY(rc_kv);
+      HIP_TRY(h, e_rec);
+      h->kv_wait = h->kv_done;
+    } else {
+      TRY(run_kv(h, text_embd, B, Tt, Dm, h->prior_kv_wt, h->prior_kv_n, kvp, h->cfg.prior_attention_dim));
+    }
     // the decoder's pre-chain rides behind the last flow step's coupling (same chain launch) when the shapes allow
     const int Dd = h->cfg.dec_attention_dim;
     std::vector<PreStage> dpre;
@@ -2156,7 +2193,9 @@ static int vnr_inference_impl(vnr_handle h, const int32_t* d_ids, const int32_t*
       dpre = decoder_pre_stages(h, B, Tz, dxa, dqkv, 1, 0);
     }
     bool dec_pre_done = false;
-    TRY(prior_body(h, d_reduced_lengths, d_text_lengths, kvp, h->prior_kv_n, B, Tz, Tt, d_eps, z, nullptr, dpre.empty() ? nullptr : &dpre, &dec_pre_done));
+    const int rc_prior = prior_body(h, d_reduced_lengths, d_text_lengths, kvp, h->prior_kv_n, B, Tz, Tt, d_eps, z, nullptr, dpre.empty() ? nullptr : &dpre, &dec_pre_done);
+    TRY(kv_join(h));                                       // (nothing read the projection, or the prior failed: the side stream joins here at the latest)
+    TRY(rc_prior);
     WS(kvd, (size_t)B * Tt * h->dec_kv_n);
     TRY(run_kv(h, text_embd, B, Tt, Dm, h->dec_kv_wt, h->dec_kv_n, kvd, h->cfg.dec_attention_dim));
     return decoder_body(h, z, kvd, h->dec_kv_n, d_reduced_lengths, d_text_lengths, B, Tz, Tt, reduction_factor, nullptr, d_mel, d_alignments,
@@ -2728,6 +2767,7 @@ int vnr_set_option(vnr_handle h, const char* name, int value) {
   if (!strcmp(name, "deterministic")) { h->deterministic = value != 0; return VNR_OK; }
   if (!strcmp(name, "range_guard")) { h->range_guard = value != 0; for (int m = 0; m < 4; ++m) h->range_state[m] = 0; return VNR_OK; }
   if (!strcmp(name, "range_sentinel")) { h->range_sentinel = value != 0; return VNR_OK; }
+  if (!strcmp(name, "kv_overlap")) { h->kv_overlap = value != 0; return VNR_OK; }
   if (!strcmp(name, "train_fp32")) { h->train_fp32 = value != 0; h->derived_fresh = false; return VNR_OK; }
   return fail(h, VNR_ERR_ARG, std::string("unknown option ") + name);
 }

@@ -917,19 +917,63 @@ hipError_t launch_philox_normal(float* out, size_t n, unsigned long long seed, u
 // (atomicMin; the caller initialises it to 0x7f800000).  Non-negative floats order like their bit patterns; a NaN counts as +inf.
 namespace {
 __global__ void __launch_bounds__(256) row_range_kernel(const float* x, long long ld, int rows, int cols, unsigned* out, int T, long long bs) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  // T > 0: a batch of matrices -- row r is row r % T of element r / T, elements bs floats apart (the attention operands of one call)
-  const int bb = T > 0 ? row / T : 0;
-  const float* p = x + (size_t)bb * bs + (size_t)(row - bb * T) * ld;
-  float m = 0.f;
-  for (int c = lane; c < cols; c += 64) { const float v = p[c]; m = fmaxf(m, (v != v) ? INFINITY : fabsf(v)); }
+  // Round 6: at most 128 workgroups whose waves stride over the rows (16-byte loads), ONE atomic pair per workgroup.  (One wave and one atomic per row --
+  // the round-5 form -- queued 6400 atomics on one word whenever the word still held its initial value: 62 us per call at S1 size,
+  // three calls per attention core on the exact mode.)
+  __shared__ float wmax[4], wmin[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gmax = 0.f, gmin = INFINITY;                     // largest / smallest non-zero row maximum seen by this wave
+  const bool vec = !(cols & 3) && !(ld & 3) && !(bs & 3) && !((size_t)x & 15);
+  // four rows per trip: their loads are all issued before the first reduction (a wave walks ~12 rows at S1 size; one dependent
+  // load -> shuffle chain per row took 10 us per call)
+  const int stride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += 4 * stride) {
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec && cols <= 256) {
+      float4 v[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (lane == 0) {
-    const unsigned b = __float_as_uint(m);
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u * stride;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && 4 * lane < cols) {
+          const int bb = T > 0 ? row / T : 0;
+          v[u] = *reinterpret_cast<const float4*>(x + (size_t)bb * bs + (size_t)(row - bb * T) * ld + 4 * lane);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+        m[u] = (v[u].x != v[u].x || v[u].y != v[u].y || v[u].z != v[u].z || v[u].w != v[u].w) ? INFINITY : a;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = row0 + u * stride;
+        if (row >= rows) continue;
+        // T > 0: a batch of matrices -- row r is row r % T of element r / T, elements bs floats apart (the attention operands of one call)
+        const int bb = T > 0 ? row / T : 0;
+        const float* p = x + (size_t)bb * bs + (size_t)(row - bb * T) * ld;
+        for (int c = lane; c < cols; c += 64) { const float v = p[c]; m[u] = fmaxf(m[u], (v != v) ? INFINITY : fabsf(v)); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float mm = m[u];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+      gmax = fmaxf(gmax, mm);
+      if (mm != 0.f && row0 + u * stride < rows) gmin = fminf(gmin, mm);
+    }
+  }
+  if (lane == 0) { wmax[wave] = gmax; wmin[wave] = gmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float mn = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
+    const unsigned b = __float_as_uint(mx);
     if (b > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, b);
-    if (b != 0u && b < __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out + 1, b);
+    const unsigned bn = __float_as_uint(mn);
+    if (mn != INFINITY && bn < __hip_atomic_load(out + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(out + 1, bn);
   }
 }
 // a table of small device-to-device copies in ONE launch (engine.hip: the BatchNormalization moving statistics are saved in front of a
@@ -951,7 +995,8 @@ __global__ void __launch_bounds__(256) finite_check_kernel(const float* x, size_
 }  // namespace
 hipError_t launch_row_range(const float* x, long long ld, int rows, int cols, unsigned* out, hipStream_t s) {
   if (rows <= 0 || cols <= 0) return hipSuccess;
-  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, rows, cols, out, 0, (long long)0);
+  const unsigned wgs = (unsigned)((rows + 3) / 4);
+  vnr_launch(row_range_kernel, dim3(wgs < 128u ? wgs : 128u), dim3(256), 0, s, x, ld, rows, cols, out, 0, (long long)0);
   return hipGetLastError();
 }
 // the same over a batch of B matrices of T rows each, `bs` floats apart: ONE record for the whole operand
@@ -959,7 +1004,8 @@ hipError_t launch_row_range_batched(const float* x, long long ld, int T, long lo
   if (T <= 0 || B <= 0 || cols <= 0) return hipSuccess;
   const long long rows = (long long)T * B;
   if (rows > 0x7fffffffLL) return hipErrorInvalidValue;
-  vnr_launch(row_range_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, (int)rows, cols, out, T, bs);
+  const unsigned wgs = (unsigned)((rows + 3) / 4);
+  vnr_launch(row_range_kernel, dim3(wgs < 128u ? wgs : 128u), dim3(256), 0, s, x, ld, (int)rows, cols, out, T, bs);
   return hipGetLastError();
 }
 hipError_t launch_copy_batch(const CopyJob* jobs, int njobs, hipStream_t s) {

@@ -192,6 +192,7 @@ struct vnr_context {
   // (the layers in FRONT of the trip have already taken their update -- predicating the update on the word protects only the ones behind it)
   CopyJob* bn_save_jobs = nullptr; CopyJob* bn_restore_jobs = nullptr; float* bn_backup = nullptr; int bn_njobs = 0; size_t bn_table_gen = (size_t)-1;
   size_t w_generation = 0;             // bumped whenever a variable is (re)allocated
+  unsigned* amax_words = nullptr; int amax_next = -1;     // exact mode: the attention cores' abs-max words, 8 per call, cleared by ONE memset per top-level call (-1: not yet)
   // (round 6) vnr_inference: the prior's cross K | V projection (one GEMM of the text encoding, 3072 workgroups, ~63 us) runs on a SECOND
   // stream beside the first flow step's pre-chain and self-attention, which do not read it; the first launch that does (a chain launch
   // with the fused cross-attention, or a cross-attention core) waits for `kv_wait`.  Engine option "kv_overlap" (default 0: measured slower; off while the
@@ -236,7 +237,7 @@ int fail(vnr_handle h, int code, const std::string& msg) {
   } while (0)
 
 // ---- arena --------------------------------------------------------------------------------------
-void ws_reset(vnr_handle h) { for (auto& c : h->chunks) c.off = 0; h->kv_aoi.clear(); }
+void ws_reset(vnr_handle h) { for (auto& c : h->chunks) c.off = 0; h->kv_aoi.clear(); h->amax_next = -1; }
 
 float* ws_alloc(vnr_handle h, size_t nfloats) {
   size_t bytes = ((nfloats * sizeof(float)) + 255) & ~(size_t)255;
@@ -416,9 +417,16 @@ int run_attention(vnr_handle h, const AttnArgs& a_in, bool cross) {
   if (!split_active(h) || (h->in_train_step && h->train_fp32)) {
     // exact-fp32 mode: the core still multiplies fp16 hi/lo pairs, so its operands get per-launch power-of-two scales from their
     // maxima (attention2.hip: AttnArgs::qkv_absmax) -- fp32's dynamic range, like the reference's tf.matmul (attention.py:224-246)
-    unsigned* words = reinterpret_cast<unsigned*>(ws_alloc(h, 8));
-    if (!words) return fail(h, VNR_ERR_NOMEM, "attention operand scales");
-    HIP_TRY(h, hipMemsetAsync(words, 0, 8 * sizeof(unsigned), h->stream));
+    constexpr int kAmaxWords = 4096;
+    unsigned* words = nullptr;
+    if (!h->amax_words && hipMalloc((void**)&h->amax_words, kAmaxWords * sizeof(unsigned)) != hipSuccess) h->amax_words = nullptr;
+    if (h->amax_words && h->amax_next < 0) { HIP_TRY(h, hipMemsetAsync(h->amax_words, 0, kAmaxWords * sizeof(unsigned), h->stream)); h->amax_next = 0; }
+    if (h->amax_words && h->amax_next + 8 <= kAmaxWords) { words = h->amax_words + h->amax_next; h->amax_next += 8; }
+    else {
+      words = reinterpret_cast<unsigned*>(ws_alloc(h, 8));
+      if (!words) return fail(h, VNR_ERR_NOMEM, "attention operand scales");
+      HIP_TRY(h, hipMemsetAsync(words, 0, 8 * sizeof(unsigned), h->stream));
+    }
     hipError_t e1 = launch_row_range_batched(a.Q, a.ldq, a.Tq, a.q_bs, a.B, a.H * 64, words, h->stream);
     if (e1 == hipSuccess) e1 = launch_row_range_batched(a.K, a.ldk, a.Tk, a.k_bs, a.B, a.H * 64, words + 2, h->stream);
     if (e1 == hipSuccess) e1 = launch_row_range_batched(a.V, a.ldv, a.Tk, a.v_bs, a.B, a.H * 64, words + 4, h->stream);
@@ -1773,6 +1781,7 @@ int vnr_destroy(vnr_handle h) {
   if (h->chain_progress) hipFree(h->chain_progress);
   if (h->range_flag) hipHostFree(h->range_flag);
   if (h->d_step_flag) hipFree(h->d_step_flag);
+  if (h->amax_words) hipFree(h->amax_words);
   if (h->kv_stream) { hipStreamSynchronize(h->kv_stream); hipStreamDestroy(h->kv_stream); }
   if (h->kv_fork) hipEventDestroy(h->kv_fork);
   if (h->kv_done) hipEventDestroy(h->kv_done);

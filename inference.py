@@ -34,6 +34,7 @@ def inference_test():
     parser.add_argument('--batch_size', type=int, default=1)
     parser.add_argument('--temperature', type=float, default=0.)
     parser.add_argument('--write_mels', type=int, default=1)
+    parser.add_argument('--draw_alignments', type=int, default=0, help='one figure per utterance and decoder block (inference.py:160-164)')
     parser.add_argument('--write_wavs', type=int, default=0,
                         help='also run the Griffin-Lim vocoder step on the GPU (audio/utils.py:24-40) and write prior-{fid}-{step}.wav')
     parser.add_argument('--num_utterances', type=int, default=8, help='synthetic data only')
@@ -103,6 +104,12 @@ def inference_test():
         if tester is not None:                                                    # audio/utils.py:24-40
             tester.synthesize_and_save_wavs(ckpt_step, outs, np.minimum(pred_m_lens, outs.shape[1]), list(ids), prefix='prior',
                                             seed=args.seed)
+        if args.draw_alignments:                                                  # inference.py:160-164
+            from vaenar_tts_amd.audio.utils import TestUtils
+            drawer = tester if tester is not None else TestUtils(hparams, args.test_dir, engine=model.engine)
+            for k in prior_ali:
+                drawer.multi_draw_attention_alignments(prior_ali[k].numpy(), texts, t_lengths, (np.asarray(pred_m_lens) + rf - 1) // rf,
+                                                       ckpt_step, list(ids), 'prior-{}'.format(k))
     time_consumed = vdist.max_over_ranks(time_consumed)
     durations = float(np.sum(vdist.gather_to_rank0(np.array([durations])))) if world > 1 else durations
     if rank == 0:

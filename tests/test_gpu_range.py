@@ -293,6 +293,64 @@ def test_sentinel_catches_inputs_that_leave_the_range_on_a_later_call(scale, tri
         model.engine.close(); exact.engine.close()
 
 
+def test_sentinel_replays_a_chain_of_pending_module_calls_in_order():
+    """The module-by-module path (models.py:201-209: text encoder -> prior.sample -> decoder): calls whose outputs feed each other are
+    pending together when `.numpy()` reaches the checkpoint.  The flagged one is the prior (its latent leaves fp16's range); the decoder's
+    first run consumed an invalid z, so the binding must replay BOTH, in order, and hand out what the exact mode computes.  With host
+    arguments in between (`fused=False` uploads the lengths per module) every upload is a checkpoint of its own and the same end result
+    must come out.  Also: more pending calls than the log holds force a checkpoint by themselves."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    b = _batch(hps, "lj")
+    big = (np.asarray(b["eps"], np.float64) * 3.0e4).astype(np.float32)
+    ref, _ = Oracle(hps, w, np.float64).inference(b["ids"], b["mel_lengths"], b["text_lengths"], 2, big)
+    scale_ref = max(1.0, float(np.abs(ref).max()))
+    pos_step = np.float32(hps.Common.mel_text_len_ratio) / np.float32(2)
+    red = ((b["mel_lengths"].astype(np.int64) + 1) // 2).astype(np.int32)
+    model = VAENAR(hps, weights=w)
+    try:
+        e = model.engine
+        model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"], fused=False)[0].numpy()     # surveys: in window
+        assert e.range_info()["sentinel_trips"] == 0 and not e._log
+        # (a) device-resident arguments: nothing synchronises between the calls
+        red_d, tl_d, eps_d = e.to_device(red, np.int32), e.to_device(b["text_lengths"], np.int32), e.to_device(big, np.float32)
+        te = model.text_encoder(b["ids"], b["text_lengths"], pos_step=pos_step)
+        te.numpy()                                            # clean checkpoint
+        z, _ = model.prior.sample(red, te, tl_d, eps=eps_d)   # (host lengths: one upload = one clean checkpoint BEFORE the call)
+        _, mel, _ali = model.decoder(inputs=z, text_embd=te, z_lengths=red_d, text_lengths=tl_d, reduction_factor=2)
+        pending = [name for name, _ in e._log if name.startswith("vnr_prior") or name.startswith("vnr_decoder")]
+        assert pending == ["vnr_prior_sample", "vnr_decoder_fwd"], [name for name, _ in e._log]
+        got = mel.numpy()
+        info = e.range_info()
+        print("two pending calls replayed:", info)
+        assert np.isfinite(got).all() and info["sentinel_trips"] == 1 and info["replays"] == 1 and not e._log
+        assert info["prior"] == 2 and info["decoder"] == 2
+        assert np.abs(got - ref).max() / scale_ref < 1e-3
+        assert np.isfinite(z.numpy()).all()                   # the replay rewrote the intermediate too
+    finally:
+        model.engine.close()
+    model = VAENAR(hps, weights=w)
+    try:
+        e = model.engine
+        model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"], fused=False)[0].numpy()
+        # (b) host arguments between the modules: the trip surfaces at an upload inside the decoder's call, is replayed there, same result
+        mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big, fused=False)
+        got = mel.numpy()
+        info = e.range_info()
+        assert np.isfinite(got).all() and info["sentinel_trips"] == 1 and info["replays"] == 1
+        assert np.abs(got - ref).max() / scale_ref < 1e-3
+        # a log that fills up synchronises (and checks) by itself: no unbounded queue of unverified results
+        e._log_cap = 4
+        ids_d, tl_d = e.to_device(b["ids"], np.int32), e.to_device(b["text_lengths"], np.int32)
+        te = None
+        for _ in range(6):
+            te = model.text_encoder(ids_d, tl_d, pos_step=pos_step)
+        assert len(e._log) < 4
+        assert np.isfinite(te.numpy()).all()
+    finally:
+        model.engine.close()
+
+
 def test_sentinel_c_abi_semantics_without_the_python_replay():
     """What a C caller sees (include/vaenar_hip.h): the flagged call itself returns VNR_OK (asynchronous); the next synchronisation point
     returns VNR_ERR_RANGE once, the modules are in state 2, and re-issuing the call gives the exact result."""

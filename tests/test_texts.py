@@ -60,3 +60,28 @@ def test_text_to_array_and_padding():
     assert "".join(DataBakerHPS.Texts.characters[i] for i in b) == "^ni3 hao3~"
     ids, lens = T.pad_batch([a, b])
     assert ids.shape == (2, len(a)) and ids.dtype == np.int32 and list(lens) == [len(a), len(b)] and (ids[1, len(b):] == 0).all()
+
+
+def test_testutils_figures(tmp_path):
+    """The harnesses' figures (reference audio/utils.py:42-116, called from train.py:319-323 / inference.py:160-164): one PDF per utterance
+    for the predicted mels, one per utterance and decoder block for the alignments (3-D: one panel, 4-D: one panel per head)."""
+    import os
+    import numpy as np
+    import pytest
+    pytest.importorskip("matplotlib")
+    from vaenar_tts_amd.audio.utils import TestUtils
+    from vaenar_tts_amd.configs import LJHPS
+    t = TestUtils.__new__(TestUtils)                      # (no engine: the figures are host-only)
+    t.hps, t.save_dir = LJHPS, str(tmp_path)
+    r = np.random.default_rng(0)
+    mels = r.standard_normal((2, 30, 80)).astype(np.float32)
+    t.draw_melspectrograms(7, mels, [30, 21], [b"utt-a", "utt-b"], prefix="test")
+    ali4 = r.random((2, 4, 15, 9)).astype(np.float32)
+    texts = r.integers(3, 29, (2, 9))
+    t.multi_draw_attention_alignments(ali4, texts, [9, 6], [15, 11], 7, ["utt-a", "utt-b"], "test-decoder-attention-0")
+    t.multi_draw_attention_alignments(ali4[:, 0], texts, [9, 6], [15, 11], 7, ["utt-a", "utt-b"], "post")
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["post-utt-a-7.pdf", "post-utt-b-7.pdf", "test-decoder-attention-0-utt-a-7.pdf", "test-decoder-attention-0-utt-b-7.pdf",
+                     "test-utt-a-7.pdf", "test-utt-b-7.pdf"], names
+    assert all(os.path.getsize(os.path.join(tmp_path, n)) > 1000 for n in names)
+    assert t._ids_to_symbols([3, 4, 5]) == list(LJHPS.Texts.characters[3:6])

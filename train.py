@@ -203,7 +203,14 @@ def main():
                 tester.synthesize_and_save_wavs(epoch, mel, ml, tb["fids"], 'test')
             except Exception as e:                             # (the reference swallows everything here, train.py:317-318)
                 print('Something wrong with the generated waveform! ({})'.format(e))
-            tester.write_mels(epoch, mel, ml, tb["fids"], 'test')  # (the reference draws spectrograms / alignments with matplotlib: out of scope)
+            tester.write_mels(epoch, mel, ml, tb["fids"], 'test')
+            try:                                               # train.py:319-323: the figures of the test batch (matplotlib, host only)
+                tester.draw_melspectrograms(epoch, mel, ml, tb["fids"], 'test')
+                for k in _ali:
+                    tester.multi_draw_attention_alignments(_ali[k].numpy(), tb["ids"], tb["text_lengths"], (ml + rf - 1) // rf, epoch,
+                                                           tb["fids"], 'test-{}'.format(k))
+            except RuntimeError as e:
+                print('figures skipped: {}'.format(e))
             print('test finished, check {} for the results'.format(test_dir))
         vdist.barrier()
     vdist.barrier()

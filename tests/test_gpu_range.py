@@ -337,7 +337,11 @@ def test_sentinel_replays_a_chain_of_pending_module_calls_in_order():
         mel, _ = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=big, fused=False)
         got = mel.numpy()
         info = e.range_info()
-        assert np.isfinite(got).all() and info["sentinel_trips"] == 1 and info["replays"] == 1
+        # (two trips here: the prior's surfaces at the upload inside the decoder's call and moves the PRIOR to the exact mode; the decoder then
+        #  runs on the split path with the replayed, still huge z, and trips at `.numpy()` in its own right)
+        print("host arguments between the modules:", info)
+        assert np.isfinite(got).all() and info["sentinel_trips"] == 2 and info["replays"] == 2
+        assert info["prior"] == 2 and info["decoder"] == 2
         assert np.abs(got - ref).max() / scale_ref < 1e-3
         # a log that fills up synchronises (and checks) by itself: no unbounded queue of unverified results
         e._log_cap = 4

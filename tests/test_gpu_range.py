@@ -355,6 +355,41 @@ def test_sentinel_replays_a_chain_of_pending_module_calls_in_order():
         model.engine.close()
 
 
+def test_sentinel_replay_repeats_the_options_set_in_front_of_the_call():
+    """VAENAR.call with n_sample = 2 (models.py:141-178) sets the engine's sample count, issues vnr_elbo_fwd and restores it: a replay that
+    started at the call would run it with the restored value on buffers sized for two samples.  Evaluation-mode ELBO forward whose mels
+    are 1e6 times larger than the surveyed call's (the posterior's PreNet output leaves fp16's range): one trip, one replay, the same
+    numbers as an engine that ran on the exact mode from the start (same kernels: bit for bit)."""
+    hps = tiny_hps()
+    hps.Train.num_samples = 2
+    w = init_weights(hps, seed=1234, mode="synthetic")
+    b = _batch(hps, "tiny")
+    r = np.random.Generator(np.random.PCG64(17))
+    B, Tm = len(b["mel_lengths"]), int(b["mel_lengths"].max())
+    mels = r.standard_normal((B, Tm, hps.Audio.num_mels)).astype(np.float32)
+    eps = r.standard_normal((B, 2, (Tm + 1) // 2, hps.Common.latent_dim)).astype(np.float32)
+    huge = (mels.astype(np.float64) * 1.0e6).astype(np.float32)
+    exact, model = VAENAR(hps, weights=w), VAENAR(hps, weights=w)
+    try:
+        exact.engine.set_option("split_fp16", 0)
+        want = exact(b["ids"], huge, b["mel_lengths"], b["text_lengths"], reduction_factor=2, training=False, reduce_loss=False, eps=eps)
+        want = [want[0].numpy(), want[1].numpy(), want[2].numpy(), want[3].numpy()]
+        model(b["ids"], mels, b["mel_lengths"], b["text_lengths"], reduction_factor=2, training=False, reduce_loss=False, eps=eps)[0].numpy()
+        assert model.engine.range_info()["sentinel_trips"] == 0
+        outs, l2, kl, ll, _ = model(b["ids"], huge, b["mel_lengths"], b["text_lengths"], reduction_factor=2, training=False,
+                                    reduce_loss=False, eps=eps)
+        assert ("vnr_set_option", (b"n_sample", 2)) in model.engine._log                 # recorded in front of the pending call
+        got = [outs.numpy(), l2.numpy(), kl.numpy(), ll.numpy()]
+        info = model.engine.range_info()
+        print("n_sample = 2 replay:", info)
+        assert info["sentinel_trips"] == 1 and info["replays"] == 1
+        assert got[0].shape == (2 * B, Tm, hps.Audio.num_mels)
+        for g_, w_ in zip(got, want):
+            assert np.isfinite(g_).all() and np.array_equal(g_, w_)
+    finally:
+        model.engine.close(); exact.engine.close()
+
+
 def test_sentinel_c_abi_semantics_without_the_python_replay():
     """What a C caller sees (include/vaenar_hip.h): the flagged call itself returns VNR_OK (asynchronous); the next synchronisation point
     returns VNR_ERR_RANGE once, the modules are in state 2, and re-issuing the call gives the exact result."""

@@ -316,6 +316,10 @@ class Engine:
             if len(self._log) >= self._log_cap:
                 self.synchronize()
 
+    def _pending(self):
+        """True while a compute call waits for its checkpoint (option settings alone do not count)."""
+        return any(name != "vnr_set_option" for name, _ in self._log)
+
     def _replay(self):
         log, self._log = self._log, []
         self.range_replays += 1
@@ -343,7 +347,7 @@ class Engine:
         return p.value
 
     def _give(self, nbytes, ptr):
-        if self._pool_bytes + nbytes <= self._pool_cap or self._log:      # (nothing goes back to the driver while calls are pending a checkpoint)
+        if self._pool_bytes + nbytes <= self._pool_cap or self._pending():      # (nothing goes back to the driver while calls are pending a checkpoint)
             self._pool.setdefault(nbytes, []).append(ptr)
             self._pool_bytes += nbytes
         else:
@@ -388,7 +392,7 @@ class Engine:
 
     # -- weights ----------------------------------------------------------------
     def set_weight(self, path, array):
-        if self._log:
+        if self._pending():
             self.synchronize()          # pending calls belong to the OLD variables: their checkpoint (and replay) comes first
         a = np.ascontiguousarray(array, dtype=np.float32)
         shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
@@ -401,7 +405,7 @@ class Engine:
 
     def get_weight(self, path, shape):
         out = np.empty(shape, np.float32)
-        check(self.lib.vnr_get_weight(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
+        self._checkpoint("vnr_get_weight", path.encode(), out.ctypes.data, out.size)      # (a device -> host copy: a checkpoint of the range sentinel)
         return out
 
     # -- data-parallel training (RCCL) ----------------------------------------------------
@@ -440,13 +444,13 @@ class Engine:
 
     def get_gradient(self, path, shape):
         out = np.empty(shape, np.float32)
-        check(self.lib.vnr_get_gradient(self.handle, path.encode(), out.ctypes.data, out.size), self.handle)
+        self._checkpoint("vnr_get_gradient", path.encode(), out.ctypes.data, out.size)
         return out
 
     # -- optimizer state (train.py:246-255: Checkpoint(step, optimizer, model)) ----------------
     def get_optimizer_slot(self, path, slot, shape):
         out = np.empty(shape, np.float32)
-        check(self.lib.vnr_get_optimizer_slot(self.handle, path.encode(), slot.encode(), out.ctypes.data, out.size), self.handle)
+        self._checkpoint("vnr_get_optimizer_slot", path.encode(), slot.encode(), out.ctypes.data, out.size)
         return out
 
     def set_optimizer_slot(self, path, slot, array):
@@ -473,8 +477,10 @@ class Engine:
         check(self.lib.vnr_set_option(self.handle, name.encode(), int(value)), self.handle)
         if name == "training":
             self._training_mode = bool(int(value))
-        elif self._log and not self._training_mode and not name.startswith("range_"):
-            self._log.append(("vnr_set_option", (name.encode(), int(value))))     # options are part of the sequence a replay repeats
+        elif not self._training_mode and not name.startswith("range_"):
+            # options are part of the sequence a replay repeats -- also the ones set in FRONT of the first pending call (VAENAR.call sets
+            # n_sample, issues vnr_elbo_fwd and sets it back: a replay that starts at the call would run it with the restored value)
+            self._log.append(("vnr_set_option", (name.encode(), int(value))))
 
     # -- instrumentation ----------------------------------------------------------
     def profile(self, on):

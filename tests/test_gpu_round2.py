@@ -506,3 +506,25 @@ def test_train_harness_on_tfrecords_with_test_synthesis(tmp_path):
     mel = np.load(tmp_path / "test" / "test-utt12-1.npy")
     assert mel.shape == (items[12][2].shape[0], hps.Audio.num_mels) and np.isfinite(mel).all()
     assert os.path.getsize(tmp_path / "test" / "test-utt12-1.wav") > 1000
+
+
+def test_kv_overlap_option_gives_the_same_bits():
+    """Engine option kv_overlap (round 6 experiment, default off: measured 1 % slower): the prior's cross K | V projection on a second
+    stream beside the first flow step's pre-chain and self-attention.  Same kernels, same operands, another schedule: bit-identical mels
+    and alignments, also with several calls in flight behind each other."""
+    hps = LJHPS
+    w = init_weights(hps, seed=1234, mode="synthetic", include_posterior=False)
+    b = make_batch(4, 37, 150, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, temperature=1.0,
+                   text_step=5, mel_step=23)
+    model = VAENAR(hps, weights=w)
+    try:
+        mel0, ali0 = model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"])
+        ref, refa = mel0.numpy(), {k: v.numpy() for k, v in ali0.items()}
+        model.engine.set_option("kv_overlap", 1)
+        outs = [model.inference(b["ids"], b["mel_lengths"], b["text_lengths"], reduction_factor=2, eps=b["eps"]) for _ in range(3)]
+        for mel, ali in outs:
+            assert np.array_equal(mel.numpy(), ref)
+            for k in refa:
+                assert np.array_equal(ali[k].numpy(), refa[k])
+    finally:
+        model.engine.close()

@@ -280,7 +280,8 @@ int vnr_voc_griffin_lim(vnr_handle h, const float *d_S, const float *d_init_angl
  * "prior_inverse" (default 0): Prior.Transformer.inverse = True (/root/reference/modules/prior.py:81-99: every flow of the prior is built
  *    with the flag, and BaseFlow.call / fwd_pass / bwd_pass, flow.py:36-113, swap _forward and _backward).  vnr_prior_sample,
  *    vnr_prior_log_probability, vnr_prior_init, vnr_inference, vnr_elbo_fwd and vnr_init then follow that dispatch (one launch per
- *    operation; neither LJHPS nor DataBakerHPS sets it); vnr_train_step refuses.
+ *    operation; neither LJHPS nor DataBakerHPS sets it), and so does vnr_train_step (round 6: log_probability through the _forward passes
+ *    of coupling, InvertibleLinear and ActNorm, flow.py:223-239,123-135,166-175, with their gradients).
  * "chain_rows64" (default 0): 64-row panels in the chain kernel -- half the workgroups, half the weight stream per row; slower
  * for one batch alone, faster in aggregate when several handles keep batches in flight on one GPU (bench.py --streams).
  * "gemm_wide_tiles" (default 0): the same trade for the tiled GEMM kernel (64x128 workgroup tiles wherever N >= 128).

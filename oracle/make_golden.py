@@ -147,7 +147,15 @@ REF_TRAIN_CASES = {
     # name: (hps factory, B, T_text, T_mel, text_step, mel_step, rf, weight seed)
     "refshim_train_tiny": (tiny_hps, 3, 11, 40, 3, 7, 2, SEED),
     "refshim_train_lj": (lambda: LJHPS, 2, 19, 46, 5, 9, 2, SEED),
+    # Prior.Transformer.inverse = True (prior.py:81,88-99): log_probability then runs the flows' _forward passes (flow.py:91-113) and
+    # init / sample the _backward ones -- the training step through them, by the reference's own Python (round 6)
+    "refshim_train_tiny_inv": (lambda: _inverse(tiny_hps()), 3, 11, 40, 3, 7, 2, SEED),
 }
+
+
+def _inverse(hps):
+    hps.Prior.Transformer.inverse = True
+    return hps
 
 
 def build_ref_train(name):

@@ -232,15 +232,37 @@ class TorchOracle:
         out = torch.cat([zc, zp], -1) if upper else torch.cat([zp, zc], -1)
         return out, logdet
 
-    # prior.py:119-152
+    # flow.py:166-175, 123-135, 223-239: the _forward passes -- what bwd_pass runs when the flows were built with inverse = True
+    def actnorm_forward(self, p, z, lengths):
+        ls = self._g(f"{p}/log_scale")
+        return z * torch.exp(ls) + self._g(f"{p}/bias"), _t(lengths) * ls.sum()
+
+    def invlinear_forward(self, p, z, lengths):
+        W = self._g(f"{p}/weight")
+        return z @ W, _t(lengths) * torch.linalg.slogdet(W)[1]
+
+    def coupling_forward(self, p, upper, z, cond, z_lengths, cond_lengths):
+        half = z.shape[-1] // 2
+        lower_pt, upper_pt = z[..., :half], z[..., half:]
+        zc, zp = (lower_pt, upper_pt) if upper else (upper_pt, lower_pt)
+        log_scale, shift = self.transformer_transform(f"{p}/net", zc, cond, cond_lengths, z_lengths)
+        scale = torch.sigmoid(log_scale + 2.0)
+        zp = scale * zp + shift
+        mask = _t(vn.sequence_mask(z_lengths, z.shape[1])[:, :, None])
+        logdet = (torch.log(scale) * mask).sum((1, 2))
+        out = torch.cat([zc, zp], -1) if upper else torch.cat([zp, zc], -1)
+        return out, logdet
+
+    # prior.py:119-152; BaseFlow.bwd_pass (flow.py:91-113) runs _backward, or _forward when Prior.Transformer.inverse is set (prior.py:81,88-99)
     def prior_log_probability(self, z, cond, z_lengths, cond_lengths):
+        inv = bool(getattr(self.hps.Prior.Transformer, "inverse", False))
         eps = z
         accum = torch.zeros(z.shape[0], dtype=z.dtype)
         for s in reversed(range(self.hps.Prior.Transformer.n_blk)):
             p = f"prior/glow/{s}"
-            eps, ld = self.coupling_backward(f"{p}/2", s % 2 == 0, eps, cond, z_lengths, cond_lengths); accum = accum + ld
-            eps, ld = self.invlinear_backward(f"{p}/1", eps, z_lengths); accum = accum + ld
-            eps, ld = self.actnorm_backward(f"{p}/0", eps, z_lengths); accum = accum + ld
+            eps, ld = (self.coupling_forward if inv else self.coupling_backward)(f"{p}/2", s % 2 == 0, eps, cond, z_lengths, cond_lengths); accum = accum + ld
+            eps, ld = (self.invlinear_forward if inv else self.invlinear_backward)(f"{p}/1", eps, z_lengths); accum = accum + ld
+            eps, ld = (self.actnorm_forward if inv else self.actnorm_backward)(f"{p}/0", eps, z_lengths); accum = accum + ld
         logp = -0.5 * (vn.LOG_2PI + eps ** 2)
         mask = _t(vn.sequence_mask(z_lengths, z.shape[1])[:, :, None])
         return (mask * logp).sum((1, 2)) + accum
@@ -248,6 +270,13 @@ class TorchOracle:
     # flow.py:166-175, 123-135, 223-239 (forward direction = prior.sample) and models.py:199-210
     def prior_sample(self, lengths, cond, cond_lengths, eps):
         z = eps
+        if bool(getattr(self.hps.Prior.Transformer, "inverse", False)):      # BaseFlow.call / fwd_pass swap to the _backward passes (flow.py:36-47,76-90)
+            for s in range(self.hps.Prior.Transformer.n_blk):
+                p = f"prior/glow/{s}"
+                z, _ = self.actnorm_backward(f"{p}/0", z, lengths)
+                z, _ = self.invlinear_backward(f"{p}/1", z, lengths)
+                z, _ = self.coupling_backward(f"{p}/2", s % 2 == 0, z, cond, lengths, cond_lengths)
+            return z
         for s in range(self.hps.Prior.Transformer.n_blk):
             p = f"prior/glow/{s}"
             z = z * torch.exp(self._g(f"{p}/0/log_scale")) + self._g(f"{p}/0/bias")

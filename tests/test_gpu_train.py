@@ -249,19 +249,41 @@ def test_decoder_branch_stays_on_the_main_stream_without_the_stacked_projection(
     assert all(v > 0 for v in a["enc_max"].values())
 
 
-def test_train_step_refuses_inverse_flows_by_name():
-    """Prior.Transformer.inverse = True (/root/reference/modules/flow.py:36-47,76-113, prior.py:88-99; no shipped configuration sets it) is
-    honoured by every inference / evaluation / init entry point (tests/test_b2_surface.py) but not by the training step: the refusal must
-    say so -- an explicit error naming the option, never a silently different gradient."""
-    from vaenar_tts_amd import _lib
-    hps = tiny_hps()
-    m = VAENAR(hps, weights=init_weights(hps, seed=3, mode="synthetic"))
+@pytest.mark.parametrize("name,kw,det", [("tiny", 1.0, 0), ("lj", 1.0, 0), ("lj", 1e-5, 1), ("tiny-mid", 1.0, 1)])
+def test_train_step_through_inverse_flows(name, kw, det):
+    """Prior.Transformer.inverse = True (/root/reference/modules/prior.py:81,88-99; no shipped configuration sets it): every flow of the prior
+    is built with the flag and BaseFlow.bwd_pass -- what TransformerPrior.log_probability calls, prior.py:119-152 -- runs the _FORWARD passes
+    (/root/reference/modules/flow.py:91-113: coupling 223-239, InvertibleLinear 123-135, ActNorm 166-175).  The training step follows (round 6;
+    it refused the option by name before): scalars and ALL gradients against the autograd restatement with the same flag, whose forward is
+    pinned to the NumPy specification and through it to the reference's own flow code (tests/test_oracle_torch.py, tests/golden/refshim_inverse.npz).
+    det = 1: the deterministic mode (ordered sums instead of float atomics) runs the same closures."""
+    import copy
+    hps, w, b, mels, eps = _case(name)
+    hps = copy.deepcopy(hps)                             # (LJHPS is a module-level object)
+    hps.Prior.Transformer.inverse = True
+    model = VAENAR(hps, weights=w)
     try:
-        m.engine.set_option("prior_inverse", 1)
-        b = make_batch(2, 9, 24, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, seed=2, text_step=2, mel_step=5)
-        mels = np.zeros((2, 24, hps.Audio.num_mels), np.float32)
-        with pytest.raises(_lib.VnrError) as ei:
-            m.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, dropout_seed=1)
-        assert "inverse" in str(ei.value).lower()
+        model.engine.set_option("deterministic", det)
+        loss, mel_l2, kl, len_l2 = model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], kw, 2, eps=eps,
+                                                    dropout_seed=11, apply_update=False)
+        got = model.gradients()
+        if det:                                          # bit-reproducible
+            model.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], kw, 2, eps=eps, dropout_seed=11, apply_update=False)
+            again = model.gradients()
+            assert all(np.array_equal(got[k], again[k]) for k in got)
     finally:
-        m.engine.close()
+        model.engine.close()
+    sc, flipped = kinks.compare(got, kinks.torch_oracle_run(hps, w, b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, kw, 11))
+    assert abs(mel_l2 - sc["mel_l2"]) < 2e-5 * max(1, abs(sc["mel_l2"]))
+    assert abs(len_l2 - sc["length_l2"]) < 1e-4 * max(1, abs(sc["length_l2"]))
+    assert abs(kl - sc["kl"]) < 1e-4 * max(1, abs(sc["kl"]))
+    assert abs(loss - sc["loss"]) < 1e-4 * max(1, abs(sc["loss"]))
+    assert len(flipped) <= 3, flipped
+    # the flag changed something: the same step without it has another KL term
+    hps2, w2, b2, mels2, eps2 = _case(name)
+    plain = VAENAR(hps2, weights=w2)
+    try:
+        _, _, kl0, _ = plain.train_step(b2["ids"], mels2, b2["text_lengths"], b2["mel_lengths"], kw, 2, eps=eps2, dropout_seed=11, apply_update=False)
+    finally:
+        plain.engine.close()
+    assert abs(kl0 - kl) > 1e-3 * max(1.0, abs(kl))

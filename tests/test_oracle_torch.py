@@ -30,8 +30,11 @@ def _np_loss(hps, w, b, mels, eps, seed=9, kl_weight=1e-5, length_weight=1.0):
     return float(l2 + kl_weight * max(kl, 0.0) + length_weight * ll), (float(l2), float(kl), float(ll))
 
 
-def test_torch_forward_equals_numpy_oracle():
+@pytest.mark.parametrize("inverse", [False, True])
+def test_torch_forward_equals_numpy_oracle(inverse):
+    """(inverse: Prior.Transformer.inverse = True -- BaseFlow.bwd_pass then runs the _forward passes, /root/reference/modules/flow.py:91-113)"""
     hps, w, b, mels, eps = _case()
+    hps.Prior.Transformer.inverse = inverse
     t = TorchOracle(hps, w)
     loss, mel_l2, kl, ll = t.train_loss(b["ids"], mels, b["mel_lengths"], b["text_lengths"], 2, eps, dropout_seed=9)
     ref, (rl2, rkl, rll) = _np_loss(hps, w, b, mels, eps)
@@ -71,9 +74,11 @@ def test_adam_step_known_answer():
     np.testing.assert_allclose(w["a"], [1.0 - 1e-3, -2.0 + 1e-3], atol=1e-8)
 
 
-def test_torch_inference_equals_numpy_oracle():
+@pytest.mark.parametrize("inverse", [False, True])
+def test_torch_inference_equals_numpy_oracle(inverse):
     """The torch restatement's inference path (the timed CPU baseline of bench.py) against the NumPy specification."""
     hps, w, b, mels, eps = _case()
+    hps.Prior.Transformer.inverse = inverse
     z_eps = np.random.Generator(np.random.PCG64(4)).standard_normal((2, (int(b["mel_lengths"].max()) + 1) // 2, hps.Common.latent_dim))
     ref, _ = Oracle(hps, {k: np.asarray(v, np.float64) for k, v in w.items()}, np.float64).inference(
         b["ids"], b["mel_lengths"], b["text_lengths"], 2, z_eps)

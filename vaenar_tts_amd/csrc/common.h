@@ -363,7 +363,8 @@ struct ChainArgs {
   int pf_wgs;                   // (set by launch_panel_chain) prefetch workgroups appended to the grid
   int vt_lds;                   // (set by launch_panel_chain, waves4 only) byte offset of the V-stage transpose scratch [4 waves][32][33] fp32 in LDS
   int waves4;                   // 1: the one-wave-per-SIMD kernel (gemm3c.hip: 4 waves x 64 columns, 8 k-tiles in flight; 32-row panels only), 0: panel_chain_kernel
-  unsigned* range_flag;         // overflow sentinel of the split path (range_note); null = not watched
+  unsigned* range_flag;         // overflow sentinel of the split path (range_note); NEVER null for a chain launch (the engine always passes its word:
+                                // the 512-register kernel has no room for the null test)
   int prio_mode;                // experiment switch (VNR_CHAIN_PRIO): 0 none, 1 static bump for waves 4..7 (default), 2 alternating per k-tile group, 3 per stage
   ChainStage st[kMaxChainStages];
 };
@@ -520,6 +521,10 @@ hipError_t launch_coupling_inv_bwd(const float* heads, const float* zp_in, float
                                    int T, int half, int zp_off, float* dheads, hipStream_t s);
 hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, const float* bias, int M, int C, double* s_b, double* s_ls, hipStream_t s);
 hipError_t launch_gauss_bwd(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d, hipStream_t s);
+// the same direction of inverse = True flows: the _forward passes (flow.py:223-239, 166-175) -- train_kernels.hip
+hipError_t launch_coupling_fwd_bwd(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len, int M,
+                                   int T, int half, int zp_off, float* dheads, hipStream_t s);
+hipError_t launch_actnorm_fwd_bwd(const float* x, float* dy, const float* ls, int M, int C, double* s_b, double* s_ls, hipStream_t s);
 hipError_t launch_reparam_bwd(const float* dz, const float* eps, const float* logvar, const float* gpost, const int32_t* len, int M,
                               int T, int C, float* dmu, float* dlogvar, hipStream_t s);
 hipError_t launch_l2_bwd(const float* rec, int Tr, const float* tgt, int Tm, const int32_t* len, int B, int C, float seed, float* d, hipStream_t s);

@@ -2384,7 +2384,6 @@ int vnr_train_step(vnr_handle h, const int32_t* d_ids, const int32_t* d_text_len
   if (!h->finalized) return fail(h, VNR_ERR_WEIGHT, "weights not finalized: call vnr_finalize_weights first");
   HIP_TRY(h, hipSetDevice(h->device));
   if (!h->has_posterior) return fail(h, VNR_ERR_WEIGHT, "posterior weights were not loaded");
-  if (h->prior_inverse) return fail(h, VNR_ERR_ARG, "the training step does not cover inverse = True flows (engine option prior_inverse): inference, the ELBO forward and init do");
   if (!d_ids || !d_text_lengths || !d_mel_targets || !d_mel_lengths || !d_reduced_lengths || !d_eps || B <= 0 || Tt <= 0 || Tm <= 0 || rf < 1)
     return fail(h, VNR_ERR_ARG, "bad argument");
   if (h->cfg.num_mels != h->cfg.output_dim) return fail(h, VNR_ERR_ARG, "num_mels must equal output_dim for the L2 loss");

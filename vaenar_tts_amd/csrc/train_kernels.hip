@@ -2420,6 +2420,68 @@ hipError_t launch_actnorm_inv_bwd(const float* x, float* dy, const float* ls, co
   if (det) { hipError_t e = launch_det_finish_dd(det, rb, (size_t)C, s_b, s); return e != hipSuccess ? e : launch_det_finish_dd(det + (size_t)rb * C, rb, (size_t)C, s_ls, s); }
   return hipGetLastError();
 }
+// ---- the same direction with inverse = True flows (prior.py:81,88-99): BaseFlow.bwd_pass runs the _forward passes (flow.py:91-113) -----------
+// coupling _forward (flow.py:223-239; forward arithmetic: misc.hip coupling_fwd_kernel): zp' = sc zp + shift, sc = sigmoid(ls + 2),
+// logdet_b = + sum_{t < len, c} log sc.  Given dz (gradient at the OUTPUT) and g_b = d loss / d logdet_b:
+//   dzp = dzp' sc ; dshift = dzp' ; dsc = dzp' zp + g_b mask_t / sc ; dls = dsc * sc (1 - sc)
+// dz is rewritten in place to the gradient at the INPUT (zp half only); dheads [M][2*half] receives (dls | dshift).
+__global__ void coupling_fwd_bwd_kernel(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len,
+                                        int M, int T, int half, int zp_off, float* dheads) {
+  const size_t n = (size_t)M * half;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / half), c = (int)(i - (size_t)m * half);
+    const int b = m / T, t = m - b * T;
+    const float ls = heads[(size_t)m * 2 * half + c];
+    const float sc = 1.0f / (1.0f + expf(-(ls + 2.0f)));
+    float* dzp = dz + (size_t)m * 2 * half + zp_off + c;
+    const float dout = *dzp;
+    const float mask = t < len[b] ? 1.f : 0.f;
+    const float dsc = dout * zp_in[i] + g_b[b] * mask / sc;
+    *dzp = dout * sc;
+    dheads[(size_t)m * 2 * half + c] = dsc * sc * (1.f - sc);
+    dheads[(size_t)m * 2 * half + half + c] = dout;
+  }
+}
+hipError_t launch_coupling_fwd_bwd(const float* heads, const float* zp_in, float* dz, const float* g_b, const int32_t* len, int M,
+                                   int T, int half, int zp_off, float* dheads, hipStream_t s) {
+  const size_t n = (size_t)M * half;
+  int blocks = (int)((n + 1023) / 1024); if (blocks > 4096) blocks = 4096;
+  vnr_launch(coupling_fwd_bwd_kernel, dim3(blocks), dim3(256), 0, s, heads, zp_in, dz, g_b, len, M, T, half, zp_off, dheads);
+  return hipGetLastError();
+}
+// ActNorm _forward (flow.py:166-175): y = x exp(ls) + bias.  Backward: dx = dy exp(ls) (in place on dy);
+// dbias[c] += sum dy ; dls[c] += sum dy x exp(ls)   [float64 buffers, same finish as actnorm_inv_bwd_kernel]
+__global__ void actnorm_fwd_bwd_kernel(const float* x, float* dy, const float* ls, int M, int C, double* s_b, double* s_ls, double* det) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    const float e = expf(ls[c]);
+    for (int m = blockIdx.y * 4 + rg; m < M; m += gridDim.y * 4) {
+      const size_t i = (size_t)m * C + c;
+      const float d = dy[i];
+      a1 += (double)d;
+      a2 += (double)(d * x[i] * e);
+      dy[i] = d * e;
+    }
+  }
+  __shared__ double p1[4][64], p2[4][64];
+  p1[rg][threadIdx.x & 63] = a1; p2[rg][threadIdx.x & 63] = a2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const double t1 = p1[0][threadIdx.x] + p1[1][threadIdx.x] + p1[2][threadIdx.x] + p1[3][threadIdx.x];
+    const double t2 = p2[0][threadIdx.x] + p2[1][threadIdx.x] + p2[2][threadIdx.x] + p2[3][threadIdx.x];
+    if (det) { det[(size_t)blockIdx.y * C + c] = t1; det[((size_t)gridDim.y + blockIdx.y) * C + c] = t2; }
+    else { atomicAdd(&s_b[c], t1); atomicAdd(&s_ls[c], t2); }
+  }
+}
+hipError_t launch_actnorm_fwd_bwd(const float* x, float* dy, const float* ls, int M, int C, double* s_b, double* s_ls, hipStream_t s) {
+  int rb = (M + 63) / 64; if (rb > 256) rb = 256; if (rb < 1) rb = 1;
+  double* det = static_cast<double*>(det_scratch(s, (size_t)2 * rb * C * sizeof(double)));
+  vnr_launch(actnorm_fwd_bwd_kernel, dim3((C + 63) / 64, rb), dim3(256), 0, s, x, dy, ls, M, C, s_b, s_ls, det);
+  if (det) { hipError_t e = launch_det_finish_dd(det, rb, (size_t)C, s_b, s); return e != hipSuccess ? e : launch_det_finish_dd(det + (size_t)rb * C, rb, (size_t)C, s_ls, s); }
+  return hipGetLastError();
+}
 // d eps = -eps * mask * g_b  (gradient of sum_t mask * -0.5 (log 2pi + eps^2)); written (not accumulated)
 __global__ void gauss_bwd_kernel(const float* eps, const float* g_b, const int32_t* len, int M, int T, int C, float* d) {
   const size_t n = (size_t)M * C;

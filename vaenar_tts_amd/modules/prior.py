@@ -11,8 +11,8 @@ class TransformerPrior(EngineModule):
                  temperature, ffn_hidden, inverse=False, name='GlowPrior', engine=None, **kwargs):
         super().__init__(name, engine)
         # inverse=True (prior.py:88-99: every flow is built with the flag; BaseFlow.call / fwd_pass / bwd_pass, flow.py:36-113, then swap
-        # _forward and _backward): sample / call / init / log_probability, VAENAR.inference and the ELBO forward run that way (engine
-        # option "prior_inverse"); the training step does not cover it.  LJHPS / DataBakerHPS use inverse=False (hparams.py:344,462).
+        # _forward and _backward): sample / call / init / log_probability, VAENAR.inference, the ELBO forward and (round 6) the training
+        # step run that way (engine option "prior_inverse").  LJHPS / DataBakerHPS use inverse=False (hparams.py:344,462).
         self.inverse = bool(inverse)
         if self.inverse:
             self.engine.set_option("prior_inverse", 1)

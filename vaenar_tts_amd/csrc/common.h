@@ -494,6 +494,10 @@ struct WordList { const unsigned* p[64]; int n; };
 hipError_t launch_max_words(const WordList& w, unsigned* out, hipStream_t s);      // *out = max(*out, max_i *w.p[i])
 hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T,
                                  int shift, const unsigned* b_absmax, hipStream_t s);
+// several of them as one launch (train_kernels.hip: gemm_tn3_group_kernel; at most kTnGroupMax jobs, each with the geometry and the bits of its own launch)
+struct TnCall { const float* A; int lda; const float* B; int ldb; float* C; int ldc; int M, K, N, T, shift; const unsigned* b_absmax; };
+constexpr int kTnGroupMax = 8;
+hipError_t launch_gemm_tn_group(const TnCall* calls, int n, hipStream_t s);
 // recomputing ("flash-style") backward: no stored probabilities, no dS in HBM -- P is rebuilt from Q, K and the row statistics
 // the forward call left in row_max / row_linv (AttnArgs), dS lives in registers.  rowdot_ws: scratch [B][H][Tq].
 hipError_t launch_attention_bwd_recompute(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, const float* O, int ldo,

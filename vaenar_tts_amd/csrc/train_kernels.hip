@@ -233,10 +233,10 @@ __device__ __forceinline__ void tn3_barrier() {           // LDS traffic of this
 // a timeline of the unspecialised version (profiles/r02_tn3_timeline.txt) showed one workgroup spending 1.0 kcyc per 32-row tile
 // in the MFMA phase, 0.95 in the conversion / LDS stores and 0.6 issuing the loads, strictly one after the other (all four
 // waves in lock step between barriers), and a second workgroup per CU did not get scheduled beside it.
-__global__ void __launch_bounds__(768)
-gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
-                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det,
-                unsigned* tickets) {
+__device__ __forceinline__ void
+tn3_body(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+         int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det,
+         unsigned* tickets, const int bid) {
   constexpr int TS = 2048 + 64;                            // one 32-column tile of a plane: [2 steps][2 halves][8 rows][32 halves] + pad
   constexpr int PL = 4 * TS;                               // one plane of one stage: 32 rows x 128 halves
   extern __shared__ __attribute__((aligned(16))) char tn3_smem[];      // [2 stages][A hi | A lo | B hi | B lo][PL]
@@ -246,7 +246,7 @@ gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int 
   // id j runs on XCD j % 8: it takes row split 8 g + j % 8 and tile j / 8 -- the nt tiles that re-read the same rows of A and B
   // run on ONE XCD at the same time and share its L2
   const int nt = tk * tn;
-  const int grp = blockIdx.x / (8 * nt), j_in = blockIdx.x - grp * 8 * nt;
+  const int grp = bid / (8 * nt), j_in = bid - grp * 8 * nt;
   const int split = grp * 8 + (j_in & 7), tile = j_in >> 3;
   if (split >= splits) return;
   const int k0 = (tile % tk) * 128, n0 = (tile / tk) * 128;
@@ -254,7 +254,7 @@ gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int 
   int m_hi = m_lo + rows_per_split; if (m_hi > M) m_hi = M;
   const int nsteps = (m_hi - m_lo + 31) / 32;
   // measurement only (VNR_GEMM_TN3_TS): per wave [0] start, then one stamp per phase (see tools/tn3_timeline.py)
-  unsigned long long* ts = dbg_ts ? dbg_ts + ((size_t)blockIdx.x * 12 + wave) * 64 : nullptr;
+  unsigned long long* ts = dbg_ts ? dbg_ts + ((size_t)bid * 12 + wave) * 64 : nullptr;
   int tsi = 1;
   auto stamp = [&]() { if (ts && lane == 0 && tsi < 64) ts[tsi] = __builtin_amdgcn_s_memtime(); ++tsi; };
   if (ts && lane == 0) ts[0] = __builtin_amdgcn_s_memtime();
@@ -528,6 +528,42 @@ gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int 
     }
   }
 }
+__global__ void __launch_bounds__(768)
+gemm_tn3_kernel(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int K, int N, int T, int shift,
+                int rows_per_split, const unsigned* b_absmax, int dbg_out, int tk, int tn, int splits, unsigned long long* dbg_ts, float* det,
+                unsigned* tickets) {
+  tn3_body(A, lda, B, ldb, C, ldc, M, K, N, T, shift, rows_per_split, b_absmax, dbg_out, tk, tn, splits, dbg_ts, det, tickets, (int)blockIdx.x);
+}
+// (round 6) SEVERAL kernel-gradient GEMMs in one launch: workgroups [wg0, wg0 + wgs) of the grid belong to job j and run its body unchanged
+// (same tiles, row splits and partials as its own launch: bit-identical results).  A launch of one job fills 128 workgroup slots of 512
+// -- sized so that the longer row ranges amortise the prologue and the main stream's launches find room beside it -- and pays its fixed
+// cost 292 times a step, twice in deterministic mode (the ordered finish is a launch of its own); a few jobs side by side share both
+// (train.inc: tn_enqueue / tn_flush; deterministic T1 step 21.0 -> 19.1 ms on one box).
+struct Tn3Job { const float* A; const float* B; float* C; const unsigned* b_absmax; float* det; int lda, ldb, ldc, M, K, N, T, shift, rps, tk, tn, splits, wg0; };
+constexpr int kTnGroup = 8;
+struct Tn3Group { Tn3Job job[kTnGroup]; int n, dbg_out; };
+__global__ void __launch_bounds__(768)
+gemm_tn3_group_kernel(const Tn3Group g) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < kTnGroup; ++i) if (i < g.n && (int)blockIdx.x >= g.job[i].wg0) j = i;
+  const Tn3Job& J = g.job[j];
+  tn3_body(J.A, J.lda, J.B, J.ldb, J.C, J.ldc, J.M, J.K, J.N, J.T, J.shift, J.rps, J.b_absmax, g.dbg_out, J.tk, J.tn, J.splits, nullptr, J.det, nullptr,
+           (int)blockIdx.x - J.wg0);
+}
+// the ordered second half of a grouped launch in deterministic mode: blockIdx.y = job (arithmetic of det_finish_2d_kernel)
+struct TnFinJob { const float* part; float* C; int nparts, K, N, ldc; };
+struct TnFinGroup { TnFinJob job[kTnGroup]; int n; };
+__global__ void det_finish_2d_group_kernel(const TnFinGroup g) {
+  const TnFinJob& J = g.job[blockIdx.y];
+  const size_t kn = (size_t)J.K * J.N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < kn; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = J.part[i];
+    for (int p = 1; p < J.nparts; ++p) acc += J.part[(size_t)p * kn + i];
+    const size_t k = i / J.N, n = i - k * J.N;
+    J.C[k * J.ldc + n] += acc;
+  }
+}
 // max |x| over a strided [rows][cols] block (bits of the non-negative float ordered like unsigned ints); *out must be 0.
 // Second generation (round 2): the first version gave a contiguous 13 MB gradient 50 workgroups of one 256 KB pseudo-row each
 // and a 256-column strided view one active wave per workgroup -- 32 us per call, 1500 calls per training step.  Now: a flat
@@ -680,6 +716,63 @@ hipError_t launch_gemm_tn_scaled(const float* A, int lda, const float* B, int ld
   const bool big = force == 2 && K >= 128 && N >= 128 && (long long)((K + 127) / 128) * ((N + 127) / 128) * ((M + 127) / 128) >= 256;
   if (big) return launch_tn_cfg<2, 2>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target / 2, s);
   return launch_tn_cfg<1, 1>(A, lda, B, ldb, C, ldc, M, K, N, T, shift, b_absmax, target, s);
+}
+
+// Several kernel-gradient GEMMs as ONE launch (gemm_tn3_group_kernel) -- every job with the geometry its own launch would have had.
+// Jobs the third-generation kernel does not take, and every job while a measurement / fallback switch is set, go out one by one.
+hipError_t launch_gemm_tn_group(const TnCall* calls, int n, hipStream_t s) {
+  static const bool single = getenv("VNR_TRAIN_SKIP_TN") || getenv("VNR_GEMM_TN_V1") || getenv("VNR_GEMM_TN_V2") || getenv("VNR_GEMM_TN3_TS") ||
+                             getenv("VNR_DET_INKERNEL_FINISH") || getenv("VNR_GEMM_TN_NO_GROUP");
+  static const int target3 = getenv("VNR_GEMM_TN3_WGS") ? atoi(getenv("VNR_GEMM_TN3_WGS")) : 128;
+  static const int min3 = getenv("VNR_GEMM_TN3_MIN") ? atoi(getenv("VNR_GEMM_TN3_MIN")) : 32;
+  static const int dbg_out = getenv("VNR_GEMM_TN3_OUT") ? atoi(getenv("VNR_GEMM_TN3_OUT")) : 0;
+  auto one = [&](const TnCall& c) { return launch_gemm_tn_scaled(c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.K, c.N, c.T, c.shift, c.b_absmax, s); };
+  auto takes3 = [&](const TnCall& c) {
+    return c.K >= min3 && c.N >= min3 && !(c.lda & 3) && !(c.ldb & 3) && !(c.K & 3) && !(c.N & 3) && !((size_t)c.A & 15) && !((size_t)c.B & 15) && c.M >= 256;
+  };
+  Tn3Group g; g.n = 0; g.dbg_out = dbg_out;
+  TnFinGroup f; f.n = 0;
+  size_t det_floats = 0;
+  int wg = 0;
+  for (int i = 0; i < n; ++i) {
+    const TnCall& c = calls[i];
+    if (single || g_train_exact || n < 2 || !takes3(c)) { const hipError_t e = one(c); if (e != hipSuccess) return e; continue; }
+    const int tk = (c.K + 127) / 128, tn = (c.N + 127) / 128;
+    int splits = target3 / (tk * tn); if (splits < 1) splits = 1;
+    int max_splits = c.M / 128; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
+    const int rps = ((c.M + splits - 1) / splits + 127) / 128 * 128;
+    splits = (c.M + rps - 1) / rps;
+    Tn3Job& J = g.job[g.n];
+    J.A = c.A; J.B = c.B; J.C = c.C; J.b_absmax = c.b_absmax; J.det = nullptr; J.lda = c.lda; J.ldb = c.ldb; J.ldc = c.ldc; J.M = c.M; J.K = c.K; J.N = c.N;
+    J.T = c.T > 0 ? c.T : c.M; J.shift = c.shift; J.rps = rps; J.tk = tk; J.tn = tn; J.splits = splits; J.wg0 = wg;
+    wg += (splits + 7) / 8 * 8 * tk * tn;
+    TnFinJob& F = f.job[g.n];
+    F.part = nullptr; F.C = c.C; F.nparts = splits; F.K = c.K; F.N = c.N; F.ldc = c.ldc;
+    det_floats += ((size_t)splits * c.K * c.N + 3) / 4 * 4;
+    ++g.n;
+  }
+  if (g.n == 0) return hipSuccess;
+  if (g.n == 1) {                                             // (the others went out alone)
+    const Tn3Job& J = g.job[0];
+    return launch_gemm_tn_scaled(J.A, J.lda, J.B, J.ldb, J.C, J.ldc, J.M, J.K, J.N, J.T, J.shift, J.b_absmax, s);
+  }
+  float* det = static_cast<float*>(det_scratch(s, det_floats * sizeof(float)));
+  if (det) {
+    size_t off = 0;
+    for (int i = 0; i < g.n; ++i) { g.job[i].det = det + off; f.job[i].part = det + off; off += ((size_t)g.job[i].splits * g.job[i].K * g.job[i].N + 3) / 4 * 4; }
+  }
+  const unsigned lds = 2 * 4 * 4 * (2048 + 64);
+  static int attr3g[kMaxDevices] = {0};
+  opt_in_dynamic_lds((const void*)gemm_tn3_group_kernel, (int)lds, attr3g);
+  vnr_launch(gemm_tn3_group_kernel, dim3((unsigned)wg), dim3(768), lds, s, g);
+  if (det) {
+    f.n = g.n;
+    size_t mx = 0;
+    for (int i = 0; i < g.n; ++i) { const size_t kn = (size_t)g.job[i].K * g.job[i].N; if (kn > mx) mx = kn; }
+    unsigned blocks = (unsigned)((mx + 255) / 256); if (blocks > 512) blocks = 512;
+    vnr_launch(det_finish_2d_group_kernel, dim3(blocks, (unsigned)g.n), dim3(256), 0, s, f);
+  }
+  return hipGetLastError();
 }
 
 // ---- attention backward -----------------------------------------------------------------------------------------------

@@ -249,6 +249,57 @@ def test_decoder_branch_stays_on_the_main_stream_without_the_stacked_projection(
     assert all(v > 0 for v in a["enc_max"].values())
 
 
+_GROUP_CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from vaenar_tts_amd.configs import LJHPS
+from vaenar_tts_amd.models import VAENAR
+from vaenar_tts_amd.synthetic import make_batch
+from vaenar_tts_amd.weights import init_weights
+hps = LJHPS
+w = init_weights(hps, seed=1234, mode="synthetic")
+b = make_batch(2, 12, 528, vocab_size=hps.Encoder.Transformer.vocab_size, latent_dim=hps.Common.latent_dim, ragged=True, text_step=3, mel_step=62)
+r = np.random.Generator(np.random.PCG64(31))
+Tm = int(b["mel_lengths"].max())
+mels = r.standard_normal((2, Tm, hps.Audio.num_mels)).astype(np.float32)
+eps = r.standard_normal((2, (Tm + 1) // 2, hps.Common.latent_dim)).astype(np.float32)
+m = VAENAR(hps, weights=w)
+m.engine.set_option("deterministic", 1)
+n0 = m.engine.launch_count()
+sc = m.train_step(b["ids"], mels, b["text_lengths"], b["mel_lengths"], 1.0, 2, eps=eps, dropout_seed=5, apply_update=False)
+launches = m.engine.launch_count() - n0
+g = m.gradients()
+print(json.dumps({"digests": {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()[:16] for k, v in g.items()}, "launches": launches,
+                  "scalars": [float(x) for x in sc]}))
+m.engine.close()
+"""
+
+
+def test_grouped_kernel_gradient_launches_keep_every_bit():
+    """Round 6: the kernel-gradient GEMMs dW = X^T.dY (one per dense / convolution tap, /root/reference/train.py:127-138 under the tape) leave the
+    training step three at a time as ONE launch (csrc/train_kernels.hip: gemm_tn3_group_kernel; csrc/train.inc: tn_enqueue / tn_flush) -- every job
+    with the tiles, row splits and ordered partials its own launch would have had.  Deterministic mode, LJ widths, 528 latent rows (the
+    third-generation kernel takes M >= 256): every gradient of one job per launch (VNR_GEMM_TN_GROUP=1, rounds 2-5), of the default and of
+    eight per launch is the same, bit for bit -- and the grouped runs really are grouped (fewer launches)."""
+    import json
+    import subprocess
+    import sys
+
+    def child(group):
+        env = dict(os.environ)
+        if group: env["VNR_GEMM_TN_GROUP"] = str(group)
+        else: env.pop("VNR_GEMM_TN_GROUP", None)
+        cp = subprocess.run([sys.executable, "-c", _GROUP_CHILD % ROOT], capture_output=True, text=True, env=env, timeout=900)
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        return json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    one, dflt, eight = child(1), child(0), child(8)
+    assert one["digests"] == dflt["digests"] == eight["digests"]
+    assert one["scalars"] == dflt["scalars"] == eight["scalars"]
+    assert eight["launches"] < dflt["launches"] < one["launches"], (one["launches"], dflt["launches"], eight["launches"])
+    assert one["launches"] - dflt["launches"] >= 100          # (292 jobs: 3 per launch saves ~190 launches)
+
+
 @pytest.mark.parametrize("name,kw,det", [("tiny", 1.0, 0), ("lj", 1.0, 0), ("lj", 1e-5, 1), ("tiny-mid", 1.0, 1)])
 def test_train_step_through_inverse_flows(name, kw, det):
     """Prior.Transformer.inverse = True (/root/reference/modules/prior.py:81,88-99; no shipped configuration sets it): every flow of the prior

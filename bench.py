@@ -743,7 +743,7 @@ def rank_shape_block(args, device, t1):
                 "inference_shard": "S3 (B = 128 over 8 GPUs) gives every rank exactly the S1 batch of the headline line: `ms_per_step` above, no collective",
                 "model": {"assumptions": {"ranks": N, "gradient_bytes": payload, "xgmi_GBps_per_link_direction": link / 1e9, "links_per_gpu": 7,
                                           "ring_allreduce_ms": 1e3 * ring, "direct_rs_ag_ms": 1e3 * direct, "exposed_last_bucket_bytes": last_bucket,
-                                          "note": "a step of 923 launches has a floor of ~9.6 ms whatever the batch (B = 1: 9.6, 4: 9.9, 16: 13.5, 32: 19 ms on one box, "
+                                          "note": "a step of ~730 launches (923 until round 6 grouped the kernel-gradient GEMMs) has a floor of ~9.6 ms whatever the batch (B = 1: 9.6, 4: 9.9, 16: 13.5, 32: 19 ms on one box, "
                                                   "profiles/r05_experiments.txt) and a chain launch lasts as long as one workgroup's walk whatever its grid (DESIGN.md "
                                                   "4.3c): a 4-utterance step is half, not an eighth, of a 32-utterance one -- that bounds the strong-scaled reading"},
                           "strong_scaling_global_B32": strong, "weak_scaling_B32_per_rank": weak,
